@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""Mint golden vectors by RUNNING THE REFERENCE (build container only).
+
+    python tools/mint_golden.py            # writes tests/golden/*.npz
+
+Imports /root/reference/src/model/model.py directly (torch + einops only) and pulls
+the pure functions `get_retrieved_features` / `get_metrics_cirr` out of
+src/eval_utils.py and the brute-force branch of src/trainer.py with `ast`, so the
+import-time file IO of those modules (eval_utils.py:46-57, data.py:56-76) never
+runs.  Weights are NOT stored: they come from the seeded generator
+`oracle.keds_oracle.synth_*_state_dict` (numpy legacy RandomState stream, frozen),
+loaded into the reference modules with `load_state_dict`; a float64 checksum of the
+weights is stored so generator drift is detected.  Only inputs + reference outputs
+are written, as small .npz files.  The reference itself never travels.
+"""
+import ast
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference/src"
+sys.path.insert(0, REF)
+
+from model.model import CLIP, IM2TEXT, CrossFormer  # noqa: E402  (the reference)
+from oracle import keds_oracle as O  # noqa: E402  (only for the seeded generators)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.manual_seed(0)
+torch.set_grad_enabled(False)
+
+
+def extract_function(path, name, namespace):
+    """exec one top-level function of a reference file in `namespace`."""
+    src = open(path).read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name == name:
+            code = compile(ast.Module(body=[node], type_ignores=[]), path, "exec")
+            exec(code, namespace)
+            return namespace[name]
+    raise KeyError(name)
+
+
+def checksum(sd):
+    return float(sum(v.double().sum().item() for v in sd.values()))
+
+
+class FakeFlatL2:
+    """Exact L2 brute force with the Faiss call shape (add / search -> D, I).
+    Stands in for faiss.IndexFlatL2 (not installed; exact by definition)."""
+
+    def __init__(self):
+        self.x = None
+
+    def add(self, x):
+        self.x = np.asarray(x, dtype=np.float64)
+
+    def search(self, q, k):
+        q = np.asarray(q, dtype=np.float64)
+        d = (q * q).sum(1)[:, None] - 2.0 * q @ self.x.T + (self.x * self.x).sum(1)[None, :]
+        idx = np.argsort(d, axis=1, kind="stable")[:, :k]
+        return np.take_along_axis(d, idx, 1).astype(np.float32), idx.astype(np.int64)
+
+
+def tiny_tokens(batch, vocab, star, rs):
+    sot, eot = vocab - 2, vocab - 1
+    out = np.zeros((batch, 77), dtype=np.int64)
+    for b in range(batch):
+        e = 8 + int(rs.randint(0, 33))
+        row = [sot, 20, 21, 22, star, 23] + list(rs.randint(30, 200, size=e - 6)) + [eot]
+        out[b, :len(row)] = row
+    return out
+
+
+def mint_clip(tag, cfg, batch, star):
+    sd = O.synth_clip_state_dict(**cfg, seed=7)
+    heads = cfg["transformer_width"] // 64
+    model = CLIP(cfg["embed_dim"], cfg["image_resolution"], cfg["vision_layers"], cfg["vision_width"],
+                 cfg["vision_patch_size"], cfg["context_length"], cfg["vocab_size"],
+                 cfg["transformer_width"], heads, cfg["transformer_layers"]).eval().float()
+    missing = model.load_state_dict(sd, strict=True)
+    rs = np.random.RandomState(1001)
+    res = cfg["image_resolution"]
+    image = rs.standard_normal((batch, 3, res, res)).astype(np.float32)
+    if cfg["vocab_size"] == 49408:
+        text = O.synth_tokens(batch, seed=4004).numpy()
+    else:
+        text = tiny_tokens(batch, cfg["vocab_size"], star, rs)
+    d = cfg["transformer_width"]
+    tok3 = (rs.standard_normal((batch, 3, d)) * 0.05).astype(np.float32)
+    tok2 = (rs.standard_normal((batch, 2, d)) * 0.05).astype(np.float32)
+    timg, ttxt = torch.from_numpy(image), torch.from_numpy(text)
+    out = {"image": image, "text": text, "tok3": tok3, "tok2": tok2, "star": np.int64(star),
+           "weights_checksum": np.float64(checksum(sd))}
+    feat, mids = model.encode_image(timg, mid_feature=True)
+    out["encode_image"] = feat.numpy()
+    out["block_cls"] = np.stack([m[:, 0, :].numpy() for m in mids])        # [layers,B,width]
+    if cfg["vision_layers"] <= 2:
+        out["block_tokens"] = np.stack([m.numpy() for m in mids])
+    out["encode_text"] = model.encode_text(ttxt).numpy()
+    out["eti3"] = model.encode_text_img_retrieval(ttxt, torch.from_numpy(tok3), split_ind=star, repeat=False).numpy()
+    out["eti2"] = model.encode_text_img_retrieval(ttxt, torch.from_numpy(tok2), split_ind=star, repeat=False).numpy()
+    out["eti3_repeat"] = model.encode_text_img_retrieval(ttxt[:1], torch.from_numpy(tok3), split_ind=star,
+                                                         repeat=True).numpy()
+    i_n, t_n, scale = model(timg, ttxt)
+    out["forward_image"], out["forward_text"], out["forward_scale"] = i_n.numpy(), t_n.numpy(), scale.numpy()
+    np.savez_compressed(os.path.join(OUT, f"clip_{tag}.npz"), **out)
+    print(f"clip_{tag}: ok", {k: v.shape for k, v in out.items() if hasattr(v, 'shape')})
+    return model, sd, timg, ttxt
+
+
+def mint_knowledge(dim, middle, batch=5, k=16):
+    sd_i = O.synth_im2text_state_dict(dim, middle, dim, 2, seed=11, tag="i2t")
+    sd_f = O.synth_crossformer_state_dict(dim, 3, seed=12, tag="fuse")
+    i2t = IM2TEXT(embed_dim=dim, middle_dim=middle, output_dim=dim, n_layer=2).eval()
+    i2t.load_state_dict(sd_i, strict=True)
+    xf = CrossFormer(q_dim=dim, k_dim=dim, v_dim=dim, num_layers=3).eval()
+    xf.load_state_dict(sd_f, strict=True)
+    rs = np.random.RandomState(55)
+    x = rs.standard_normal((batch, dim)).astype(np.float32)
+    nb = rs.standard_normal((batch, k, dim)).astype(np.float32)
+    y = i2t(torch.from_numpy(x))
+    ynb = i2t(torch.from_numpy(nb))
+    z = xf(y.unsqueeze(1), ynb, ynb)
+    np.savez_compressed(os.path.join(OUT, f"knowledge_d{dim}.npz"), x=x, nb=nb, im2text_x=y.numpy(),
+                        im2text_nb=ynb.numpy(), crossformer=z.numpy(),
+                        weights_checksum=np.float64(checksum(sd_i) + checksum(sd_f)))
+    print("knowledge: ok")
+
+
+def mint_cirr_batch(model, sd_clip, timg, ttxt, star, dim, middle):
+    """Per-batch body of evaluate_cirr (eval_utils.py:652-714) driven through the
+    reference's own modules and its own get_retrieved_features."""
+    ns = {"torch": torch, "np": np}
+    grf = extract_function(os.path.join(REF, "eval_utils.py"), "get_retrieved_features", ns)
+    n_db = 2048
+    image_base = O.synth_database(n_db, dim, seed=2002)
+    text_base = O.synth_database(n_db, dim, seed=2003)
+    ii, ti = FakeFlatL2(), FakeFlatL2()
+    ii.add(image_base.numpy())
+    ti.add(text_base.numpy())
+    database = [image_base, text_base, [str(i) for i in range(n_db)], ii, ti]
+
+    def stream(seed):
+        sds = (O.synth_im2text_state_dict(dim, middle, dim, 2, seed=seed, tag="i2t"),
+               O.synth_crossformer_state_dict(dim, 3, seed=seed, tag="fuse"),
+               O.synth_crossformer_state_dict(dim, 3, seed=seed, tag="cond"))
+        a = IM2TEXT(embed_dim=dim, middle_dim=middle, output_dim=dim, n_layer=2).eval()
+        b = CrossFormer(q_dim=dim, k_dim=dim, v_dim=dim, num_layers=3).eval()
+        c = CrossFormer(q_dim=dim, k_dim=dim, v_dim=dim, num_layers=3).eval()
+        a.load_state_dict(sds[0]); b.load_state_dict(sds[1]); c.load_state_dict(sds[2])
+        return a, b, c
+
+    img2text, retrieval_fuse, text_condition = stream(21)
+    img2text_tb, retrieval_fuse_tb, text_condition_tb = stream(22)
+    m = model
+    # ---- eval_utils.py:654-695, statement for statement, on the reference objects ----
+    query_image_features = m.encode_image(timg)
+    topk_image, topk_text = grf(query_image_features, database, None)
+    mapped_features = img2text(query_image_features)
+    topk_image_features = img2text(topk_image)
+    topk_text_features = img2text(topk_text)
+    fused_features = retrieval_fuse(mapped_features.unsqueeze(1), topk_image_features, topk_image_features)
+    text_conditioned = text_condition(mapped_features.unsqueeze(1), topk_text_features, topk_text_features)
+    fused_features = torch.cat([fused_features, text_conditioned, mapped_features.unsqueeze(1)], dim=1)
+    composed_feature = m.encode_text_img_retrieval(ttxt, fused_features, split_ind=star, repeat=False)
+    mapped_features_tb = img2text_tb(query_image_features)
+    topk_image_features_tb = img2text_tb(topk_image)
+    topk_text_features_tb = img2text_tb(topk_text)
+    fused_features_tb = retrieval_fuse_tb(mapped_features_tb.unsqueeze(1), topk_image_features_tb, topk_image_features_tb)
+    text_conditioned_tb = text_condition_tb(mapped_features_tb.unsqueeze(1), topk_text_features_tb, topk_text_features_tb)
+    fused_features_tb = torch.cat([fused_features_tb, text_conditioned_tb, mapped_features_tb.unsqueeze(1)], dim=1)
+    composed_feature_tb = m.encode_text_img_retrieval(ttxt, fused_features_tb, split_ind=star, repeat=False)
+    # ---- eval_utils.py:698-710 ----
+    query_image_features = composed_feature_tb
+    query_image_features = query_image_features / query_image_features.norm(dim=-1, keepdim=True)
+    composed_feature = composed_feature / composed_feature.norm(dim=-1, keepdim=True)
+    mixture_features = 0.5 * query_image_features + 0.5 * composed_feature
+    mixture_features = mixture_features / mixture_features.norm(dim=-1, keepdim=True)
+    np.savez_compressed(os.path.join(OUT, "cirr_batch_tiny.npz"),
+                        composed=composed_feature.numpy(), image=query_image_features.numpy(),
+                        mixture=mixture_features.numpy(),
+                        tokens_image_stream=fused_features.numpy(), tokens_text_stream=fused_features_tb.numpy(),
+                        topk_image_sorted=np.sort(topk_image.numpy(), axis=1),
+                        topk_text=topk_text.numpy(), n_db=np.int64(n_db))
+    print("cirr_batch: ok")
+
+
+def mint_search():
+    """The reference's own brute-force statement (trainer.py:232-257, use_faiss=False)."""
+    ns = {"torch": torch, "np": np}
+    grf = extract_function(os.path.join(REF, "trainer.py"), "get_retrieved_features", ns)
+    dim, n = 64, 3000
+    image_base = O.synth_database(n, dim, seed=31)
+    text_base = O.synth_database(n, dim, seed=32, clustered=True, n_centroids=64)
+    q = O.synth_database(9, dim, seed=33)
+    ti, tt = grf(q, [image_base, text_base], None, topk=16, use_faiss=False)
+    fa, fb = FakeFlatL2(), FakeFlatL2()
+    fa.add(image_base.numpy()); fb.add(text_base.numpy())
+    Da, Ia = fa.search(q.numpy(), 16)
+    Db, Ib = fb.search(q.numpy(), 16)
+    # unit-norm rows: inner-product order == L2 order; check the fake index against the reference here
+    assert np.array_equal(ti.numpy(), image_base.numpy()[Ia.reshape(-1)].reshape(9, 16, dim))
+    assert np.array_equal(tt.numpy(), text_base.numpy()[Ib.reshape(-1)].reshape(9, 16, dim))
+    np.savez_compressed(os.path.join(OUT, "search_small.npz"), q=q.numpy(), topk_image=ti.numpy(),
+                        topk_text=tt.numpy(), I_image=Ia, I_text=Ib, D_image=Da, D_text=Db)
+    print("search: ok")
+
+
+def mint_metrics():
+    ns = {"torch": torch, "np": np, "os": os}
+    gm = extract_function(os.path.join(REF, "eval_utils.py"), "get_metrics_cirr", ns)
+    rs = np.random.RandomState(77)
+    G, Q, dim = 300, 40, 32
+    gallery = O.l2_normalize(torch.from_numpy(rs.standard_normal((G, dim)).astype(np.float32)))
+    index_names = [f"/data/cirr/dev/img_{i:05d}.png" for i in range(G)]
+    ref_idx = rs.randint(0, G, size=Q)
+    tgt_idx = (ref_idx + 1 + rs.randint(0, G - 1, size=Q)) % G
+    ref_feats = O.l2_normalize(gallery[tgt_idx] + 0.9 * torch.from_numpy(rs.standard_normal((Q, dim)).astype(np.float32)) / np.sqrt(dim) * 3)
+    reference_names = [os.path.basename(index_names[i]) for i in ref_idx]
+    target_names = [os.path.basename(index_names[i]) for i in tgt_idx]
+    metrics = gm(gallery, ref_feats, np.array(reference_names), np.array(index_names), np.array(target_names))
+    np.savez_compressed(os.path.join(OUT, "metrics_cirr.npz"), gallery=gallery.numpy(), ref=ref_feats.numpy(),
+                        ref_idx=ref_idx, tgt_idx=tgt_idx,
+                        **{k.replace("@", "_at_"): np.float64(v) for k, v in metrics.items()})
+    print("metrics:", metrics)
+
+
+TINY = dict(embed_dim=128, image_resolution=56, vision_layers=2, vision_width=128, vision_patch_size=14,
+            context_length=77, vocab_size=512, transformer_width=128, transformer_layers=2)
+VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
+            context_length=77, vocab_size=49408, transformer_width=768, transformer_layers=12)
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["tiny", "knowledge", "cirr", "search", "metrics", "vitl"]
+    model = None
+    if "tiny" in which or "cirr" in which:
+        model, sd, timg, ttxt = mint_clip("tiny", TINY, batch=4, star=265)
+    if "knowledge" in which:
+        mint_knowledge(128, 64)
+        mint_knowledge(768, 512, batch=3)
+    if "cirr" in which:
+        mint_cirr_batch(model, sd, timg, ttxt, 265, 128, 64)
+    if "search" in which:
+        mint_search()
+    if "metrics" in which:
+        mint_metrics()
+    if "vitl" in which:
+        mint_clip("vitl14", VITL, batch=2, star=265)
