@@ -1,0 +1,263 @@
+/*
+ * keds_hip.h -- C ABI of libkeds_hip.so: the MI355X (gfx950) retrieval hot path of KEDs.
+ *
+ * The reference (suoych/KEDs) has no FFI seam: its seam is the Python object API
+ * (SURVEY.md section 8b).  The Python facade in keds_amd/ keeps that API and binds the
+ * functions below with ctypes; each entry point names the reference code it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns every buffer (inputs, outputs, workspaces); the library never
+ *     allocates, frees or synchronises, so every call is capturable in a hipGraph;
+ *   - all launches go to the `stream` argument (a hipStream_t passed as void*);
+ *   - return 0 on success, a negative KEDS_E_* code otherwise; keds_last_error()
+ *     returns a thread-local message for the last failure;
+ *   - bf16 tensors are raw 16-bit patterns (uint16_t), row-major, innermost dim contiguous.
+ */
+#ifndef KEDS_HIP_H
+#define KEDS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KEDS_OK 0
+#define KEDS_E_ARG (-1)      /* bad argument / unsupported shape */
+#define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
+#define KEDS_E_WORKSPACE (-3)/* workspace too small */
+
+#define KEDS_ABI_VERSION 1
+
+int keds_abi_version(void);
+const char* keds_last_error(void);
+
+/* ---- profiling of kernel classes with hipEvents on the launch stream -------------
+ * bench.py switches this on over its timed region to get the dominant kernel's average
+ * launch duration (roofline.achieved).  Classes: see KEDS_PROF_*. */
+#define KEDS_PROF_GEMM 0
+#define KEDS_PROF_ATTN 1
+#define KEDS_PROF_SCAN 2
+#define KEDS_PROF_LN 3
+#define KEDS_PROF_OTHER 4
+#define KEDS_PROF_NCLASS 5
+int keds_prof_enable(int on);                 /* 1: record an event pair around every launch */
+int keds_prof_reset(void);
+int keds_prof_read(int klass, double* total_ms, int64_t* launches);  /* synchronises the events */
+
+/* =====================================================================================
+ * 1. Similarity + top-k  (replaces faiss.IndexFlatL2 + index_cpu_to_all_gpus + .add/.search,
+ *    src/eval_retrieval.py:289-298, src/eval_utils.py:169,177; brute-force twin
+ *    src/trainer.py:246-257)
+ * ===================================================================================== */
+#define KEDS_METRIC_L2 0   /* D = ||q - x||^2 ascending (IndexFlatL2) */
+#define KEDS_METRIC_IP 1   /* D = q . x descending (trainer.py:246-249) */
+
+#define KEDS_SCAN_STAGE_KEYS 32     /* keys per packed stage */
+#define KEDS_SCAN_MAX_QUERIES 128   /* queries per scan launch (one query block) */
+#define KEDS_SCAN_LIST 16           /* per-lane exact list depth == max k of the fast path */
+#define KEDS_SCAN_CAND 64           /* candidates re-ranked in fp32 per query */
+
+/* bytes of the packed bf16 scan image for n rows of dimension dim (dim % 128 == 0) */
+size_t keds_index_packed_bytes(int64_t n, int dim);
+
+/* `.add`: build the scan image from fp32 rows [n, dim] (device).  The image is the exact
+ * LDS layout the scan kernel streams: per stage of 32 keys, XOR-swizzled bf16 rows followed
+ * by 32 fp32 bias terms (-0.5*||x||^2 for L2, 0 for IP; -inf for rows >= n). */
+int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream);
+
+/* workspace bytes for keds_index_search with up to `nq` queries */
+size_t keds_index_search_workspace_bytes(int nq, int dim);
+
+/* `.search`: exact top-k (k <= 16) of nq fp32 queries [nq, dim] against the index.
+ *   normalize_q != 0 : L2-normalise the queries first (src/eval_utils.py:162)
+ *   D [nq,k] fp32, I [nq,k] int64 (row ids offset by id_base, -1 if fewer than k rows)
+ *   rows_out (nullable) [nq,k,dim] fp32 : gathered rows db[I]  (src/eval_utils.py:171-172,179-180)
+ * Pipeline: bf16 MFMA scan with per-lane exact top-16 lists -> merge to 64 candidates ->
+ * exact fp32 re-rank from `db` -> top-k.  `db` is the fp32 matrix given to keds_index_pack. */
+int keds_index_search(const void* packed, const float* db, int64_t n, int dim, int metric,
+                      const float* queries, int nq, int normalize_q, int k, int64_t id_base,
+                      float* D, int64_t* I, float* rows_out,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* merge `parts` partial results [parts, nq, k] (each sorted) into the global top-k
+ * (multi-GPU: after the all-gather of per-shard results).  Keyed on (D, I). */
+int keds_topk_merge_parts(const float* D_parts, const int64_t* I_parts, int parts, int nq, int k,
+                          int metric, float* D, int64_t* I, void* stream);
+
+/* out[i,:] = db[idx[i],:]  (idx < 0 gives zeros) */
+int keds_gather_rows(const float* db, int dim, const int64_t* idx, int64_t count, float* out, void* stream);
+
+/* full gallery ranking for the recall metric (src/eval_utils.py:1040-1067):
+ * order[q,:] = stable argsort of (1 - ref[q] . gallery[g]) ascending; G <= 8192. */
+size_t keds_rank_gallery_workspace_bytes(int nq, int ng);
+int keds_rank_gallery(const float* ref, int nq, const float* gallery, int ng, int dim,
+                      int32_t* order, void* workspace, size_t workspace_bytes, void* stream);
+
+/* recall hits from a ranking with the reference image removed (eval_utils.py:1050-1065):
+ * names are integer ids (basename-interned on the host).  rank_out[q] = position of target
+ * id in order[q] after removing ref_id[q]; -1 if absent. */
+int keds_cirr_target_rank(const int32_t* order, int nq, int ng, const int32_t* gallery_ids,
+                          const int32_t* ref_ids, const int32_t* target_ids, int32_t* rank_out,
+                          int32_t* counts_out /* nullable [nq,2]: reference matches, target matches */,
+                          void* stream);
+
+/* =====================================================================================
+ * 2. Encoder primitives (src/model/model.py:291-326).  bf16 GEMM inputs, fp32 accumulate,
+ *    fp32 residual stream, fp32 LayerNorm / softmax statistics.
+ * ===================================================================================== */
+#define KEDS_EPI_BIAS_BF16 0        /* out bf16 = acc + bias */
+#define KEDS_EPI_BIAS_QGELU_BF16 1  /* out bf16 = qgelu(acc + bias)          (model.py:300-302,311-315) */
+#define KEDS_EPI_BIAS_RELU_BF16 2   /* out bf16 = relu(acc + bias)           (IM2TEXT, model.py:112-116) */
+#define KEDS_EPI_BIAS_RESID_F32 3   /* out f32 += acc + bias (in place)      (model.py:324-325) */
+#define KEDS_EPI_BIAS_F32 4         /* out f32 = acc + bias */
+#define KEDS_EPI_PATCH_F32 5        /* out f32 row (m/G)*(G+1)+1+m%G = acc + aux[1+m%G]  (model.py:394-398) */
+
+/* out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W bf16 row-major (W is the nn.Linear
+ * weight as stored).  N % 128 == 0, K % 64 == 0; rows of A / out up to the next multiple of
+ * 128 above M must be addressable (workspaces are allocated padded).  `bias` may be NULL.
+ * aux: EPI_PATCH: fp32 positional embedding [G+1, N], aux_i = G (patches per image). */
+int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                 int epilogue, const float* aux, int aux_i, void* stream);
+
+/* y = LayerNorm(x) * gamma + beta over the last dim (fp32 statistics, eps 1e-5).
+ * x fp32 [rows, dim] with row stride x_stride (elements); out bf16 (out_f32 == 0) or fp32,
+ * dense [rows, dim].  dim % 256 == 0 or dim == 128; dim <= 2048. */
+int keds_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta,
+                   void* out, int out_f32, int rows, int dim, void* stream);
+
+/* multi-head self attention core on a packed qkv buffer (nn.MultiheadAttention,
+ * model.py:309,319-321): qkv bf16 [B*S, 3*d] (q | k | v, head h at columns h*64),
+ * out bf16 [B*S, d] = softmax(q k^T / 8 [+ causal mask, model.py:543-549]) v.  dh = 64,
+ * S <= 288. */
+int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream);
+
+/* patch im2col for conv1 (model.py:381,394-396): image fp32 [B,3,R,R] -> bf16 [B*G, Kpad],
+ * column c*P*P + ky*P + kx, zero padded to Kpad (a multiple of 64). */
+int keds_im2col(const float* image, void* out, int B, int R, int P, int Kpad, void* stream);
+
+/* token embedding + optional pseudo-token splice + positional embedding
+ * (model.py:579-581, 817-837): x fp32 [B, L, d].
+ *   tokens int32 [B,L]; table bf16/fp32?  -> fp32 table [vocab, d]
+ *   img_tokens (nullable) fp32 [B, n_tok, d] replaces column `insert_col`, the tail is shifted
+ *   right by n_tok-1 and truncated to L. */
+int keds_embed_tokens(const int32_t* tokens, const float* table, const float* pos,
+                      const float* img_tokens, int n_tok, int insert_col,
+                      float* x, int B, int L, int d, void* stream);
+
+/* read-out: out[b,:] = LayerNorm(x[b*S + row[b], :]) . proj  (+ optional L2 normalisation)
+ * (model.py:412-414, 586-589, 841-849).  proj_t bf16 [E, d] (the projection transposed),
+ * row int32 [B] (NULL: row 0, the CLS token).  out fp32 [B, E]. */
+int keds_readout(const float* x, int S, const int32_t* row, const float* gamma, const float* beta,
+                 const void* proj_t, float* out, int B, int d, int E, int normalize,
+                 void* workspace, size_t workspace_bytes, void* stream);
+size_t keds_readout_workspace_bytes(int B, int d);
+
+/* rows /= ||row||  (eval_utils.py:162,704-710);  out may alias x */
+int keds_l2_normalize(const float* x, float* out, int rows, int dim, void* stream);
+/* out = normalize(wa * normalize(a) + wb * normalize(b))  (eval_utils.py:704-710) */
+int keds_mix_normalize(const float* a, const float* b, float wa, float wb,
+                       float* a_n, float* b_n, float* mix, int rows, int dim, void* stream);
+/* fp32 -> bf16 cast (weight packing, model.py:927-948 stand-in) */
+int keds_cast_bf16(const float* x, void* out, int64_t count, void* stream);
+
+/* =====================================================================================
+ * 3. Whole towers
+ * ===================================================================================== */
+typedef struct {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;     /* fp32 [d] */
+    const void *qkv_w, *out_w, *fc_w, *proj_w;      /* bf16 [3d,d] [d,d] [4d,d] [d,4d] */
+    const float *qkv_b, *out_b, *fc_b, *proj_b;     /* fp32 */
+} keds_block_params;
+
+typedef struct {
+    int width, layers, heads, seq;                  /* seq = tokens per sample (257 / 77) */
+    int causal;
+    const keds_block_params* blocks;                /* HOST array [layers] of device pointers */
+} keds_tower_params;
+
+typedef struct {
+    keds_tower_params tower;
+    int resolution, patch, kpad, embed_dim;
+    const void* conv_w;                             /* bf16 [width, kpad] (im2col order, zero padded) */
+    const float *class_emb, *pos_emb;               /* fp32 [width], [G+1, width] */
+    const float *ln_pre_g, *ln_pre_b, *ln_post_g, *ln_post_b;
+    const void* proj_t;                             /* bf16 [embed_dim, width] */
+} keds_vit_params;
+
+typedef struct {
+    keds_tower_params tower;
+    int vocab, embed_dim;
+    const float *token_emb, *pos_emb;               /* fp32 [vocab,d], [L,d] */
+    const float *ln_final_g, *ln_final_b;
+    const void* proj_t;                             /* bf16 [embed_dim, d] */
+} keds_text_params;
+
+size_t keds_tower_workspace_bytes(int width, int seq, int B);
+
+/* x fp32 [B*seq (padded to 128), width] in place through all residual blocks (model.py:372-373) */
+int keds_tower_forward(const keds_tower_params* p, float* x, int B,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* CLIP.encode_image (model.py:569-575,393-415): image fp32 [B,3,R,R] -> out fp32 [B, embed_dim] */
+size_t keds_vit_workspace_bytes(const keds_vit_params* p, int B);
+int keds_vit_forward(const keds_vit_params* p, const float* image, int B, float* out, int normalize,
+                     void* workspace, size_t workspace_bytes, void* stream);
+
+/* CLIP.encode_text / encode_text_img_retrieval (model.py:577-590, 808-851):
+ * tokens int32 [B,L]; readout_row int32 [B]; img_tokens nullable fp32 [B,n_tok,d]. */
+size_t keds_text_workspace_bytes(const keds_text_params* p, int B);
+int keds_text_forward(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
+                      const float* img_tokens, int n_tok, int insert_col, int B, float* out, int normalize,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
+/* =====================================================================================
+ * 4. Knowledge injection (IM2TEXT + 2 x CrossFormer, model.py:37-123, eval_utils.py:661-672)
+ * ===================================================================================== */
+typedef struct {
+    const void *wq, *wk, *wv, *wo;                  /* bf16 [inner,dim] x3, [dim,inner] */
+    const float *bq, *bk, *bv, *bo;
+} keds_cross_layer_params;
+
+typedef struct {                                    /* IM2TEXT: dim_in -> middle (x n_layer, ReLU) -> dim_out */
+    int dim_in, middle, dim_out, n_layer;
+    const void* w[4]; const float* b[4];            /* bf16 [middle, in] / fp32 [middle] per hidden layer */
+    const void* out_w; const float* out_b;          /* bf16 [dim_out, middle] */
+} keds_im2text_params;
+
+typedef struct {                                    /* CrossFormer: `layers` chained CrossAttention layers */
+    int dim, heads, layers;                         /* dim_head = 64, inner = heads*64 */
+    const keds_cross_layer_params* layer;           /* HOST array [layers] of device pointers */
+} keds_crossformer_params;
+
+typedef struct {
+    keds_im2text_params i2t;
+    keds_crossformer_params fuse, cond;             /* retrieval_fuse, text_condition */
+} keds_knowledge_params;
+
+/* IM2TEXT.forward (model.py:120-123): x fp32 [rows, dim_in] -> out fp32 [rows, dim_out] */
+size_t keds_im2text_workspace_bytes(const keds_im2text_params* p, int rows);
+int keds_im2text_forward(const keds_im2text_params* p, const float* x, int rows, float* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* CrossFormer.forward (model.py:98-101) for single-query attention: q fp32 [B,dim],
+ * k, v fp32 [B,K,dim] (K <= 32; v may alias k) -> out fp32 [B,dim] */
+size_t keds_crossformer_workspace_bytes(const keds_crossformer_params* p, int B, int K);
+int keds_crossformer_forward(const keds_crossformer_params* p, const float* q, const float* k, const float* v,
+                             int B, int K, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+size_t keds_knowledge_workspace_bytes(const keds_knowledge_params* p, int B, int K);
+/* one stream of eval_utils.py:661-672: q [B,dim] fp32, nbr_img / nbr_txt [B,K,dim] fp32 ->
+ * tokens_out [B,3,dim] fp32 = [retrieval_fuse(m, I, I), text_condition(m, T, T), m], m = img2text(q),
+ * I = img2text(nbr_img), T = img2text(nbr_txt) */
+int keds_knowledge_forward(const keds_knowledge_params* p, const float* q, const float* nbr_img,
+                           const float* nbr_txt, int B, int K, float* tokens_out,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KEDS_HIP_H */

@@ -1,0 +1,17 @@
+"""keds_amd -- MI355X-native retrieval hot path of KEDs (suoych/KEDs) behind the reference's model API.
+
+    from keds_amd import CLIP, IM2TEXT, CrossFormer, build_model, FlatIndex, IndexFlatL2
+
+Python here is the host side only (parameter containers, argument checks, torch device memory and
+torch.distributed); all compute runs in hand-written gfx950 kernels in csrc/libkeds_hip.so.
+"""
+from ._lib import LIB_PATH, build as build_library, load as load_library   # noqa: F401
+from .index import (FlatIndex, IndexFlatIP, IndexFlatL2, ShardedFlatIndex, index_cpu_to_all_gpus,   # noqa: F401
+                    merge_partials, shard_bounds)
+from .model import (CLIP, CrossAttention, CrossFormer, IM2TEXT, KnowledgeStream, LayerNorm, QuickGELU,   # noqa: F401
+                    ResidualAttentionBlock, Transformer, VisualTransformer, build_model,
+                    clip_config_from_state_dict, convert_models_to_fp32, convert_weights)
+from .retrieval import (build_database, compose_query_features, get_metrics_cirr, get_retrieved_features,   # noqa: F401
+                        load_checkpoint, make_stream_modules)
+
+__version__ = "0.1.0"

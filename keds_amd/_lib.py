@@ -1,0 +1,193 @@
+"""ctypes binding of libkeds_hip.so (the C ABI declared in include/keds_hip.h).
+
+There is no CPU fallback anywhere in this package: if the shared library is missing
+or a call fails, a RuntimeError is raised.  Torch is used only for device memory,
+streams and torch.distributed.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
+
+# ---- constants mirrored from keds_hip.h ------------------------------------------------------
+ABI_VERSION = 1
+METRIC_L2, METRIC_IP = 0, 1
+EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
+PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
+SCAN_MAX_K = 16
+
+vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+
+
+class BlockParams(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "out_w", "fc_w", "proj_w",
+                                  "qkv_b", "out_b", "fc_b", "proj_b")]
+
+
+class TowerParams(C.Structure):
+    _fields_ = [("width", i32), ("layers", i32), ("heads", i32), ("seq", i32), ("causal", i32),
+                ("blocks", C.POINTER(BlockParams))]
+
+
+class VitParams(C.Structure):
+    _fields_ = [("tower", TowerParams), ("resolution", i32), ("patch", i32), ("kpad", i32), ("embed_dim", i32),
+                ("conv_w", vp), ("class_emb", vp), ("pos_emb", vp), ("ln_pre_g", vp), ("ln_pre_b", vp),
+                ("ln_post_g", vp), ("ln_post_b", vp), ("proj_t", vp)]
+
+
+class TextParams(C.Structure):
+    _fields_ = [("tower", TowerParams), ("vocab", i32), ("embed_dim", i32), ("token_emb", vp), ("pos_emb", vp),
+                ("ln_final_g", vp), ("ln_final_b", vp), ("proj_t", vp)]
+
+
+class CrossLayerParams(C.Structure):
+    _fields_ = [(n, vp) for n in ("wq", "wk", "wv", "wo", "bq", "bk", "bv", "bo")]
+
+
+class Im2TextParams(C.Structure):
+    _fields_ = [("dim_in", i32), ("middle", i32), ("dim_out", i32), ("n_layer", i32), ("w", vp * 4), ("b", vp * 4),
+                ("out_w", vp), ("out_b", vp)]
+
+
+class CrossFormerParams(C.Structure):
+    _fields_ = [("dim", i32), ("heads", i32), ("layers", i32), ("layer", C.POINTER(CrossLayerParams))]
+
+
+class KnowledgeParams(C.Structure):
+    _fields_ = [("i2t", Im2TextParams), ("fuse", CrossFormerParams), ("cond", CrossFormerParams)]
+
+
+# name -> (restype, argtypes).  Every symbol of include/keds_hip.h is listed; tests check the set.
+SIGNATURES = {
+    "keds_abi_version": (i32, []),
+    "keds_last_error": (C.c_char_p, []),
+    "keds_prof_enable": (i32, [i32]),
+    "keds_prof_reset": (i32, []),
+    "keds_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(i64)]),
+    "keds_index_packed_bytes": (sz, [i64, i32]),
+    "keds_index_pack": (i32, [vp, i64, i32, i32, vp, vp]),
+    "keds_index_search_workspace_bytes": (sz, [i32, i32]),
+    "keds_index_search": (i32, [vp, vp, i64, i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, sz, vp]),
+    "keds_topk_merge_parts": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "keds_gather_rows": (i32, [vp, i32, vp, i64, vp, vp]),
+    "keds_rank_gallery_workspace_bytes": (sz, [i32, i32]),
+    "keds_rank_gallery": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
+    "keds_cirr_target_rank": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
+    "keds_attention": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "keds_im2col": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "keds_embed_tokens": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),
+    "keds_readout_workspace_bytes": (sz, [i32, i32]),
+    "keds_readout": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, sz, vp]),
+    "keds_l2_normalize": (i32, [vp, vp, i32, i32, vp]),
+    "keds_mix_normalize": (i32, [vp, vp, f32, f32, vp, vp, vp, i32, i32, vp]),
+    "keds_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "keds_tower_workspace_bytes": (sz, [i32, i32, i32]),
+    "keds_tower_forward": (i32, [C.POINTER(TowerParams), vp, i32, vp, sz, vp]),
+    "keds_vit_workspace_bytes": (sz, [C.POINTER(VitParams), i32]),
+    "keds_vit_forward": (i32, [C.POINTER(VitParams), vp, i32, vp, i32, vp, sz, vp]),
+    "keds_text_workspace_bytes": (sz, [C.POINTER(TextParams), i32]),
+    "keds_text_forward": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "keds_im2text_workspace_bytes": (sz, [C.POINTER(Im2TextParams), i32]),
+    "keds_im2text_forward": (i32, [C.POINTER(Im2TextParams), vp, i32, vp, vp, sz, vp]),
+    "keds_crossformer_workspace_bytes": (sz, [C.POINTER(CrossFormerParams), i32, i32]),
+    "keds_crossformer_forward": (i32, [C.POINTER(CrossFormerParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
+    "keds_knowledge_workspace_bytes": (sz, [C.POINTER(KnowledgeParams), i32, i32]),
+    "keds_knowledge_forward": (i32, [C.POINTER(KnowledgeParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def build(verbose: bool = False) -> str:
+    """Compile libkeds_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", os.path.join(_HERE, "csrc"), "-j8"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("building libkeds_hip.so failed:\n" + res.stdout[-4000:] + res.stderr[-4000:])
+    if verbose:
+        print(res.stdout[-2000:])
+    return LIB_PATH
+
+
+def load() -> C.CDLL:
+    """Load the HIP library.  Raises RuntimeError if it is missing (no fallback path exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(or `make -C keds_amd/csrc`).  keds_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.keds_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError(f"libkeds_hip.so ABI {got} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return (load().keds_last_error() or b"").decode()
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed ({rc}): {last_error()}")
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise RuntimeError("keds_amd needs an MI355X (ROCm device); there is no CPU fallback")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("keds_amd: tensor is not on the GPU")
+    if not t.is_contiguous():
+        raise RuntimeError("keds_amd: tensor must be contiguous")
+    return t.data_ptr()
+
+
+def stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Workspace:
+    """Grow-only device scratch buffer (one per owner object)."""
+
+    def __init__(self):
+        self.buf: Optional[torch.Tensor] = None
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
+            self.buf = torch.zeros(int(nbytes) + 256, dtype=torch.uint8, device=device)
+        return self.buf
+
+
+def prof_enable(on: bool) -> None:
+    check(load().keds_prof_enable(1 if on else 0), "keds_prof_enable")
+
+
+def prof_reset() -> None:
+    check(load().keds_prof_reset(), "keds_prof_reset")
+
+
+def prof_read(klass: int):
+    ms, n = C.c_double(0), i64(0)
+    check(load().keds_prof_read(klass, C.byref(ms), C.byref(n)), "keds_prof_read")
+    return ms.value, n.value

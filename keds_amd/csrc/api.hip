@@ -1,0 +1,104 @@
+// Error reporting, ABI version, hipEvent profiling of kernel classes.
+#include "keds_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <mutex>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void keds_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int keds_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        keds_set_error("%s: %s", what, hipGetErrorString(e));
+        return KEDS_E_LAUNCH;
+    }
+    return KEDS_OK;
+}
+
+extern "C" int keds_abi_version(void) { return KEDS_ABI_VERSION; }
+extern "C" const char* keds_last_error(void) { return g_err; }
+
+// ---- profiling ---------------------------------------------------------------------------
+namespace {
+struct EvPair {
+    hipEvent_t a, b;
+};
+struct ProfState {
+    bool on = false;
+    std::mutex mu;
+    std::vector<EvPair> used[KEDS_PROF_NCLASS];
+    std::vector<EvPair> pool;
+};
+ProfState& prof() {
+    static ProfState s;
+    return s;
+}
+}  // namespace
+
+KedsProfScope::KedsProfScope(int k, hipStream_t s) : klass(k), stream(s), slot(nullptr) {
+    ProfState& p = prof();
+    if (!p.on) return;
+    std::lock_guard<std::mutex> g(p.mu);
+    EvPair ev;
+    if (!p.pool.empty()) {
+        ev = p.pool.back();
+        p.pool.pop_back();
+    } else {
+        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
+    }
+    (void)hipEventRecord(ev.a, stream);
+    p.used[klass].push_back(ev);
+    slot = (void*)1;
+}
+
+KedsProfScope::~KedsProfScope() {
+    if (!slot) return;
+    ProfState& p = prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    (void)hipEventRecord(p.used[klass].back().b, stream);
+}
+
+extern "C" int keds_prof_enable(int on) {
+    prof().on = on != 0;
+    return KEDS_OK;
+}
+
+extern "C" int keds_prof_reset(void) {
+    ProfState& p = prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    for (int k = 0; k < KEDS_PROF_NCLASS; ++k) {
+        for (auto& e : p.used[k]) p.pool.push_back(e);
+        p.used[k].clear();
+    }
+    return KEDS_OK;
+}
+
+extern "C" int keds_prof_read(int klass, double* total_ms, int64_t* launches) {
+    if (klass < 0 || klass >= KEDS_PROF_NCLASS || !total_ms || !launches) {
+        keds_set_error("keds_prof_read: bad argument");
+        return KEDS_E_ARG;
+    }
+    ProfState& p = prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    double t = 0;
+    for (auto& e : p.used[klass]) {
+        if (hipEventSynchronize(e.b) != hipSuccess) {
+            keds_set_error("keds_prof_read: event sync failed");
+            return KEDS_E_LAUNCH;
+        }
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e.a, e.b);
+        t += ms;
+    }
+    *total_ms = t;
+    *launches = (int64_t)p.used[klass].size();
+    return KEDS_OK;
+}

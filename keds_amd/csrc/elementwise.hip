@@ -1,0 +1,263 @@
+// Memory-bound helpers of the encoder path: LayerNorm (fp32 statistics), patch im2col,
+// token embedding + pseudo-token splice + positional embedding, read-out, L2 normalisation.
+// References: src/model/model.py:291-297 (LayerNorm), :394-398 (patch tokens), :579-581 and
+// :817-837 (text embedding and splice), :412-414/:586-589/:841-849 (read-out),
+// src/eval_utils.py:162,704-710 (normalise / mixture).
+#include "keds_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr float LN_EPS = 1e-5f;
+constexpr int LN_MAXV = 8;  // f32x4 chunks per lane: dim <= 2048
+
+// one wave per output row r; source row = r*row_mul + (row_map ? row_map[r] : 0)
+template <bool OUT_F32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long x_stride,
+                                                        const int* __restrict__ row_map, int row_mul,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, void* __restrict__ out,
+                                                        int rows, int dim) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const long long src = (long long)r * row_mul + (row_map ? row_map[r] : 0);
+    const float* p = x + src * x_stride;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = j * 256 + lane * 4;
+        if (i < dim) {
+            v[j] = *reinterpret_cast<const f32x4*>(p + i);
+            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        } else {
+            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = j * 256 + lane * 4;
+        if (i < dim) {
+            const f32x4 d = v[j] - mean;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + LN_EPS);
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = j * 256 + lane * 4;
+        if (i < dim) {
+            const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + i);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + i);
+            const f32x4 y = (v[j] - mean) * rstd * gg + bb;
+            if constexpr (OUT_F32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)r * dim + i) = y;
+            } else {
+                *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + (size_t)r * dim + i) =
+                    bf16x4{(bf16_t)y[0], (bf16_t)y[1], (bf16_t)y[2], (bf16_t)y[3]};
+            }
+        }
+    }
+}
+
+// one block per output row (b, patch); columns c*P*P + ky*P + kx, zero padded to Kpad
+__global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int R,
+                                                     int P, int Kpad) {
+    const int g = R / P;
+    const int row = blockIdx.x;
+    const int b = row / (g * g), pi = row % (g * g);
+    const int py = pi / g, px = pi % g;
+    const int kreal = 3 * P * P;
+    const float* base = img + (size_t)b * 3 * R * R;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        float v = 0.f;
+        if (k < kreal) {
+            const int ch = k / (P * P), rem = k % (P * P);
+            const int ky = rem / P, kx = rem % P;
+            v = base[(size_t)ch * R * R + (size_t)(py * P + ky) * R + px * P + kx];
+        }
+        out[(size_t)row * Kpad + k] = (bf16_t)v;
+    }
+}
+
+// CLS rows: x[b*(G+1), :] = class_emb + pos[0]
+__global__ void cls_rows_kernel(float* __restrict__ x, const float* __restrict__ cls, const float* __restrict__ pos,
+                                int B, int S, int d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * d) return;
+    const int b = i / d, j = i % d;
+    x[(size_t)b * S * d + j] = cls[j] + pos[j];
+}
+
+// one block per (b, t)
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict__ tokens,
+                                                           const float* __restrict__ table,
+                                                           const float* __restrict__ pos,
+                                                           const float* __restrict__ img_tokens, int n_tok,
+                                                           int insert_col, float* __restrict__ x, int L, int d) {
+    const int b = blockIdx.x / L, t = blockIdx.x % L;
+    const float* src;
+    if (img_tokens && t >= insert_col && t < insert_col + n_tok) {
+        src = img_tokens + ((size_t)b * n_tok + (t - insert_col)) * d;
+    } else {
+        const int col = (img_tokens && t >= insert_col + n_tok) ? t - (n_tok - 1) : t;
+        src = table + (size_t)tokens[(size_t)b * L + col] * d;
+    }
+    const float* pe = pos + (size_t)t * d;
+    float* o = x + ((size_t)b * L + t) * d;
+    for (int i = threadIdx.x * 4; i < d; i += 1024)
+        *reinterpret_cast<f32x4*>(o + i) =
+            *reinterpret_cast<const f32x4*>(src + i) + *reinterpret_cast<const f32x4*>(pe + i);
+}
+
+__global__ __launch_bounds__(256) void l2norm_kernel(const float* __restrict__ x, float* __restrict__ out, int rows,
+                                                     int dim) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* p = x + (size_t)r * dim;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s += p[i] * p[i];
+    const float nrm = sqrtf(wave_sum(s));
+    for (int i = lane; i < dim; i += 64) out[(size_t)r * dim + i] = p[i] / nrm;
+}
+
+__global__ __launch_bounds__(256) void mix_kernel(const float* __restrict__ a, const float* __restrict__ b, float wa,
+                                                  float wb, float* __restrict__ an, float* __restrict__ bn,
+                                                  float* __restrict__ mix, int rows, int dim) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* pa = a + (size_t)r * dim;
+    const float* pb = b + (size_t)r * dim;
+    float sa = 0.f, sb = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        sa += pa[i] * pa[i];
+        sb += pb[i] * pb[i];
+    }
+    const float na = sqrtf(wave_sum(sa)), nb = sqrtf(wave_sum(sb));
+    float sm = 0.f;
+    for (int i = lane; i < dim; i += 64) {
+        const float m = wa * (pa[i] / na) + wb * (pb[i] / nb);
+        sm += m * m;
+    }
+    const float nm = sqrtf(wave_sum(sm));
+    for (int i = lane; i < dim; i += 64) {
+        const float va = pa[i] / na, vb = pb[i] / nb;
+        an[(size_t)r * dim + i] = va;
+        bn[(size_t)r * dim + i] = vb;
+        mix[(size_t)r * dim + i] = (wa * va + wb * vb) / nm;
+    }
+}
+
+__global__ void cast_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ out, long long n) {
+    long long i = (blockIdx.x * (long long)blockDim.x + threadIdx.x) * 4;
+    const long long step = (long long)gridDim.x * blockDim.x * 4;
+    for (; i + 3 < n; i += step) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + i);
+        *reinterpret_cast<bf16x4*>(out + i) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    }
+    if (i < n && i + 3 >= n)
+        for (long long j = i; j < n; ++j) out[j] = (bf16_t)x[j];
+}
+
+bool ln_dim_ok(int dim) { return dim > 0 && dim <= 2048 && dim % 4 == 0 && (dim % 256 == 0 || dim == 128); }
+
+}  // namespace
+
+int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
+                        const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st) {
+    KedsProfScope prof(KEDS_PROF_LN, st);
+    const unsigned grid = (rows + 3) / 4;
+    if (out_f32)
+        layernorm_kernel<true><<<grid, 256, 0, st>>>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim);
+    else
+        layernorm_kernel<false><<<grid, 256, 0, st>>>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim);
+    return keds_check_launch("layernorm_kernel");
+}
+
+extern "C" int keds_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out,
+                              int out_f32, int rows, int dim, void* stream) {
+    KEDS_REQUIRE(x && gamma && beta && out && rows > 0, "keds_layernorm: bad argument");
+    KEDS_REQUIRE(ln_dim_ok(dim), "keds_layernorm: dim %d unsupported", dim);
+    KEDS_REQUIRE(x_stride % 4 == 0, "keds_layernorm: row stride must be a multiple of 4");
+    return keds_layernorm_impl(x, x_stride, nullptr, 1, gamma, beta, out, out_f32, rows, dim, (hipStream_t)stream);
+}
+
+extern "C" int keds_im2col(const float* image, void* out, int B, int R, int P, int Kpad, void* stream) {
+    KEDS_REQUIRE(image && out && B > 0 && P > 0 && R % P == 0, "keds_im2col: bad argument");
+    KEDS_REQUIRE(Kpad >= 3 * P * P && Kpad % 64 == 0, "keds_im2col: Kpad must cover 3*P*P and be a multiple of 64");
+    const int g = R / P;
+    KedsProfScope prof(KEDS_PROF_OTHER, (hipStream_t)stream);
+    im2col_kernel<<<B * g * g, 256, 0, (hipStream_t)stream>>>(image, (bf16_t*)out, R, P, Kpad);
+    return keds_check_launch("im2col_kernel");
+}
+
+int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int S, int d, hipStream_t st) {
+    cls_rows_kernel<<<(B * d + 255) / 256, 256, 0, st>>>(x, cls, pos, B, S, d);
+    return keds_check_launch("cls_rows_kernel");
+}
+
+extern "C" int keds_embed_tokens(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
+                                 int n_tok, int insert_col, float* x, int B, int L, int d, void* stream) {
+    KEDS_REQUIRE(tokens && table && pos && x && B > 0 && L > 0, "keds_embed_tokens: bad argument");
+    KEDS_REQUIRE(d % 4 == 0, "keds_embed_tokens: d must be a multiple of 4");
+    if (img_tokens) {
+        KEDS_REQUIRE(n_tok >= 1 && insert_col >= 0 && insert_col + n_tok <= L,
+                     "keds_embed_tokens: splice [%d,%d) outside the context of %d", insert_col, insert_col + n_tok, L);
+    }
+    KedsProfScope prof(KEDS_PROF_OTHER, (hipStream_t)stream);
+    embed_tokens_kernel<<<B * L, 256, 0, (hipStream_t)stream>>>(tokens, table, pos, img_tokens, n_tok, insert_col, x, L,
+                                                                 d);
+    return keds_check_launch("embed_tokens_kernel");
+}
+
+extern "C" size_t keds_readout_workspace_bytes(int B, int d) {
+    return keds_align_up((size_t)B, 128) * d * 2;
+}
+
+extern "C" int keds_readout(const float* x, int S, const int32_t* row, const float* gamma, const float* beta,
+                            const void* proj_t, float* out, int B, int d, int E, int normalize, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+    KEDS_REQUIRE(x && gamma && beta && proj_t && out && workspace && B > 0, "keds_readout: bad argument");
+    KEDS_REQUIRE(ln_dim_ok(d), "keds_readout: d %d unsupported", d);
+    if (workspace_bytes < keds_readout_workspace_bytes(B, d)) {
+        keds_set_error("keds_readout: workspace too small");
+        return KEDS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    int rc = keds_layernorm_impl(x, d, row, S, gamma, beta, workspace, 0, B, d, st);
+    if (rc) return rc;
+    rc = keds_gemm_bt(workspace, proj_t, nullptr, out, B, E, d, KEDS_EPI_BIAS_F32, nullptr, 0, stream);
+    if (rc) return rc;
+    if (normalize) {
+        l2norm_kernel<<<(B + 3) / 4, 256, 0, st>>>(out, out, B, E);
+        rc = keds_check_launch("l2norm_kernel");
+    }
+    return rc;
+}
+
+extern "C" int keds_l2_normalize(const float* x, float* out, int rows, int dim, void* stream) {
+    KEDS_REQUIRE(x && out && rows > 0 && dim > 0, "keds_l2_normalize: bad argument");
+    l2norm_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(x, out, rows, dim);
+    return keds_check_launch("l2norm_kernel");
+}
+
+extern "C" int keds_mix_normalize(const float* a, const float* b, float wa, float wb, float* a_n, float* b_n,
+                                  float* mix, int rows, int dim, void* stream) {
+    KEDS_REQUIRE(a && b && a_n && b_n && mix && rows > 0 && dim > 0, "keds_mix_normalize: bad argument");
+    mix_kernel<<<(rows + 3) / 4, 256, 0, (hipStream_t)stream>>>(a, b, wa, wb, a_n, b_n, mix, rows, dim);
+    return keds_check_launch("mix_kernel");
+}
+
+extern "C" int keds_cast_bf16(const float* x, void* out, int64_t count, void* stream) {
+    KEDS_REQUIRE(x && out && count > 0, "keds_cast_bf16: bad argument");
+    long long blocks = (count / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    cast_bf16_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)out, count);
+    return keds_check_launch("cast_bf16_kernel");
+}

@@ -1,0 +1,282 @@
+// Dual-stream knowledge injection (one stream per keds_knowledge_forward call):
+//   m      = IM2TEXT(q)                                   (src/model/model.py:105-123)
+//   I', T' = IM2TEXT(neighbour image rows), IM2TEXT(neighbour text rows)
+//   fused  = CrossFormer_fuse(m, I', I');  cond = CrossFormer_cond(m, T', T')   (model.py:37-101)
+//   tokens = [fused, cond, m]                              (src/eval_utils.py:661-672)
+// IM2TEXT runs ONCE over the stacked rows [q; I; T] (B*(1+2K) rows) through the MFMA GEMM with
+// fused bias+ReLU; the cross-attention core (1 query x K keys x heads) is one wave per
+// (sample, head) with the head dimension (64) on the lanes.  keds_im2text_forward and
+// keds_crossformer_forward expose the two modules on their own (IM2TEXT.forward /
+// CrossFormer.forward of the reference API).
+#include "keds_common.h"
+#include <math.h>
+
+namespace {
+
+// one wave per (b, head): lane = head-dim element (dim_head = 64)
+__global__ __launch_bounds__(256) void cross_attn_core_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ Kp,
+                                                              const bf16_t* __restrict__ Vp, bf16_t* __restrict__ out,
+                                                              int B, int K, int heads) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= B * heads) return;
+    const int b = w / heads, h = w % heads;
+    const int inner = heads * 64;
+    const float q = (float)Q[(size_t)b * inner + h * 64 + lane];
+    float sc[32];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j < K) {
+            const float kv = (float)Kp[((size_t)b * K + j) * inner + h * 64 + lane];
+            sc[j] = wave_sum(q * kv) * 0.125f;
+            mx = fmaxf(mx, sc[j]);
+        } else {
+            sc[j] = -INFINITY;
+        }
+    }
+    float sum = 0.f, o = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+        if (j < K) {
+            const float p = __expf(sc[j] - mx);
+            sum += p;
+            o += p * (float)Vp[((size_t)b * K + j) * inner + h * 64 + lane];
+        }
+    }
+    out[(size_t)b * inner + h * 64 + lane] = (bf16_t)(o / sum);
+}
+
+// tokens[b, slot, :] = src[b, :]
+__global__ void place_token_kernel(const float* __restrict__ src, float* __restrict__ tokens, int B, int dim, int slot,
+                                   int nslots) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * dim) return;
+    const int b = i / dim, j = i % dim;
+    tokens[((size_t)b * nslots + slot) * dim + j] = src[i];
+}
+
+size_t rpad(size_t r) { return keds_align_up(r, 128); }
+
+int check_i2t(const keds_im2text_params* p, const char* who) {
+    if (!p || p->n_layer < 1 || p->n_layer > 4 || !p->out_w) {
+        keds_set_error("%s: bad IM2TEXT parameters", who);
+        return KEDS_E_ARG;
+    }
+    if (p->dim_in % 128 || p->middle % 128 || p->dim_out % 128) {
+        keds_set_error("%s: IM2TEXT dims (%d,%d,%d) must be multiples of 128", who, p->dim_in, p->middle, p->dim_out);
+        return KEDS_E_ARG;
+    }
+    return KEDS_OK;
+}
+
+int check_xf(const keds_crossformer_params* p, const char* who) {
+    if (!p || !p->layer || p->layers < 1 || p->heads < 1 || (p->heads * 64) % 128 || p->dim % 128) {
+        keds_set_error("%s: bad CrossFormer parameters", who);
+        return KEDS_E_ARG;
+    }
+    return KEDS_OK;
+}
+
+// ---- IM2TEXT on bf16 rows [R, dim_in] -> fp32 [R, dim_out]; scratch: 2 x [Rp, middle] bf16
+size_t i2t_scratch(const keds_im2text_params* p, size_t R) { return 2 * keds_align_up(rpad(R) * p->middle * 2, 256); }
+
+int i2t_run(const keds_im2text_params* p, const void* rows_bf, int R, float* out_f, char* scratch, void* stream) {
+    char* hbuf[2] = {scratch, scratch + keds_align_up(rpad(R) * p->middle * 2, 256)};
+    const void* cur = rows_bf;
+    int cur_dim = p->dim_in, rc;
+    for (int l = 0; l < p->n_layer; ++l) {
+        if ((rc = keds_gemm_bt(cur, p->w[l], p->b[l], hbuf[l & 1], R, p->middle, cur_dim, KEDS_EPI_BIAS_RELU_BF16, nullptr,
+                               0, stream)))
+            return rc;
+        cur = hbuf[l & 1];
+        cur_dim = p->middle;
+    }
+    return keds_gemm_bt(cur, p->out_w, p->out_b, out_f, R, p->dim_out, p->middle, KEDS_EPI_BIAS_F32, nullptr, 0, stream);
+}
+
+// ---- CrossFormer on bf16 inputs: q [B,dim], k rows [B*K,dim], v rows [B*K,dim] -> fp32 [B,dim]
+struct XfScratch {
+    char *qcur, *Qp, *Kp, *Vp, *att;
+    size_t bytes;
+};
+XfScratch carve_xf(const keds_crossformer_params* p, int B, int K, char* base) {
+    XfScratch s;
+    size_t off = 0;
+    auto take = [&](size_t b) {
+        char* r = base ? base + off : nullptr;
+        off += keds_align_up(b, 256);
+        return r;
+    };
+    const size_t Bp = rpad(B), BKp = rpad((size_t)B * K);
+    const int inner = p->heads * 64;
+    s.qcur = take(Bp * p->dim * 2);
+    s.Qp = take(Bp * inner * 2);
+    s.Kp = take(BKp * inner * 2);
+    s.Vp = take(BKp * inner * 2);
+    s.att = take(Bp * inner * 2);
+    s.bytes = off;
+    return s;
+}
+
+int xf_run(const keds_crossformer_params* p, const void* q_bf, const void* k_bf, const void* v_bf, int B, int K,
+           float* out_f, char* scratch, void* stream) {
+    XfScratch s = carve_xf(p, B, K, scratch);
+    hipStream_t st = (hipStream_t)stream;
+    const int dim = p->dim, inner = p->heads * 64, BK = B * K;
+    const void* qin = q_bf;
+    int rc;
+    for (int l = 0; l < p->layers; ++l) {
+        const keds_cross_layer_params& c = p->layer[l];
+        if ((rc = keds_gemm_bt(qin, c.wq, c.bq, s.Qp, B, inner, dim, KEDS_EPI_BIAS_BF16, nullptr, 0, stream))) return rc;
+        if ((rc = keds_gemm_bt(k_bf, c.wk, c.bk, s.Kp, BK, inner, dim, KEDS_EPI_BIAS_BF16, nullptr, 0, stream))) return rc;
+        if ((rc = keds_gemm_bt(v_bf, c.wv, c.bv, s.Vp, BK, inner, dim, KEDS_EPI_BIAS_BF16, nullptr, 0, stream))) return rc;
+        {
+            KedsProfScope prof(KEDS_PROF_OTHER, st);
+            cross_attn_core_kernel<<<(B * p->heads + 3) / 4, 256, 0, st>>>((const bf16_t*)s.Qp, (const bf16_t*)s.Kp,
+                                                                           (const bf16_t*)s.Vp, (bf16_t*)s.att, B, K,
+                                                                           p->heads);
+            if ((rc = keds_check_launch("cross_attn_core_kernel"))) return rc;
+        }
+        if (l == p->layers - 1) {
+            if ((rc = keds_gemm_bt(s.att, c.wo, c.bo, out_f, B, dim, inner, KEDS_EPI_BIAS_F32, nullptr, 0, stream))) return rc;
+        } else {
+            if ((rc = keds_gemm_bt(s.att, c.wo, c.bo, s.qcur, B, dim, inner, KEDS_EPI_BIAS_BF16, nullptr, 0, stream)))
+                return rc;
+            qin = s.qcur;
+        }
+    }
+    return KEDS_OK;
+}
+
+}  // namespace
+
+// ---- standalone IM2TEXT ------------------------------------------------------------------------
+extern "C" size_t keds_im2text_workspace_bytes(const keds_im2text_params* p, int rows) {
+    if (!p || rows <= 0) return 0;
+    return keds_align_up(rpad(rows) * p->dim_in * 2, 256) + i2t_scratch(p, rows);
+}
+
+extern "C" int keds_im2text_forward(const keds_im2text_params* p, const float* x, int rows, float* out, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    int rc = check_i2t(p, "keds_im2text_forward");
+    if (rc) return rc;
+    KEDS_REQUIRE(x && out && workspace && rows > 0, "keds_im2text_forward: bad argument");
+    if (workspace_bytes < keds_im2text_workspace_bytes(p, rows)) {
+        keds_set_error("keds_im2text_forward: workspace too small");
+        return KEDS_E_WORKSPACE;
+    }
+    char* xb = (char*)workspace;
+    char* scratch = xb + keds_align_up(rpad(rows) * p->dim_in * 2, 256);
+    if ((rc = keds_cast_bf16(x, xb, (int64_t)rows * p->dim_in, stream))) return rc;
+    return i2t_run(p, xb, rows, out, scratch, stream);
+}
+
+// ---- standalone CrossFormer --------------------------------------------------------------------
+extern "C" size_t keds_crossformer_workspace_bytes(const keds_crossformer_params* p, int B, int K) {
+    if (!p || B <= 0 || K <= 0) return 0;
+    const size_t qb = keds_align_up(rpad(B) * p->dim * 2, 256);
+    const size_t kb = keds_align_up(rpad((size_t)B * K) * p->dim * 2, 256);
+    return qb + 2 * kb + carve_xf(p, B, K, nullptr).bytes;
+}
+
+extern "C" int keds_crossformer_forward(const keds_crossformer_params* p, const float* q, const float* k, const float* v,
+                                        int B, int K, float* out, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+    int rc = check_xf(p, "keds_crossformer_forward");
+    if (rc) return rc;
+    KEDS_REQUIRE(q && k && v && out && workspace && B > 0, "keds_crossformer_forward: bad argument");
+    KEDS_REQUIRE(K >= 1 && K <= 32, "keds_crossformer_forward: K=%d must be in [1,32]", K);
+    if (workspace_bytes < keds_crossformer_workspace_bytes(p, B, K)) {
+        keds_set_error("keds_crossformer_forward: workspace too small");
+        return KEDS_E_WORKSPACE;
+    }
+    const size_t qb = keds_align_up(rpad(B) * p->dim * 2, 256);
+    const size_t kb = keds_align_up(rpad((size_t)B * K) * p->dim * 2, 256);
+    char* base = (char*)workspace;
+    char *q_bf = base, *k_bf = base + qb, *v_bf = base + qb + kb, *scratch = base + qb + 2 * kb;
+    if ((rc = keds_cast_bf16(q, q_bf, (int64_t)B * p->dim, stream))) return rc;
+    if ((rc = keds_cast_bf16(k, k_bf, (int64_t)B * K * p->dim, stream))) return rc;
+    if (v != k) {
+        if ((rc = keds_cast_bf16(v, v_bf, (int64_t)B * K * p->dim, stream))) return rc;
+    } else {
+        v_bf = k_bf;
+    }
+    return xf_run(p, q_bf, k_bf, v_bf, B, K, out, scratch, stream);
+}
+
+// ---- one full stream ---------------------------------------------------------------------------
+namespace {
+struct KnWs {
+    char* rows_bf;   // [R, dim] bf16 stacked q | nbr_img | nbr_txt (R = B(1+2K))
+    float* map_f;    // [R, dim] fp32 IM2TEXT output
+    char* map_bf;    // [R + 128, dim] bf16
+    float* outf;     // [Bp, dim] fp32 CrossFormer output
+    char* i2t;       // IM2TEXT scratch
+    char* xf;        // CrossFormer scratch
+    size_t bytes;
+};
+KnWs carve_kn(const keds_knowledge_params* p, int B, int K, void* ws) {
+    KnWs w;
+    char* base = (char*)ws;
+    size_t off = 0;
+    auto take = [&](size_t b) {
+        char* r = base ? base + off : nullptr;
+        off += keds_align_up(b, 256);
+        return r;
+    };
+    const size_t R = (size_t)B * (1 + 2 * K);
+    const int dim = p->i2t.dim_out;
+    w.rows_bf = take(rpad(R) * p->i2t.dim_in * 2);
+    w.map_f = (float*)take(rpad(R) * dim * 4);
+    w.map_bf = take((rpad(R) + 128) * dim * 2);   // GEMMs on sub-ranges may read up to 127 rows past R
+    w.outf = (float*)take(rpad(B) * dim * 4);
+    w.i2t = take(i2t_scratch(&p->i2t, R));
+    w.xf = take(carve_xf(&p->fuse, B, K, nullptr).bytes);
+    w.bytes = off;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t keds_knowledge_workspace_bytes(const keds_knowledge_params* p, int B, int K) {
+    if (!p || B <= 0 || K <= 0) return 0;
+    return carve_kn(p, B, K, nullptr).bytes;
+}
+
+extern "C" int keds_knowledge_forward(const keds_knowledge_params* p, const float* q, const float* nbr_img,
+                                      const float* nbr_txt, int B, int K, float* tokens_out, void* workspace,
+                                      size_t workspace_bytes, void* stream) {
+    KEDS_REQUIRE(p && q && nbr_img && nbr_txt && tokens_out && workspace, "keds_knowledge_forward: null pointer");
+    KEDS_REQUIRE(B > 0 && K >= 1 && K <= 32, "keds_knowledge_forward: K must be in [1,32]");
+    int rc;
+    if ((rc = check_i2t(&p->i2t, "keds_knowledge_forward"))) return rc;
+    if ((rc = check_xf(&p->fuse, "keds_knowledge_forward"))) return rc;
+    if ((rc = check_xf(&p->cond, "keds_knowledge_forward"))) return rc;
+    const int dim = p->i2t.dim_out;
+    KEDS_REQUIRE(p->i2t.dim_in == dim && p->fuse.dim == dim && p->cond.dim == dim && p->fuse.heads == p->cond.heads,
+                 "keds_knowledge_forward: IM2TEXT and CrossFormer dims must agree");
+    KnWs w = carve_kn(p, B, K, workspace);
+    if (workspace_bytes < w.bytes) {
+        keds_set_error("keds_knowledge_forward: workspace %zu < %zu", workspace_bytes, w.bytes);
+        return KEDS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int R = B * (1 + 2 * K), BK = B * K;
+    bf16_t* rows = (bf16_t*)w.rows_bf;
+    if ((rc = keds_cast_bf16(q, rows, (int64_t)B * dim, stream))) return rc;
+    if ((rc = keds_cast_bf16(nbr_img, rows + (size_t)B * dim, (int64_t)BK * dim, stream))) return rc;
+    if ((rc = keds_cast_bf16(nbr_txt, rows + (size_t)(B + BK) * dim, (int64_t)BK * dim, stream))) return rc;
+    if ((rc = i2t_run(&p->i2t, rows, R, w.map_f, w.i2t, stream))) return rc;
+    if ((rc = keds_cast_bf16(w.map_f, w.map_bf, (int64_t)R * dim, stream))) return rc;
+    place_token_kernel<<<(B * dim + 255) / 256, 256, 0, st>>>(w.map_f, tokens_out, B, dim, 2, 3);
+    if ((rc = keds_check_launch("place_token_kernel"))) return rc;
+    const bf16_t* map_bf = (const bf16_t*)w.map_bf;
+    for (int which = 0; which < 2; ++which) {
+        const keds_crossformer_params* xf = which == 0 ? &p->fuse : &p->cond;
+        const bf16_t* nb = map_bf + (size_t)(B + which * BK) * dim;
+        if ((rc = xf_run(xf, map_bf, nb, nb, B, K, w.outf, w.xf, stream))) return rc;
+        place_token_kernel<<<(B * dim + 255) / 256, 256, 0, st>>>(w.outf, tokens_out, B, dim, which, 3);
+        if ((rc = keds_check_launch("place_token_kernel"))) return rc;
+    }
+    return KEDS_OK;
+}

@@ -1,0 +1,169 @@
+// Gallery ranking + CIRR recall bookkeeping on device.
+// Reference: get_metrics_cirr, src/eval_utils.py:1040-1067 -- `1 - ref @ gallery.T`, a full
+// ascending argsort per query, removal of the reference image from each ranking, one-hot against
+// the target name.  The reference does the name work with a Python double loop over Q x G
+// basenames; here names are interned to integer ids on the host once and compared on device.
+#include "keds_common.h"
+#include <math.h>
+
+namespace {
+
+// dist[q,g] = 1 - sum_k ref[q,k] * gal[g,k]  (fp32, 64x64 tile per 256-thread block, 4x4 per thread)
+__global__ __launch_bounds__(256) void dist_kernel(const float* __restrict__ ref, int nq, const float* __restrict__ gal,
+                                                   int ng, int dim, float* __restrict__ dist) {
+    __shared__ float sa[16][64 + 1];
+    __shared__ float sb[16][64 + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int q0 = blockIdx.y * 64, g0 = blockIdx.x * 64;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < dim; k0 += 16) {
+        for (int i = threadIdx.x; i < 64 * 16; i += 256) {
+            const int r = i >> 4, k = i & 15;
+            sa[k][r] = (q0 + r < nq && k0 + k < dim) ? ref[(size_t)(q0 + r) * dim + k0 + k] : 0.f;
+            sb[k][r] = (g0 + r < ng && k0 + k < dim) ? gal[(size_t)(g0 + r) * dim + k0 + k] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = sa[k][ty * 4 + i];
+                b[i] = sb[k][tx * 4 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + ty * 4 + i, g = g0 + tx * 4 + j;
+            if (q < nq && g < ng) dist[(size_t)q * ng + g] = 1.0f - acc[i][j];
+        }
+}
+
+__device__ __forceinline__ unsigned int orderable(float f) {
+    const unsigned int u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// one block per query: bitonic sort of (orderable(dist) << 32 | g) in LDS; P = padded power of two
+__global__ __launch_bounds__(256) void sort_rows_kernel(const float* __restrict__ dist, int ng, int P,
+                                                        int* __restrict__ order) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int q = blockIdx.x;
+    for (int i = threadIdx.x; i < P; i += 256)
+        keys[i] = i < ng ? (((unsigned long long)orderable(dist[(size_t)q * ng + i])) << 32) | (unsigned)i
+                         : 0xFFFFFFFFFFFFFFFFull;
+    __syncthreads();
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = keys[i], b = keys[l];
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < ng; i += 256) order[(size_t)q * ng + i] = (int)(keys[i] & 0xFFFFFFFFu);
+}
+
+// one wave per query
+__global__ __launch_bounds__(256) void cirr_rank_kernel(const int* __restrict__ order, int nq, int ng,
+                                                        const int* __restrict__ gallery_ids,
+                                                        const int* __restrict__ ref_ids,
+                                                        const int* __restrict__ target_ids, int* __restrict__ rank_out,
+                                                        int* __restrict__ counts_out) {
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= nq) return;
+    const int rid = ref_ids[q], tid_ = target_ids[q];
+    int removed = 0, nref = 0, ntgt = 0, rank = -1;
+    for (int base = 0; base < ng; base += 64) {
+        const int i = base + lane;
+        const int id = i < ng ? gallery_ids[order[(size_t)q * ng + i]] : -2147483647;
+        const bool is_ref = i < ng && id == rid;
+        const bool is_tgt = i < ng && id == tid_ && !is_ref;
+        const unsigned long long mref = __ballot(is_ref);
+        const unsigned long long mtgt = __ballot(is_tgt);
+        if (mtgt && rank < 0) {
+            const int first = __ffsll((long long)mtgt) - 1;
+            const int refs_before = __popcll(mref & ((1ull << first) - 1ull));
+            rank = base + first - removed - refs_before;
+        }
+        removed += __popcll(mref);
+        nref += __popcll(mref);
+        ntgt += __popcll(mtgt);
+    }
+    if (lane == 0) {
+        rank_out[q] = rank;
+        if (counts_out) {
+            counts_out[2 * q] = nref;
+            counts_out[2 * q + 1] = ntgt;
+        }
+    }
+}
+
+int next_pow2(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+extern "C" size_t keds_rank_gallery_workspace_bytes(int nq, int ng) {
+    if (nq <= 0 || ng <= 0) return 0;
+    return keds_align_up((size_t)nq * ng * sizeof(float), 256);
+}
+
+extern "C" int keds_rank_gallery(const float* ref, int nq, const float* gallery, int ng, int dim, int32_t* order,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    KEDS_REQUIRE(ref && gallery && order && workspace && nq > 0 && ng > 0 && dim > 0, "keds_rank_gallery: bad argument");
+    KEDS_REQUIRE(ng <= 8192, "keds_rank_gallery: gallery of %d rows exceeds the 8192-row LDS sort", ng);
+    if (workspace_bytes < keds_rank_gallery_workspace_bytes(nq, ng)) {
+        keds_set_error("keds_rank_gallery: workspace too small");
+        return KEDS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    float* dist = (float*)workspace;
+    dim3 grid((ng + 63) / 64, (nq + 63) / 64);
+    dist_kernel<<<grid, 256, 0, st>>>(ref, nq, gallery, ng, dim, dist);
+    int rc = keds_check_launch("dist_kernel");
+    if (rc) return rc;
+    const int P = next_pow2(ng);
+    const size_t lds = (size_t)P * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)sort_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) !=
+            hipSuccess) {
+            keds_set_error("keds_rank_gallery: cannot set dynamic LDS size");
+            return KEDS_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    sort_rows_kernel<<<nq, 256, lds, st>>>(dist, ng, P, order);
+    return keds_check_launch("sort_rows_kernel");
+}
+
+extern "C" int keds_cirr_target_rank(const int32_t* order, int nq, int ng, const int32_t* gallery_ids,
+                                     const int32_t* ref_ids, const int32_t* target_ids, int32_t* rank_out,
+                                     int32_t* counts_out, void* stream) {
+    KEDS_REQUIRE(order && gallery_ids && ref_ids && target_ids && rank_out && nq > 0 && ng > 0,
+                 "keds_cirr_target_rank: bad argument");
+    cirr_rank_kernel<<<(nq + 3) / 4, 256, 0, (hipStream_t)stream>>>(order, nq, ng, gallery_ids, ref_ids, target_ids,
+                                                                    rank_out, counts_out);
+    return keds_check_launch("cirr_rank_kernel");
+}

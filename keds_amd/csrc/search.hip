@@ -1,0 +1,638 @@
+// Similarity + top-k over a resident database: the replacement for faiss.IndexFlatL2
+// (reference: src/eval_retrieval.py:289-298, src/eval_utils.py:169-180, src/trainer.py:246-257).
+//
+// Pipeline (all on one stream, no host sync):
+//   qprep   : fp32 queries -> (optionally L2-normalised) fp32 copy + bf16 block of 128 rows
+//   scan    : HBM-bound.  One persistent 512-thread workgroup per CU streams its contiguous
+//             range of 32-key stages HBM -> LDS with LDS-DMA (the HBM image IS the LDS image,
+//             pre-swizzled at pack time), keeps the 128 queries as MFMA B-operands in
+//             registers, and folds every 16x16 score tile into per-lane exact top-16 lists
+//             (lane = one query x one quarter of the keys; the list threshold makes inserts rare).
+//   merge   : per query, tournament over the sorted per-lane lists -> 64 candidates
+//   rerank  : exact fp32 distance of each candidate from the fp32 rows
+//   select  : order the 64 by (distance, id) -> top-k  (+ optional row gather)
+//
+// Score used by the scan: s = q.x - 0.5*||x||^2 (L2; monotone in -||q-x||^2) or q.x (IP);
+// the per-key bias enters as the MFMA C-in operand, read from the stage's fp32 tail.
+#include "keds_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int STAGE_KEYS = KEDS_SCAN_STAGE_KEYS;  // 32
+constexpr int LISTK = KEDS_SCAN_LIST;             // 16
+constexpr int NCAND = KEDS_SCAN_CAND;             // 64
+constexpr int QBLOCK = KEDS_SCAN_MAX_QUERIES;     // 128
+constexpr int SCAN_THREADS = 512;
+
+template <int D>
+struct ScanCfg {
+    static constexpr int ROWB = D * 2;                   // bytes per bf16 key row
+    static constexpr int CHUNKS = D / 8;                 // 16-byte chunks per row
+    static constexpr int KEYB = STAGE_KEYS * ROWB;       // key bytes per stage
+    static constexpr int STAGEB = KEYB + 128;            // HBM blob: keys + 32 fp32 biases
+    static constexpr int LDS_STAGE = KEYB + 8 * 128;     // LDS slot: keys + 8 wave-private bias copies
+    static constexpr int NST_RAW = (160 * 1024) / LDS_STAGE;
+    static constexpr int NST = NST_RAW > 8 ? 8 : NST_RAW;  // ring depth
+    static constexpr int PIECES = KEYB / 1024;           // 1-KiB DMA pieces per stage
+    static constexpr int PPW = PIECES / 8;               // per wave
+    static constexpr int PW = PPW + 1;                   // + the bias piece: vm ops per wave per stage
+    static constexpr int KSTEPS = D / 32;
+    static_assert(D % 128 == 0, "row must be a whole number of 256-byte bank rows");
+    static_assert(PIECES % 8 == 0, "pieces must split evenly over 8 waves");
+    static_assert(NST >= 2, "need at least a double buffer");
+    static_assert((NST - 2) * PW <= 63, "vmcnt immediate");
+};
+
+// 16-byte chunk `ch` of key row `row` lives at slot (ch ^ row) in its 16-chunk (256-byte) group:
+// 16 lanes reading the same chunk of 16 different rows then hit 16 different 16-byte slots.
+__host__ __device__ __forceinline__ int swz_chunk(int ch, int row) { return (ch & ~15) | ((ch ^ row) & 15); }
+
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <int PW, int MAXAHEAD>
+__device__ __forceinline__ void wait_stage_and_barrier(int ahead) {
+    // `ahead` = stages issued after the one we are about to read (wave-uniform)
+    if constexpr (MAXAHEAD == 0) {
+        wait_vm_barrier<0>();
+    } else {
+        if (ahead >= MAXAHEAD) wait_vm_barrier<MAXAHEAD * PW>();
+        else wait_stage_and_barrier<PW, MAXAHEAD - 1>(ahead);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
+    const char* __restrict__ packed, int total_stages, const bf16_t* __restrict__ qb,
+    const float* __restrict__ thr, float* __restrict__ out_val, int* __restrict__ out_idx) {
+    using C = ScanCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, c = lane & 15;
+    const int nwg = gridDim.x;
+    const int s0 = (int)(((long long)blockIdx.x * total_stages) / nwg);
+    const int s1 = (int)(((long long)(blockIdx.x + 1) * total_stages) / nwg);
+
+    // queries of this wave as MFMA B operands: lane (g,c) holds Q[16*wave + c][32*s + 8*g .. +7]
+    bf16x8 qf[C::KSTEPS];
+    {
+        const bf16_t* qrow = qb + (size_t)(wave * 16 + c) * D + 8 * g;
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s);
+    }
+    float lv[LISTK];
+    int li[LISTK];
+#pragma unroll
+    for (int j = 0; j < LISTK; ++j) {
+        lv[j] = -INFINITY;
+        li[j] = -1;
+    }
+    const float thr0 = thr ? thr[wave * 16 + c] : -INFINITY;
+    float lmin = thr0;
+
+    // make sure the query loads are consumed before any LDS-DMA is counted on vmcnt
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    auto issue = [&](int stage, int slot) {
+        const char* src = packed + (size_t)stage * C::STAGEB + lane * 16;
+        char* dst = smem + slot * C::LDS_STAGE;
+#pragma unroll
+        for (int i = 0; i < C::PPW; ++i) {
+            const int piece = wave + 8 * i;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+        }
+        if (lane < 8) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + C::KEYB),
+                                             (__attribute__((address_space(3))) void*)(dst + C::KEYB + wave * 128), 16, 0, 0);
+        }
+    };
+
+    // prologue: NST-1 stages in flight
+#pragma unroll
+    for (int i = 0; i < C::NST - 1; ++i)
+        if (s0 + i < s1) issue(s0 + i, i);
+
+    // per-lane LDS read offset of chunk (4*s + g) of row c (row 16+c has the same swizzle)
+    const int row_off = c * C::ROWB;
+
+    int slot = 0;
+    for (int t = s0; t < s1; ++t) {
+        int ahead = s1 - 1 - t;
+        if (ahead > C::NST - 2) ahead = C::NST - 2;
+        wait_stage_and_barrier<C::PW, C::NST - 2>(ahead);   // stage t landed for every wave
+        {
+            const int nt = t + C::NST - 1;                   // refill the slot read in iteration t-1
+            int nslot = slot + C::NST - 1;
+            if (nslot >= C::NST) nslot -= C::NST;
+            if (nt < s1) issue(nt, nslot);
+        }
+        const char* sb = smem + slot * C::LDS_STAGE;
+        f32x4 acc0 = *reinterpret_cast<const f32x4*>(sb + C::KEYB + wave * 128 + g * 16);
+        f32x4 acc1 = *reinterpret_cast<const f32x4*>(sb + C::KEYB + wave * 128 + 64 + g * 16);
+#pragma unroll
+        for (int s = 0; s < C::KSTEPS; ++s) {
+            const int ch = swz_chunk(4 * s + g, c);
+            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sb + row_off + ch * 16);
+            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sb + row_off + 16 * C::ROWB + ch * 16);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[s], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[s], acc1, 0, 0, 0);
+        }
+        // D layout: lane (g,c) holds query c, keys 4g..4g+3 of each 16-key tile
+        const int kbase = t * STAGE_KEYS + g * 4;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = tt == 0 ? acc0[r] : acc1[r];
+                if (sc > lmin) {
+                    float cv = sc;
+                    int ci = kbase + tt * 16 + r;
+#pragma unroll
+                    for (int j = 0; j < LISTK; ++j) {
+                        const bool gt = cv > lv[j];
+                        const float ov = lv[j];
+                        const int oi = li[j];
+                        lv[j] = gt ? cv : ov;
+                        li[j] = gt ? ci : oi;
+                        cv = gt ? ov : cv;
+                        ci = gt ? oi : ci;
+                    }
+                    lmin = fmaxf(thr0, lv[LISTK - 1]);
+                }
+            }
+        }
+        slot = slot + 1 == C::NST ? 0 : slot + 1;
+    }
+
+    // lists out: [query][wg][g][LISTK]
+    const size_t o = (((size_t)(wave * 16 + c) * nwg + blockIdx.x) * 4 + g) * LISTK;
+#pragma unroll
+    for (int j = 0; j < LISTK; j += 4) {
+        *reinterpret_cast<f32x4*>(out_val + o + j) = f32x4{lv[j], lv[j + 1], lv[j + 2], lv[j + 3]};
+        *reinterpret_cast<int4*>(out_idx + o + j) = make_int4(li[j], li[j + 1], li[j + 2], li[j + 3]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pack: fp32 rows -> swizzled bf16 stage blobs + fp32 bias tail.  One 256-thread block per stage.
+template <int D>
+__global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ db, long long n, int metric,
+                                                   char* __restrict__ packed) {
+    using C = ScanCfg<D>;
+    const long long stage = blockIdx.x;
+    char* blob = packed + (size_t)stage * C::STAGEB;
+    for (int id = threadIdx.x; id < STAGE_KEYS * C::CHUNKS; id += 256) {
+        const int row = id / C::CHUNKS, ch = id % C::CHUNKS;
+        const long long key = stage * STAGE_KEYS + row;
+        bf16x8 v;
+        if (key < n) {
+            const float* p = db + (size_t)key * D + ch * 8;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+            v = bf16x8{(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3],
+                       (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
+        } else {
+            v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        *reinterpret_cast<bf16x8*>(blob + row * C::ROWB + swz_chunk(ch, row) * 16) = v;
+    }
+    // bias tail: one wave per 8 rows
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int row = wave * 8; row < wave * 8 + 8; ++row) {
+        const long long key = stage * STAGE_KEYS + row;
+        float bias;
+        if (key < n) {
+            float s = 0.f;
+            if (metric == KEDS_METRIC_L2) {
+                const float* p = db + (size_t)key * D;
+                for (int i = lane; i < D; i += 64) s += p[i] * p[i];
+                s = wave_sum(s);
+            }
+            bias = -0.5f * s;
+        } else {
+            bias = -INFINITY;
+        }
+        if (lane == 0) reinterpret_cast<float*>(blob + C::KEYB)[row] = bias;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// qprep: one wave per query row (rows >= nq of the bf16 block are zeroed)
+__global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q, int nq, int dim, int normalize,
+                                                    float* __restrict__ qn, bf16_t* __restrict__ qb, int qb_rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= qb_rows) return;
+    if (row >= nq) {
+        for (int i = lane; i < dim; i += 64) qb[(size_t)row * dim + i] = (bf16_t)0.f;
+        return;
+    }
+    const float* p = q + (size_t)row * dim;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s += p[i] * p[i];
+    s = wave_sum(s);
+    const float nrm = sqrtf(s);
+    for (int i = lane; i < dim; i += 64) {
+        const float v = normalize ? p[i] / nrm : p[i];
+        qn[(size_t)row * dim + i] = v;
+        qb[(size_t)row * dim + i] = (bf16_t)v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// merge: one 256-thread block per query; lists sorted descending; tournament for NCAND rounds.
+// order key: (value desc, id asc); empty entries are (-inf, -1).
+__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) {
+    // true if (va, ia) ranks before (vb, ib); ids are unique except the -1 fillers
+    return va > vb || (va == vb && (unsigned)ia < (unsigned)ib);
+}
+
+constexpr int MERGE_MAXL = 4;  // lists per thread: nwg*4 <= 1024
+
+__global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ val, const int* __restrict__ idx,
+                                                          int nlists, int* __restrict__ cand_idx,
+                                                          float* __restrict__ cand_val) {
+    __shared__ float s_v[4];
+    __shared__ int s_i[4];
+    __shared__ int s_t[4];
+    const int q = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* v = val + (size_t)q * nlists * LISTK;
+    const int* ix = idx + (size_t)q * nlists * LISTK;
+    int pos[MERGE_MAXL];
+    float hv[MERGE_MAXL];
+    int hi[MERGE_MAXL];
+#pragma unroll
+    for (int m = 0; m < MERGE_MAXL; ++m) {
+        const int l = tid + m * 256;
+        pos[m] = 0;
+        hv[m] = l < nlists ? v[(size_t)l * LISTK] : -INFINITY;
+        hi[m] = l < nlists ? ix[(size_t)l * LISTK] : -1;
+    }
+    for (int round = 0; round < NCAND; ++round) {
+        // thread-local best head
+        float bv = hv[0];
+        int bi = hi[0], bm = 0;
+#pragma unroll
+        for (int m = 1; m < MERGE_MAXL; ++m)
+            if (better(hv[m], hi[m], bv, bi)) {
+                bv = hv[m];
+                bi = hi[m];
+                bm = m;
+            }
+        // wave argmax
+        float wv = bv;
+        int wi = bi, wt = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(wv, o, 64);
+            const int oi = __shfl_xor(wi, o, 64);
+            const int ot = __shfl_xor(wt, o, 64);
+            if (better(ov, oi, wv, wi) || (ov == wv && oi == wi && ot < wt)) {
+                wv = ov;
+                wi = oi;
+                wt = ot;
+            }
+        }
+        if (lane == 0) {
+            s_v[wave] = wv;
+            s_i[wave] = wi;
+            s_t[wave] = wt;
+        }
+        __syncthreads();
+        float gv = s_v[0];
+        int gi = s_i[0], gt = s_t[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better(s_v[w], s_i[w], gv, gi) || (s_v[w] == gv && s_i[w] == gi && s_t[w] < gt)) {
+                gv = s_v[w];
+                gi = s_i[w];
+                gt = s_t[w];
+            }
+        __syncthreads();
+        if (tid == 0) {
+            cand_idx[q * NCAND + round] = gi;
+            cand_val[q * NCAND + round] = gv;
+        }
+        if (tid == gt && gi >= 0) {
+            // advance the winning list (static indexing: no scratch)
+#pragma unroll
+            for (int m = 0; m < MERGE_MAXL; ++m)
+                if (m == bm) {
+                    const int l = tid + m * 256;
+                    pos[m] += 1;
+                    if (pos[m] < LISTK) {
+                        hv[m] = v[(size_t)l * LISTK + pos[m]];
+                        hi[m] = ix[(size_t)l * LISTK + pos[m]];
+                    } else {
+                        hv[m] = -INFINITY;
+                        hi[m] = -1;
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// rerank: exact fp32 distance (L2: sum (q-x)^2; IP: q.x) of every candidate; one wave each.
+__global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, int dim, int metric,
+                                                     const float* __restrict__ qn, const int* __restrict__ cand_idx,
+                                                     float* __restrict__ cand_d, int total) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= total) return;
+    const int q = w / NCAND;
+    const int id = cand_idx[w];
+    if (id < 0) {
+        if (lane == 0) cand_d[w] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+        return;
+    }
+    const float* x = db + (size_t)id * dim;
+    const float* qq = qn + (size_t)q * dim;
+    float s = 0.f;
+    if (metric == KEDS_METRIC_L2) {
+        for (int i = lane * 4; i < dim; i += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qq + i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(x + i);
+            const f32x4 d = a - b;
+            s += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+        }
+    } else {
+        for (int i = lane * 4; i < dim; i += 256) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qq + i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(x + i);
+            s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) cand_d[w] = s;
+}
+
+// select: one wave per query; rank the NCAND (=64) candidates by (distance, id); write top-k.
+__global__ __launch_bounds__(64) void select_kernel(const int* __restrict__ cand_idx, const float* __restrict__ cand_d,
+                                                    int metric, int k, long long id_base, float* __restrict__ D,
+                                                    long long* __restrict__ I) {
+    const int q = blockIdx.x, lane = threadIdx.x;
+    const float d = cand_d[q * NCAND + lane];
+    const int id = cand_idx[q * NCAND + lane];
+    // key: smaller is better
+    const float key = metric == KEDS_METRIC_L2 ? d : -d;
+    int rank = 0;
+    for (int j = 0; j < NCAND; ++j) {
+        const float kj = __shfl(key, j, 64);
+        const int ij = __shfl(id, j, 64);
+        const bool valid_j = ij >= 0;
+        const bool before = valid_j && (id < 0 || kj < key || (kj == key && ij < id));
+        rank += (before && j != lane) ? 1 : 0;
+    }
+    if (id < 0) rank = NCAND + lane;  // never selected before a valid one
+    if (rank < k) {
+        D[(size_t)q * k + rank] = d;
+        I[(size_t)q * k + rank] = id + id_base;
+    }
+}
+
+__global__ void fill_invalid_kernel(float* D, long long* I, long long count, int metric) {
+    const long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+    if (i < count) {
+        D[i] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+        I[i] = -1;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ db, int dim,
+                                                          const long long* __restrict__ idx, long long id_base,
+                                                          long long count, float* __restrict__ out) {
+    const long long w = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (w >= count) return;
+    const long long id = idx[w] - id_base;
+    float* o = out + (size_t)w * dim;
+    if (idx[w] < 0) {
+        for (int i = lane * 4; i < dim; i += 256) *reinterpret_cast<f32x4*>(o + i) = f32x4{0, 0, 0, 0};
+        return;
+    }
+    const float* x = db + (size_t)id * dim;
+    for (int i = lane * 4; i < dim; i += 256) *reinterpret_cast<f32x4*>(o + i) = *reinterpret_cast<const f32x4*>(x + i);
+}
+
+// merge of per-shard partial results [parts, nq, k] -> [nq, k]; one thread per query (tiny).
+__global__ void merge_parts_kernel(const float* __restrict__ Dp, const long long* __restrict__ Ip, int parts, int nq,
+                                   int k, int metric, float* __restrict__ D, long long* __restrict__ I) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    int pos[64];
+    for (int p = 0; p < parts; ++p) pos[p] = 0;
+    for (int r = 0; r < k; ++r) {
+        int bp = -1;
+        float bk = 0.f;
+        long long bi = 0;
+        for (int p = 0; p < parts; ++p) {
+            if (pos[p] >= k) continue;
+            const size_t o = ((size_t)p * nq + q) * k + pos[p];
+            const long long id = Ip[o];
+            if (id < 0) continue;
+            const float key = metric == KEDS_METRIC_L2 ? Dp[o] : -Dp[o];
+            if (bp < 0 || key < bk || (key == bk && id < bi)) {
+                bp = p;
+                bk = key;
+                bi = id;
+            }
+        }
+        if (bp < 0) {
+            D[(size_t)q * k + r] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+            I[(size_t)q * k + r] = -1;
+        } else {
+            D[(size_t)q * k + r] = metric == KEDS_METRIC_L2 ? bk : -bk;
+            I[(size_t)q * k + r] = bi;
+            pos[bp] += 1;
+        }
+    }
+}
+
+int device_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+struct SearchWs {
+    float* qn;       // [nq_pad, dim]
+    bf16_t* qb;      // [128, dim]
+    float* lval;     // [128, nwg, 4, LISTK]
+    int* lidx;
+    int* cidx;       // [128, NCAND]
+    float* cval;
+    float* cdist;
+    size_t bytes;
+};
+
+SearchWs carve(void* ws, int nq, int dim) {
+    SearchWs w;
+    char* p = (char*)ws;
+    const int nwg = 256;  // upper bound used for sizing
+    size_t off = 0;
+    auto take = [&](size_t b) {
+        char* r = p ? p + off : nullptr;
+        off += keds_align_up(b, 256);
+        return r;
+    };
+    const size_t nq_pad = keds_align_up((size_t)nq, QBLOCK);
+    w.qn = (float*)take(nq_pad * dim * sizeof(float));
+    w.qb = (bf16_t*)take((size_t)QBLOCK * dim * 2);
+    w.lval = (float*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(float));
+    w.lidx = (int*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(int));
+    w.cidx = (int*)take((size_t)QBLOCK * NCAND * sizeof(int));
+    w.cval = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
+    w.cdist = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
+    w.bytes = off;
+    return w;
+}
+
+template <int D>
+int launch_scan(const void* packed, int total_stages, const bf16_t* qb, float* lval, int* lidx, int nwg,
+                hipStream_t st) {
+    using C = ScanCfg<D>;
+    const size_t lds = (size_t)C::NST * C::LDS_STAGE;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)scan_topk_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            keds_set_error("scan: cannot raise dynamic LDS to %zu bytes", lds);
+            return KEDS_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    KedsProfScope prof(KEDS_PROF_SCAN, st);
+    scan_topk_kernel<D><<<nwg, SCAN_THREADS, lds, st>>>((const char*)packed, total_stages, qb, nullptr, lval, lidx);
+    return keds_check_launch("scan_topk_kernel");
+}
+
+template <int D>
+int launch_pack(const float* db, int64_t n, int metric, void* packed, hipStream_t st) {
+    const int64_t stages = (n + STAGE_KEYS - 1) / STAGE_KEYS;
+    pack_kernel<D><<<(unsigned)stages, 256, 0, st>>>(db, n, metric, (char*)packed);
+    return keds_check_launch("pack_kernel");
+}
+
+bool dim_supported(int dim) { return dim == 128 || dim == 256 || dim == 512 || dim == 768 || dim == 1024; }
+
+size_t stage_bytes(int dim) { return (size_t)STAGE_KEYS * dim * 2 + 128; }
+
+}  // namespace
+
+extern "C" size_t keds_index_packed_bytes(int64_t n, int dim) {
+    if (n < 0 || !dim_supported(dim)) return 0;
+    const int64_t stages = (n + STAGE_KEYS - 1) / STAGE_KEYS;
+    return (size_t)stages * stage_bytes(dim);
+}
+
+extern "C" int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream) {
+    KEDS_REQUIRE(db && packed && n > 0, "keds_index_pack: null pointer or empty database");
+    KEDS_REQUIRE(dim_supported(dim), "keds_index_pack: dim %d unsupported (128,256,512,768,1024)", dim);
+    KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "keds_index_pack: bad metric");
+    KEDS_REQUIRE(n < (1LL << 31) - 64, "keds_index_pack: at most 2^31 rows per shard");
+    hipStream_t st = (hipStream_t)stream;
+    switch (dim) {
+        case 128: return launch_pack<128>(db, n, metric, packed, st);
+        case 256: return launch_pack<256>(db, n, metric, packed, st);
+        case 512: return launch_pack<512>(db, n, metric, packed, st);
+        case 768: return launch_pack<768>(db, n, metric, packed, st);
+        default: return launch_pack<1024>(db, n, metric, packed, st);
+    }
+}
+
+extern "C" size_t keds_index_search_workspace_bytes(int nq, int dim) {
+    if (nq <= 0 || dim <= 0) return 0;
+    return carve(nullptr, nq, dim).bytes;
+}
+
+extern "C" int keds_index_search(const void* packed, const float* db, int64_t n, int dim, int metric,
+                                 const float* queries, int nq, int normalize_q, int k, int64_t id_base, float* D,
+                                 int64_t* I, float* rows_out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    KEDS_REQUIRE(packed && db && queries && D && I && workspace, "keds_index_search: null pointer");
+    KEDS_REQUIRE(dim_supported(dim), "keds_index_search: dim %d unsupported", dim);
+    KEDS_REQUIRE(n > 0 && nq > 0, "keds_index_search: empty database or query set");
+    KEDS_REQUIRE(k >= 1 && k <= LISTK, "keds_index_search: k must be in [1,%d] (got %d)", LISTK, k);
+    KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "keds_index_search: bad metric");
+    SearchWs w = carve(workspace, nq, dim);
+    if (workspace_bytes < w.bytes) {
+        keds_set_error("keds_index_search: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+        return KEDS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const int total_stages = (int)((n + STAGE_KEYS - 1) / STAGE_KEYS);
+    int nwg = device_cus();
+    if (nwg > 256) nwg = 256;
+    if (nwg > total_stages) nwg = total_stages;
+    const int nlists = nwg * 4;
+    int rc;
+    {
+        const long long cnt = (long long)nq * k;
+        fill_invalid_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(D, (long long*)I, cnt, metric);
+        if ((rc = keds_check_launch("fill_invalid_kernel"))) return rc;
+    }
+    for (int q0 = 0; q0 < nq; q0 += QBLOCK) {
+        const int nb = nq - q0 < QBLOCK ? nq - q0 : QBLOCK;
+        float* qn = w.qn + (size_t)q0 * dim;
+        qprep_kernel<<<QBLOCK / 4, 256, 0, st>>>(queries + (size_t)q0 * dim, nb, dim, normalize_q, qn, w.qb, QBLOCK);
+        if ((rc = keds_check_launch("qprep_kernel"))) return rc;
+        switch (dim) {
+            case 128: rc = launch_scan<128>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
+            case 256: rc = launch_scan<256>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
+            case 512: rc = launch_scan<512>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
+            case 768: rc = launch_scan<768>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
+            default: rc = launch_scan<1024>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
+        }
+        if (rc) return rc;
+        {
+            KedsProfScope prof(KEDS_PROF_OTHER, st);
+            merge_lists_kernel<<<nb, 256, 0, st>>>(w.lval, w.lidx, nlists, w.cidx, w.cval);
+            if ((rc = keds_check_launch("merge_lists_kernel"))) return rc;
+            rerank_kernel<<<(nb * NCAND + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * NCAND);
+            if ((rc = keds_check_launch("rerank_kernel"))) return rc;
+            select_kernel<<<nb, 64, 0, st>>>(w.cidx, w.cdist, metric, k, (long long)id_base, D + (size_t)q0 * k,
+                                             (long long*)I + (size_t)q0 * k);
+            if ((rc = keds_check_launch("select_kernel"))) return rc;
+        }
+    }
+    if (rows_out) {
+        const long long cnt = (long long)nq * k;
+        gather_rows_kernel<<<(unsigned)((cnt + 3) / 4), 256, 0, st>>>(db, dim, (const long long*)I, (long long)id_base,
+                                                                       cnt, rows_out);
+        if ((rc = keds_check_launch("gather_rows_kernel"))) return rc;
+    }
+    return KEDS_OK;
+}
+
+extern "C" int keds_topk_merge_parts(const float* D_parts, const int64_t* I_parts, int parts, int nq, int k,
+                                     int metric, float* D, int64_t* I, void* stream) {
+    KEDS_REQUIRE(D_parts && I_parts && D && I, "keds_topk_merge_parts: null pointer");
+    KEDS_REQUIRE(parts >= 1 && parts <= 64 && nq > 0 && k > 0, "keds_topk_merge_parts: bad sizes");
+    merge_parts_kernel<<<(nq + 63) / 64, 64, 0, (hipStream_t)stream>>>(D_parts, (const long long*)I_parts, parts, nq,
+                                                                       k, metric, D, (long long*)I);
+    return keds_check_launch("merge_parts_kernel");
+}
+
+extern "C" int keds_gather_rows(const float* db, int dim, const int64_t* idx, int64_t count, float* out,
+                                void* stream) {
+    KEDS_REQUIRE(db && idx && out && count > 0, "keds_gather_rows: bad argument");
+    KEDS_REQUIRE(dim % 4 == 0, "keds_gather_rows: dim must be a multiple of 4");
+    gather_rows_kernel<<<(unsigned)((count + 3) / 4), 256, 0, (hipStream_t)stream>>>(db, dim, (const long long*)idx, 0,
+                                                                                      count, out);
+    return keds_check_launch("gather_rows_kernel");
+}

@@ -1,0 +1,200 @@
+// Whole-tower forward passes built from the kernels in gemm/attention/elementwise:
+//   keds_tower_forward : N pre-LN residual blocks        (src/model/model.py:305-326,372-373)
+//   keds_vit_forward   : CLIP.encode_image, ViT branch   (src/model/model.py:569-575,393-415)
+//   keds_text_forward  : CLIP.encode_text / encode_text_img_retrieval (src/model/model.py:577-590,808-851)
+// Host code only: every launch is asynchronous on the caller's stream, the caller owns the
+// workspace, nothing is allocated or synchronised here.
+#include "keds_common.h"
+
+int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
+                        const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
+int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int S, int d, hipStream_t st);
+
+namespace {
+
+size_t pad_rows(size_t m) { return keds_align_up(m, 128); }
+
+// scratch of one tower: h [Mp,w] bf16 | big [Mp,4w] bf16 (qkv [Mp,3w] + attn [Mp,w], later the MLP hidden)
+struct TowerWs {
+    char* h;
+    char* big;
+    size_t bytes;
+};
+
+TowerWs carve_tower(void* ws, int width, int seq, int B) {
+    const size_t Mp = pad_rows((size_t)B * seq);
+    TowerWs t;
+    char* p = (char*)ws;
+    const size_t hb = keds_align_up(Mp * width * 2, 256);
+    const size_t bb = keds_align_up(Mp * (size_t)width * 4 * 2, 256);
+    t.h = p;
+    t.big = p ? p + hb : nullptr;
+    t.bytes = hb + bb;
+    return t;
+}
+
+int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st) {
+    const int w = p->width, S = p->seq;
+    const int M = B * S;
+    const size_t Mp = pad_rows((size_t)M);
+    TowerWs t = carve_tower(ws, w, S, B);
+    void* qkv = t.big;                         // [Mp, 3w]
+    void* att = t.big + Mp * (size_t)w * 3 * 2;  // [Mp, w]
+    void* hid = t.big;                         // [Mp, 4w] (aliases qkv|att, both dead by then)
+    int rc;
+    for (int l = 0; l < p->layers; ++l) {
+        const keds_block_params& k = p->blocks[l];
+        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
+        if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
+        if ((rc = keds_attention(qkv, att, B, S, p->heads, p->causal, st))) return rc;
+        if ((rc = keds_gemm_bt(att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
+        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;
+        if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, hid, M, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st)))
+            return rc;
+        if ((rc = keds_gemm_bt(hid, k.proj_w, k.proj_b, x, M, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
+            return rc;
+    }
+    return KEDS_OK;
+}
+
+int check_tower(const keds_tower_params* p, const char* who) {
+    if (!p || !p->blocks || p->layers <= 0) {
+        keds_set_error("%s: missing tower parameters", who);
+        return KEDS_E_ARG;
+    }
+    if (p->width % 128 != 0 || p->width != p->heads * 64) {
+        keds_set_error("%s: width %d must be heads*64 and a multiple of 128", who, p->width);
+        return KEDS_E_ARG;
+    }
+    if (p->seq < 1 || p->seq > 288) {
+        keds_set_error("%s: sequence length %d unsupported", who, p->seq);
+        return KEDS_E_ARG;
+    }
+    return KEDS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t keds_tower_workspace_bytes(int width, int seq, int B) {
+    return carve_tower(nullptr, width, seq, B).bytes;
+}
+
+extern "C" int keds_tower_forward(const keds_tower_params* p, float* x, int B, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    int rc = check_tower(p, "keds_tower_forward");
+    if (rc) return rc;
+    KEDS_REQUIRE(x && workspace && B > 0, "keds_tower_forward: bad argument");
+    if (workspace_bytes < keds_tower_workspace_bytes(p->width, p->seq, B)) {
+        keds_set_error("keds_tower_forward: workspace too small");
+        return KEDS_E_WORKSPACE;
+    }
+    return tower_forward(p, x, B, workspace, (hipStream_t)stream);
+}
+
+// ---- ViT -------------------------------------------------------------------------------------
+namespace {
+struct VitWs {
+    float* x;      // [Mp, w] fp32 residual stream
+    char* tower;   // tower scratch (the im2col matrix aliases its head)
+    char* ro;      // read-out scratch
+    size_t bytes;
+};
+VitWs carve_vit(const keds_vit_params* p, int B, void* ws) {
+    VitWs v;
+    char* base = (char*)ws;
+    const int w = p->tower.width, S = p->tower.seq;
+    const size_t Mp = pad_rows((size_t)B * S);
+    const size_t xb = keds_align_up(Mp * w * sizeof(float), 256);
+    size_t tb = keds_tower_workspace_bytes(w, S, B);
+    const size_t colb = keds_align_up(pad_rows((size_t)B * (S - 1)) * p->kpad * 2, 256);
+    if (colb > tb) tb = colb;
+    const size_t rb = keds_align_up(keds_readout_workspace_bytes(B, w), 256);
+    v.x = (float*)base;
+    v.tower = base ? base + xb : nullptr;
+    v.ro = base ? base + xb + tb : nullptr;
+    v.bytes = xb + tb + rb;
+    return v;
+}
+}  // namespace
+
+extern "C" size_t keds_vit_workspace_bytes(const keds_vit_params* p, int B) {
+    if (!p || B <= 0) return 0;
+    return carve_vit(p, B, nullptr).bytes;
+}
+
+extern "C" int keds_vit_forward(const keds_vit_params* p, const float* image, int B, float* out, int normalize,
+                                void* workspace, size_t workspace_bytes, void* stream) {
+    KEDS_REQUIRE(p && image && out && workspace && B > 0, "keds_vit_forward: bad argument");
+    int rc = check_tower(&p->tower, "keds_vit_forward");
+    if (rc) return rc;
+    const int w = p->tower.width, S = p->tower.seq, G = S - 1;
+    const int g = p->resolution / p->patch;
+    KEDS_REQUIRE(p->resolution % p->patch == 0 && g * g == G, "keds_vit_forward: seq must be (res/patch)^2 + 1");
+    KEDS_REQUIRE(p->kpad % 64 == 0 && p->kpad >= 3 * p->patch * p->patch, "keds_vit_forward: bad kpad");
+    KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_vit_forward: embed_dim must be a multiple of 128");
+    VitWs v = carve_vit(p, B, workspace);
+    if (workspace_bytes < v.bytes) {
+        keds_set_error("keds_vit_forward: workspace %zu < %zu", workspace_bytes, v.bytes);
+        return KEDS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    void* col = v.tower;
+    if ((rc = keds_im2col(image, col, B, p->resolution, p->patch, p->kpad, stream))) return rc;
+    if ((rc = keds_gemm_bt(col, p->conv_w, nullptr, v.x, B * G, w, p->kpad, KEDS_EPI_PATCH_F32, p->pos_emb, G, stream)))
+        return rc;
+    if ((rc = keds_cls_rows_impl(v.x, p->class_emb, p->pos_emb, B, S, w, st))) return rc;
+    // ln_pre in place (each wave holds its whole row in registers before it stores)
+    if ((rc = keds_layernorm_impl(v.x, w, nullptr, 1, p->ln_pre_g, p->ln_pre_b, v.x, 1, B * S, w, st))) return rc;
+    if ((rc = tower_forward(&p->tower, v.x, B, v.tower, st))) return rc;
+    return keds_readout(v.x, S, nullptr, p->ln_post_g, p->ln_post_b, p->proj_t, out, B, w, p->embed_dim, normalize, v.ro,
+                        keds_readout_workspace_bytes(B, w), stream);
+}
+
+// ---- text ------------------------------------------------------------------------------------
+namespace {
+struct TextWs {
+    float* x;
+    char* tower;
+    char* ro;
+    size_t bytes;
+};
+TextWs carve_text(const keds_text_params* p, int B, void* ws) {
+    TextWs v;
+    char* base = (char*)ws;
+    const int w = p->tower.width, S = p->tower.seq;
+    const size_t Mp = pad_rows((size_t)B * S);
+    const size_t xb = keds_align_up(Mp * w * sizeof(float), 256);
+    const size_t tb = keds_tower_workspace_bytes(w, S, B);
+    const size_t rb = keds_align_up(keds_readout_workspace_bytes(B, w), 256);
+    v.x = (float*)base;
+    v.tower = base ? base + xb : nullptr;
+    v.ro = base ? base + xb + tb : nullptr;
+    v.bytes = xb + tb + rb;
+    return v;
+}
+}  // namespace
+
+extern "C" size_t keds_text_workspace_bytes(const keds_text_params* p, int B) {
+    if (!p || B <= 0) return 0;
+    return carve_text(p, B, nullptr).bytes;
+}
+
+extern "C" int keds_text_forward(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
+                                 const float* img_tokens, int n_tok, int insert_col, int B, float* out, int normalize,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    KEDS_REQUIRE(p && tokens && readout_row && out && workspace && B > 0, "keds_text_forward: bad argument");
+    int rc = check_tower(&p->tower, "keds_text_forward");
+    if (rc) return rc;
+    KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_text_forward: embed_dim must be a multiple of 128");
+    TextWs v = carve_text(p, B, workspace);
+    if (workspace_bytes < v.bytes) {
+        keds_set_error("keds_text_forward: workspace %zu < %zu", workspace_bytes, v.bytes);
+        return KEDS_E_WORKSPACE;
+    }
+    const int w = p->tower.width, L = p->tower.seq;
+    if ((rc = keds_embed_tokens(tokens, p->token_emb, p->pos_emb, img_tokens, n_tok, insert_col, v.x, B, L, w, stream)))
+        return rc;
+    if ((rc = tower_forward(&p->tower, v.x, B, v.tower, (hipStream_t)stream))) return rc;
+    return keds_readout(v.x, L, readout_row, p->ln_final_g, p->ln_final_b, p->proj_t, out, B, w, p->embed_dim, normalize,
+                        v.ro, keds_readout_workspace_bytes(B, w), stream);
+}

@@ -1,0 +1,203 @@
+"""Faiss-shaped flat index backed by the gfx950 scan kernel.
+
+Mirrors the object the reference builds at src/eval_retrieval.py:289-298 and calls at
+src/eval_utils.py:169,177:
+
+    index = IndexFlatL2(768); index = index_cpu_to_all_gpus(index)
+    index.add(bases.numpy());  D, I = index.search(q_numpy, 16)
+
+`add` takes np.float32 [N, d] (or a torch tensor), `search` takes np.float32 [B, d] and
+returns (D float32 [B,k] ascending squared L2, I int64 [B,k]) as numpy arrays -- or torch
+device tensors when the query is a device tensor, which skips the D2H/H2D hop the reference
+pays.  `search_gather` additionally returns the gathered rows (eval_utils.py:171-172).
+
+Row ranges can be sharded over ranks: every rank holds rows
+[row0, row0 + n_local), searches them for ALL queries, the [B,k] partials are all-gathered
+with torch.distributed and merged keyed on (distance, id), so results are identical for any
+number of shards.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from ._lib import check, load, ptr, stream
+
+ArrayLike = Union[np.ndarray, torch.Tensor]
+
+
+class FlatIndex:
+    def __init__(self, d: int, metric: str = "l2", device: Optional[Union[str, torch.device]] = None,
+                 row0: int = 0):
+        if metric not in ("l2", "ip"):
+            raise ValueError("metric must be 'l2' or 'ip'")
+        if d not in (128, 256, 512, 768, 1024):
+            raise ValueError(f"dimension {d} unsupported (128, 256, 512, 768, 1024)")
+        self.d = d
+        self.metric = _lib.METRIC_L2 if metric == "l2" else _lib.METRIC_IP
+        self.device = torch.device(device) if device is not None else None
+        self.row0 = int(row0)            # global id of local row 0 (sharding)
+        self.rows: Optional[torch.Tensor] = None      # fp32 [n, d] on device (re-rank + gather source)
+        self.packed: Optional[torch.Tensor] = None    # bf16 scan image
+        self._ws = _lib.Workspace()
+
+    # ---- faiss-like surface -------------------------------------------------------------------
+    @property
+    def ntotal(self) -> int:
+        return 0 if self.rows is None else int(self.rows.shape[0])
+
+    def _dev(self) -> torch.device:
+        if self.device is None:
+            _lib.require_gpu()
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        return self.device
+
+    def add(self, x: ArrayLike) -> None:
+        """Append rows and (re)build the bf16 scan image.  x: float32 [n, d]."""
+        t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if isinstance(x, np.ndarray) else x
+        if t.dim() != 2 or t.shape[1] != self.d:
+            raise ValueError(f"expected [n, {self.d}] rows, got {tuple(t.shape)}")
+        t = t.to(self._dev(), dtype=torch.float32).contiguous()
+        self.rows = t if self.rows is None else torch.cat([self.rows, t]).contiguous()
+        lib = load()
+        n = self.rows.shape[0]
+        nbytes = lib.keds_index_packed_bytes(n, self.d)
+        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        check(lib.keds_index_pack(ptr(self.rows), n, self.d, self.metric, ptr(self.packed), stream()),
+              "keds_index_pack")
+
+    def reset(self) -> None:
+        self.rows = None
+        self.packed = None
+
+    # ---- search ---------------------------------------------------------------------------------
+    def search_device(self, q: torch.Tensor, k: int, normalize: bool = False,
+                      gather: bool = False) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:
+        """Device-resident search.  q fp32 [B, d] on the index's device."""
+        if self.rows is None:
+            raise RuntimeError("search on an empty index")
+        if not (1 <= k <= _lib.SCAN_MAX_K):
+            raise ValueError(f"k must be in [1, {_lib.SCAN_MAX_K}] for the scan path (got {k})")
+        if q.dim() != 2 or q.shape[1] != self.d:
+            raise ValueError(f"expected [B, {self.d}] queries, got {tuple(q.shape)}")
+        q = q.to(self.device, dtype=torch.float32).contiguous()
+        B = q.shape[0]
+        lib = load()
+        nbytes = lib.keds_index_search_workspace_bytes(B, self.d)
+        ws = self._ws.get(nbytes, self.device)
+        D = torch.empty((B, k), dtype=torch.float32, device=self.device)
+        I = torch.empty((B, k), dtype=torch.int64, device=self.device)
+        rows = torch.empty((B, k, self.d), dtype=torch.float32, device=self.device) if gather else None
+        check(lib.keds_index_search(ptr(self.packed), ptr(self.rows), self.rows.shape[0], self.d, self.metric,
+                                    ptr(q), B, 1 if normalize else 0, k, self.row0, ptr(D), ptr(I), ptr(rows),
+                                    ptr(ws), ws.numel(), stream()), "keds_index_search")
+        return D, I, rows
+
+    def search(self, q: ArrayLike, k: int):
+        """Faiss call shape: numpy in -> numpy out; device tensor in -> device tensors out."""
+        if isinstance(q, np.ndarray):
+            D, I, _ = self.search_device(torch.from_numpy(np.ascontiguousarray(q, dtype=np.float32)), k)
+            return D.cpu().numpy(), I.cpu().numpy()
+        D, I, _ = self.search_device(q, k)
+        return D, I
+
+    def search_gather(self, q: torch.Tensor, k: int, normalize: bool = False):
+        """(D, I, rows [B,k,d]) with the winners' fp32 rows gathered on device."""
+        return self.search_device(q, k, normalize=normalize, gather=True)
+
+
+def IndexFlatL2(d: int) -> FlatIndex:
+    """faiss.IndexFlatL2(d) stand-in (src/eval_retrieval.py:291)."""
+    return FlatIndex(d, "l2")
+
+
+def IndexFlatIP(d: int) -> FlatIndex:
+    return FlatIndex(d, "ip")
+
+
+def index_cpu_to_all_gpus(index: FlatIndex) -> FlatIndex:
+    """faiss.index_cpu_to_all_gpus stand-in (src/eval_retrieval.py:292): the index already lives on
+    this process's GPU; multi-GPU sharding is per process (see ShardedFlatIndex)."""
+    return index
+
+
+# ---------------------------------------------------------------------------------------------------
+# sharding over ranks (one process per GPU, torch.distributed; backend "nccl" == RCCL on ROCm)
+# ---------------------------------------------------------------------------------------------------
+def shard_bounds(n: int, world: int, rank: int) -> Tuple[int, int]:
+    """Rows [lo, hi) of shard `rank`: contiguous, sizes differ by at most one 32-row stage."""
+    stages = (n + 31) // 32
+    lo = (stages * rank // world) * 32
+    hi = min(n, (stages * (rank + 1) // world) * 32)
+    return lo, hi
+
+
+def merge_partials(D_parts: torch.Tensor, I_parts: torch.Tensor, metric: int = _lib.METRIC_L2):
+    """Host-side (torch) merge of [parts, B, k] partial results keyed on (distance, id): the same
+    ordering the device merge uses.  Works on CPU tensors, so the N>1 logic is testable with gloo."""
+    parts, B, k = D_parts.shape
+    D = D_parts.permute(1, 0, 2).reshape(B, parts * k)
+    I = I_parts.permute(1, 0, 2).reshape(B, parts * k)
+    key = D if metric == _lib.METRIC_L2 else -D
+    key = torch.where(I < 0, torch.full_like(key, float("inf")), key)
+    # lexicographic (key, id): sort by id first, then stable sort by key
+    o1 = torch.sort(I, dim=1, stable=True).indices
+    key1 = torch.gather(key, 1, o1)
+    o2 = torch.sort(key1, dim=1, stable=True).indices
+    order = torch.gather(o1, 1, o2)[:, :k]
+    return torch.gather(D, 1, order), torch.gather(I, 1, order)
+
+
+def exchange_and_merge(D: torch.Tensor, I: torch.Tensor, metric: int = _lib.METRIC_L2, group=None):
+    """All-gather every rank's [B,k] partial result and merge keyed on (distance, id).
+
+    One small collective per search (B*k*12 bytes per rank: latency-bound on xGMI).
+    Device tensors are merged by the HIP kernel (keds_topk_merge_parts); CPU tensors -- the gloo
+    tests of the multi-rank logic -- by `merge_partials`, which a GPU test pins to the kernel."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    Dp = [torch.empty_like(D) for _ in range(world)]
+    Ip = [torch.empty_like(I) for _ in range(world)]
+    dist.all_gather(Dp, D.contiguous(), group=group)
+    dist.all_gather(Ip, I.contiguous(), group=group)
+    Dp, Ip = torch.stack(Dp), torch.stack(Ip)
+    if D.is_cuda:
+        return ops.topk_merge_parts(Dp, Ip, metric)
+    return merge_partials(Dp, Ip, metric)
+
+
+class ShardedFlatIndex:
+    """Row-sharded index: rank r owns rows shard_bounds(n, world, r).
+
+    search(q): every rank passes the SAME queries (all-gather them first if they were produced
+    data-parallel); each scans its shard, the [B,k] partials are all-gathered and merged.
+    """
+
+    def __init__(self, d: int, metric: str = "l2", group=None, device=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.d = d
+        self.metric_name = metric
+        self.local: Optional[FlatIndex] = None
+        self.device = device
+        self.n_global = 0
+
+    def add_global(self, x: ArrayLike) -> None:
+        """Give every rank the full matrix (or a view of it); each keeps only its shard."""
+        n = x.shape[0]
+        lo, hi = shard_bounds(n, self.world, self.rank)
+        self.n_global = n
+        self.local = FlatIndex(self.d, self.metric_name, device=self.device, row0=lo)
+        self.local.add(x[lo:hi])
+
+    def search(self, q: torch.Tensor, k: int, normalize: bool = False):
+        D, I, _ = self.local.search_device(q, k, normalize=normalize)
+        if self.world == 1:
+            return D, I
+        return exchange_and_merge(D, I, self.local.metric, self.group)

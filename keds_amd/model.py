@@ -1,0 +1,502 @@
+"""Drop-in model API of the KEDs retrieval path on MI355X.
+
+Same class names, constructor arguments, method signatures and ``state_dict`` keys as the
+reference's ``src/model/model.py`` (CLIP :431-911, IM2TEXT :105-123, CrossFormer :81-101,
+build_model :951, convert_weights :927), so reference checkpoints load unchanged
+(``main.py:330-341`` layout) and reference call sites (``eval_utils.py:610,652-695``,
+``eval_retrieval.py:96-101``) run as written.  The modules here only HOLD parameters
+(torch.nn containers); every forward runs hand-written gfx950 kernels through
+``libkeds_hip.so`` -- bf16 MFMA GEMMs with fp32 accumulation, fp32 residual stream,
+fp32 LayerNorm/softmax statistics.  There is no PyTorch compute path and no CPU fallback:
+calling a forward without the library or without a GPU raises RuntimeError.
+
+Out of scope: ModifiedResNet towers, `mid_feature`,
+`encode_text_img_vis`, the training-only splice variants and `forward(extra=True)` (undefined
+in the reference itself, App. B).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check, load, ptr, stream
+
+
+def _bf16(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.bfloat16).contiguous()
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameter containers (key names are the checkpoint contract)
+# ---------------------------------------------------------------------------------------------------
+class LayerNorm(nn.LayerNorm):
+    """Parameter holder; the statistics run in fp32 inside the HIP kernels (model.py:291-297)."""
+
+
+class QuickGELU(nn.Module):
+    """x * sigmoid(1.702 x), fused into the c_fc GEMM epilogue (model.py:300-302)."""
+
+
+class ResidualAttentionBlock(nn.Module):
+    def __init__(self, d_model: int, n_head: int, attn_mask: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.attn = nn.MultiheadAttention(d_model, n_head)     # holds in_proj_weight/bias, out_proj.*
+        self.ln_1 = LayerNorm(d_model)
+        self.mlp = nn.Sequential(OrderedDict([("c_fc", nn.Linear(d_model, d_model * 4)), ("gelu", QuickGELU()),
+                                              ("c_proj", nn.Linear(d_model * 4, d_model))]))
+        self.ln_2 = LayerNorm(d_model)
+        self.causal = attn_mask is not None
+
+
+class Transformer(nn.Module):
+    def __init__(self, width: int, layers: int, heads: int, attn_mask: Optional[torch.Tensor] = None):
+        super().__init__()
+        self.width, self.layers, self.heads = width, layers, heads
+        self.resblocks = nn.Sequential(*[ResidualAttentionBlock(width, heads, attn_mask) for _ in range(layers)])
+
+
+class VisualTransformer(nn.Module):
+    def __init__(self, input_resolution: int, patch_size: int, width: int, layers: int, heads: int, output_dim: int):
+        super().__init__()
+        self.input_resolution, self.output_dim, self.patch_size = input_resolution, output_dim, patch_size
+        self.conv1 = nn.Conv2d(3, width, kernel_size=patch_size, stride=patch_size, bias=False)
+        scale = width ** -0.5
+        self.class_embedding = nn.Parameter(scale * torch.randn(width))
+        self.positional_embedding = nn.Parameter(scale * torch.randn((input_resolution // patch_size) ** 2 + 1, width))
+        self.ln_pre = LayerNorm(width)
+        self.transformer = Transformer(width, layers, heads)
+        self.ln_post = LayerNorm(width)
+        self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
+
+
+def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list) -> _lib.TowerParams:
+    blocks = (_lib.BlockParams * tr.layers)()
+    for i, blk in enumerate(tr.resblocks):
+        t = dict(
+            ln1_g=_f32(blk.ln_1.weight), ln1_b=_f32(blk.ln_1.bias), ln2_g=_f32(blk.ln_2.weight), ln2_b=_f32(blk.ln_2.bias),
+            qkv_w=_bf16(blk.attn.in_proj_weight), out_w=_bf16(blk.attn.out_proj.weight),
+            fc_w=_bf16(blk.mlp.c_fc.weight), proj_w=_bf16(blk.mlp.c_proj.weight),
+            qkv_b=_f32(blk.attn.in_proj_bias), out_b=_f32(blk.attn.out_proj.bias),
+            fc_b=_f32(blk.mlp.c_fc.bias), proj_b=_f32(blk.mlp.c_proj.bias))
+        for k, v in t.items():
+            setattr(blocks[i], k, ptr(v))
+        keep.append(t)
+    keep.append(blocks)
+    return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks)
+
+
+class _Packed:
+    """bf16/fp32 device copies of the weights in the layout the kernels want + the ABI structs."""
+
+    def __init__(self, clip: "CLIP"):
+        self.keep: list = []
+        v = clip.visual
+        width = v.conv1.weight.shape[0]
+        P = v.patch_size
+        kreal = 3 * P * P
+        self.kpad = (kreal + 63) // 64 * 64
+        conv = torch.zeros((width, self.kpad), dtype=torch.bfloat16, device=v.conv1.weight.device)
+        conv[:, :kreal] = v.conv1.weight.detach().reshape(width, kreal).to(torch.bfloat16)
+        g = v.input_resolution // P
+        t = dict(conv_w=conv, class_emb=_f32(v.class_embedding), pos_emb=_f32(v.positional_embedding),
+                 ln_pre_g=_f32(v.ln_pre.weight), ln_pre_b=_f32(v.ln_pre.bias), ln_post_g=_f32(v.ln_post.weight),
+                 ln_post_b=_f32(v.ln_post.bias), proj_t=_bf16(v.proj.detach().t()))
+        self.keep.append(t)
+        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep), v.input_resolution, P,
+                                  self.kpad, v.output_dim, *[ptr(t[k]) for k in (
+                                      "conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
+                                      "ln_post_b", "proj_t")])
+        tt = dict(token_emb=_f32(clip.token_embedding.weight), pos_emb=_f32(clip.positional_embedding),
+                  ln_final_g=_f32(clip.ln_final.weight), ln_final_b=_f32(clip.ln_final.bias),
+                  proj_t=_bf16(clip.text_projection.detach().t()))
+        self.keep.append(tt)
+        self.text = _lib.TextParams(_pack_tower(clip.transformer, clip.context_length, True, self.keep),
+                                    clip.vocab_size, clip.embed_dim,
+                                    *[ptr(tt[k]) for k in ("token_emb", "pos_emb", "ln_final_g", "ln_final_b", "proj_t")])
+        self.device = conv.device
+
+
+class CLIP(nn.Module):
+    def __init__(self, embed_dim: int, image_resolution: int, vision_layers: Union[Tuple[int, int, int, int], int],
+                 vision_width: int, vision_patch_size: int, context_length: int, vocab_size: int,
+                 transformer_width: int, transformer_heads: int, transformer_layers: int,
+                 extra_transformer_layers: int = 0, share_projection_layer: bool = True):
+        super().__init__()
+        if isinstance(vision_layers, (tuple, list)):
+            raise NotImplementedError("ModifiedResNet visual towers are out of scope (ViT only)")
+        if extra_transformer_layers:
+            raise NotImplementedError("extra_transformer_layers is unused by the retrieval path")
+        self.embed_dim, self.context_length = embed_dim, context_length
+        self.share_projection_layer, self.has_extra = share_projection_layer, False
+        self.visual = VisualTransformer(image_resolution, vision_patch_size, vision_width, vision_layers,
+                                        vision_width // 64, embed_dim)
+        self.transformer_width = transformer_width
+        self.transformer = Transformer(transformer_width, transformer_layers, transformer_heads,
+                                       attn_mask=self.build_attention_mask())
+        self.vocab_size = vocab_size
+        self.end_id = vocab_size - 1
+        self.token_embedding = nn.Embedding(vocab_size, transformer_width)
+        self.positional_embedding = nn.Parameter(torch.empty(context_length, transformer_width))
+        self.ln_final = LayerNorm(transformer_width)
+        self.text_projection = nn.Parameter(torch.empty(transformer_width, embed_dim))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / 0.07))
+        self.initialize_parameters()
+        self._packed: Optional[_Packed] = None
+        self._ws = _lib.Workspace()
+
+    # ---- init (same distributions as model.py:511-541) ------------------------------------------
+    def initialize_parameters(self):
+        nn.init.normal_(self.token_embedding.weight, std=0.02)
+        nn.init.normal_(self.positional_embedding, std=0.01)
+        w, L = self.transformer.width, self.transformer.layers
+        for blk in self.transformer.resblocks:
+            nn.init.normal_(blk.attn.in_proj_weight, std=w ** -0.5)
+            nn.init.normal_(blk.attn.out_proj.weight, std=w ** -0.5 * (2 * L) ** -0.5)
+            nn.init.normal_(blk.mlp.c_fc.weight, std=(2 * w) ** -0.5)
+            nn.init.normal_(blk.mlp.c_proj.weight, std=w ** -0.5 * (2 * L) ** -0.5)
+        nn.init.normal_(self.text_projection, std=w ** -0.5)
+
+    def build_attention_mask(self):
+        m = torch.full((self.context_length, self.context_length), float("-inf"))
+        return m.triu_(1)           # kept for API parity; the kernel applies the causal mask itself
+
+    @property
+    def dtype(self):
+        return self.visual.conv1.weight.dtype
+
+    # ---- weight packing -------------------------------------------------------------------------
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._packed = None
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def repack(self):
+        """Re-read the parameters (call after mutating weights in place)."""
+        self._packed = None
+
+    def _engine(self) -> _Packed:
+        _lib.require_gpu()
+        load()
+        if not self.visual.conv1.weight.is_cuda:
+            raise RuntimeError("keds_amd.CLIP: move the model to the GPU first (model.cuda()); no CPU path exists")
+        if self._packed is None:
+            self._packed = _Packed(self)
+        return self._packed
+
+    # ---- encoders ------------------------------------------------------------------------------------
+    def encode_image(self, image, mid_feature=False, mask_token=False, normalize: bool = False):
+        """model.py:569-575 -> VisualTransformer.forward :393-415.  image [B,3,R,R] -> [B, embed_dim]."""
+        if mid_feature:
+            raise NotImplementedError("mid_feature is a training/ablation path (out of scope)")
+        eng = self._engine()
+        if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.visual.input_resolution \
+                or image.shape[3] != self.visual.input_resolution:
+            raise RuntimeError(f"expected images [B,3,{self.visual.input_resolution},{self.visual.input_resolution}], "
+                               f"got {tuple(image.shape)}")
+        img = image.to(eng.device, dtype=torch.float32).contiguous()
+        B = img.shape[0]
+        lib = load()
+        nbytes = lib.keds_vit_workspace_bytes(C.byref(eng.vit), B)
+        ws = self._ws.get(nbytes, eng.device)
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
+        check(lib.keds_vit_forward(C.byref(eng.vit), ptr(img), B, ptr(out), 1 if normalize else 0, ptr(ws), ws.numel(),
+                                   stream()), "keds_vit_forward")
+        return out.to(self.dtype)
+
+    def _eot_columns(self, text: torch.Tensor) -> torch.Tensor:
+        hits = text == self.end_id
+        if not bool((hits.sum(dim=1) == 1).all()):
+            # the reference indexes nonzero()[:,1] with arange(B): anything but one EOT per row fails there
+            raise IndexError("every token row must contain exactly one EOT token")
+        return hits.to(torch.int32).argmax(dim=1)
+
+    def _run_text(self, text, readout, img_tokens, insert_col, normalize):
+        eng = self._engine()
+        lib = load()
+        B = text.shape[0]
+        tok = text.to(eng.device, dtype=torch.int32).contiguous()
+        ro = readout.to(eng.device, dtype=torch.int32).contiguous()
+        it = None if img_tokens is None else img_tokens.to(eng.device, dtype=torch.float32).contiguous()
+        n_tok = 0 if it is None else it.shape[1]
+        nbytes = lib.keds_text_workspace_bytes(C.byref(eng.text), B)
+        ws = self._ws.get(nbytes, eng.device)
+        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
+        check(lib.keds_text_forward(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, ptr(out),
+                                    1 if normalize else 0, ptr(ws), ws.numel(), stream()), "keds_text_forward")
+        return out.to(self.dtype)
+
+    def encode_text(self, text, normalize: bool = False):
+        """model.py:577-590.  text int [B, L] -> [B, embed_dim]; read-out at the EOT column."""
+        if text.dim() != 2 or text.shape[1] != self.context_length:
+            raise RuntimeError(f"expected tokens [B,{self.context_length}], got {tuple(text.shape)}")
+        return self._run_text(text, self._eot_columns(text), None, 0, normalize)
+
+    def encode_text_img_retrieval(self, text, img_tokens, split_ind=4, repeat=True, normalize: bool = False):
+        """model.py:808-851.  The first `split_ind` token of ROW 0 is replaced by the 2 or 3 pseudo tokens of
+        every row, the tail shifts right, read-out at EOT column + n_tok - 1."""
+        if isinstance(img_tokens, tuple):
+            raise NotImplementedError("tuple img_tokens (multi-insert) is not used by the retrieval path")
+        b_size = img_tokens.shape[0]
+        if repeat:
+            text = text.repeat(b_size, 1)
+        if text.shape[0] != b_size or text.shape[1] != self.context_length:
+            raise RuntimeError(f"token rows {tuple(text.shape)} do not match {b_size} pseudo-token rows")
+        n_tok = img_tokens.shape[1]
+        if n_tok not in (2, 3):
+            raise RuntimeError("img_tokens must carry 2 or 3 pseudo tokens per row (sequence length would not be "
+                               f"{self.context_length})")
+        if img_tokens.shape[2] != self.transformer_width:
+            raise RuntimeError("pseudo-token width does not match the text transformer")
+        where = (text[0] == int(split_ind)).nonzero()
+        if where.numel() == 0:
+            raise IndexError("split token not present in text[0]")
+        ins = int(where[0])
+        readout = self._eot_columns(text) + (n_tok - 1)
+        if int(readout.max()) >= self.context_length:
+            raise IndexError("read-out row beyond the context length")
+        return self._run_text(text, readout, img_tokens, ins, normalize)
+
+    def get_text_tokens(self, text):
+        raise NotImplementedError("get_text_tokens is not on the retrieval path")
+
+    def forward(self, image, text, extra=False):
+        """model.py:894-911 (extra=True is broken in the reference: undefined encode_text_extra)."""
+        if extra:
+            raise NotImplementedError("extra text tower is not part of the retrieval path")
+        if image is None:
+            return self.encode_text(text)
+        if text is None:
+            return self.encode_image(image)
+        return self.encode_image(image, normalize=True), self.encode_text(text, normalize=True), self.logit_scale.exp()
+
+
+# ---------------------------------------------------------------------------------------------------
+# knowledge-injection modules
+# ---------------------------------------------------------------------------------------------------
+class IM2TEXT(nn.Module):
+    """model.py:105-123: (Linear, Dropout, ReLU) x n_layer then fc_out; eval-mode forward on HIP."""
+
+    def __init__(self, embed_dim=512, middle_dim=512, output_dim=512, n_layer=2, dropout=0.1):
+        super().__init__()
+        if not 1 <= n_layer <= 4:
+            raise ValueError("n_layer must be in [1,4]")
+        self.fc_out = nn.Linear(middle_dim, output_dim)
+        layers, dim = [], embed_dim
+        for _ in range(n_layer):
+            layers.append(nn.Sequential(nn.Linear(dim, middle_dim), nn.Dropout(dropout), nn.ReLU()))
+            dim = middle_dim
+        self.layers = nn.Sequential(*layers)
+        self.embed_dim, self.middle_dim, self.output_dim, self.n_layer = embed_dim, middle_dim, output_dim, n_layer
+        self._packed = None
+        self._ws = _lib.Workspace()
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._packed = None
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def params(self) -> _lib.Im2TextParams:
+        _lib.require_gpu()
+        if not self.fc_out.weight.is_cuda:
+            raise RuntimeError("keds_amd.IM2TEXT: move the module to the GPU first; no CPU path exists")
+        if self._packed is None:
+            keep = []
+            p = _lib.Im2TextParams()
+            p.dim_in, p.middle, p.dim_out, p.n_layer = self.embed_dim, self.middle_dim, self.output_dim, self.n_layer
+            for i, blk in enumerate(self.layers):
+                w, b = _bf16(blk[0].weight), _f32(blk[0].bias)
+                keep += [w, b]
+                p.w[i], p.b[i] = ptr(w), ptr(b)
+            ow, ob = _bf16(self.fc_out.weight), _f32(self.fc_out.bias)
+            keep += [ow, ob]
+            p.out_w, p.out_b = ptr(ow), ptr(ob)
+            self._packed = (p, keep)
+        return self._packed[0]
+
+    def forward(self, x: torch.Tensor):
+        if self.training:
+            raise RuntimeError("keds_amd.IM2TEXT runs the eval-mode forward only (dropout = identity); call .eval()")
+        p = self.params()
+        lib = load()
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1]).to(dtype=torch.float32).contiguous()
+        rows = x2.shape[0]
+        nbytes = lib.keds_im2text_workspace_bytes(C.byref(p), rows)
+        ws = self._ws.get(nbytes, x2.device)
+        out = torch.empty((rows, self.output_dim), dtype=torch.float32, device=x2.device)
+        check(lib.keds_im2text_forward(C.byref(p), ptr(x2), rows, ptr(out), ptr(ws), ws.numel(), stream()),
+              "keds_im2text_forward")
+        return out.reshape(*shape[:-1], self.output_dim).to(x.dtype)
+
+
+class CrossAttention(nn.Module):
+    """Parameter holder for one layer (model.py:37-54)."""
+
+    def __init__(self, q_dim, k_dim, v_dim, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        if dim_head != 64:
+            raise ValueError("the HIP cross-attention core is built for dim_head = 64")
+        inner = dim_head * heads
+        self.heads = heads
+        self.to_q = nn.Linear(q_dim, inner, bias=True)
+        self.to_k = nn.Linear(k_dim, inner, bias=True)
+        self.to_v = nn.Linear(v_dim, inner, bias=True)
+        self.to_out = nn.Sequential(nn.Linear(inner, q_dim), nn.Dropout(dropout))
+
+
+class CrossFormer(nn.Module):
+    """model.py:81-101: q chained through `num_layers` CrossAttention layers, k and v fixed."""
+
+    def __init__(self, q_dim, k_dim, v_dim, num_layers=1, heads=8, dim_head=64, dropout=0.):
+        super().__init__()
+        if not (q_dim == k_dim == v_dim):
+            raise ValueError("the HIP path needs q_dim == k_dim == v_dim")
+        self._num_layers, self.dim, self.heads = num_layers, q_dim, heads
+        self.cross_layers = nn.ModuleList([CrossAttention(q_dim, k_dim, v_dim, heads, dim_head, dropout)
+                                           for _ in range(num_layers)])
+        self._packed = None
+        self._ws = _lib.Workspace()
+
+    def _apply(self, fn, *a, **k):
+        self._packed = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        self._packed = None
+        return super().load_state_dict(state_dict, strict=strict, **kw)
+
+    def params(self) -> _lib.CrossFormerParams:
+        _lib.require_gpu()
+        if not self.cross_layers[0].to_q.weight.is_cuda:
+            raise RuntimeError("keds_amd.CrossFormer: move the module to the GPU first; no CPU path exists")
+        if self._packed is None:
+            keep = []
+            arr = (_lib.CrossLayerParams * self._num_layers)()
+            for i, l in enumerate(self.cross_layers):
+                t = dict(wq=_bf16(l.to_q.weight), wk=_bf16(l.to_k.weight), wv=_bf16(l.to_v.weight),
+                         wo=_bf16(l.to_out[0].weight), bq=_f32(l.to_q.bias), bk=_f32(l.to_k.bias),
+                         bv=_f32(l.to_v.bias), bo=_f32(l.to_out[0].bias))
+                for k, v in t.items():
+                    setattr(arr[i], k, ptr(v))
+                keep.append(t)
+            p = _lib.CrossFormerParams(self.dim, self.heads, self._num_layers, arr)
+            self._packed = (p, keep, arr)
+        return self._packed[0]
+
+    def forward(self, q, k, v):
+        """q [B,1,D], k [B,K,D], v [B,K,D] -> [B,1,D]"""
+        p = self.params()
+        if q.dim() != 3 or q.shape[1] != 1:
+            raise RuntimeError("the HIP CrossFormer handles single-query attention: q must be [B,1,D]")
+        if k.shape != v.shape or k.shape[0] != q.shape[0] or k.shape[2] != self.dim:
+            raise RuntimeError("k and v must both be [B,K,D]")
+        B, K = k.shape[0], k.shape[1]
+        lib = load()
+        qf = q.reshape(B, self.dim).to(dtype=torch.float32).contiguous()
+        kf = k.to(dtype=torch.float32).contiguous()
+        vf = kf if v is k else v.to(dtype=torch.float32).contiguous()
+        nbytes = lib.keds_crossformer_workspace_bytes(C.byref(p), B, K)
+        ws = self._ws.get(nbytes, qf.device)
+        out = torch.empty((B, self.dim), dtype=torch.float32, device=qf.device)
+        check(lib.keds_crossformer_forward(C.byref(p), ptr(qf), ptr(kf), ptr(vf), B, K, ptr(out), ptr(ws), ws.numel(),
+                                           stream()), "keds_crossformer_forward")
+        return out.reshape(B, 1, self.dim).to(q.dtype)
+
+
+class KnowledgeStream:
+    """One stream (img2text + retrieval_fuse + text_condition) fused into a single library call
+    (eval_utils.py:661-672): tokens = [fuse(m,I,I), cond(m,T,T), m]."""
+
+    def __init__(self, img2text: IM2TEXT, retrieval_fuse: CrossFormer, text_condition: CrossFormer):
+        self.img2text, self.retrieval_fuse, self.text_condition = img2text, retrieval_fuse, text_condition
+        self._ws = _lib.Workspace()
+
+    def __call__(self, q: torch.Tensor, nbr_img: torch.Tensor, nbr_txt: torch.Tensor) -> torch.Tensor:
+        kp = _lib.KnowledgeParams(self.img2text.params(), self.retrieval_fuse.params(), self.text_condition.params())
+        lib = load()
+        B, K, dim = nbr_img.shape
+        qf = q.to(dtype=torch.float32).contiguous()
+        ni = nbr_img.to(dtype=torch.float32).contiguous()
+        nt = nbr_txt.to(dtype=torch.float32).contiguous()
+        nbytes = lib.keds_knowledge_workspace_bytes(C.byref(kp), B, K)
+        ws = self._ws.get(nbytes, qf.device)
+        out = torch.empty((B, 3, dim), dtype=torch.float32, device=qf.device)
+        check(lib.keds_knowledge_forward(C.byref(kp), ptr(qf), ptr(ni), ptr(nt), B, K, ptr(out), ptr(ws), ws.numel(),
+                                         stream()), "keds_knowledge_forward")
+        return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# builders (model.py:927-991)
+# ---------------------------------------------------------------------------------------------------
+def convert_weights(model: nn.Module):
+    """fp16 cast of Linear/Conv/MHA/projection weights (model.py:927-948).  Kept for API parity: it
+    changes the checkpoint dtype (`model.dtype`), the kernels always compute bf16 x bf16 -> fp32."""
+    def _cast(l):
+        if isinstance(l, (nn.Conv1d, nn.Conv2d, nn.Linear)):
+            l.weight.data = l.weight.data.half()
+            if l.bias is not None:
+                l.bias.data = l.bias.data.half()
+        if isinstance(l, nn.MultiheadAttention):
+            for attr in ["in_proj_weight", "q_proj_weight", "k_proj_weight", "v_proj_weight", "in_proj_bias",
+                         "bias_k", "bias_v"]:
+                t = getattr(l, attr, None)
+                if t is not None:
+                    t.data = t.data.half()
+        for name in ("text_projection", "proj"):
+            t = getattr(l, name, None)
+            if isinstance(t, torch.Tensor):
+                t.data = t.data.half()
+    model.apply(_cast)
+    if hasattr(model, "repack"):
+        model.repack()
+
+
+def clip_config_from_state_dict(state_dict: Dict[str, torch.Tensor]) -> Dict[str, int]:
+    if "visual.proj" not in state_dict:
+        raise NotImplementedError("only ViT visual towers are supported")
+    vw = state_dict["visual.conv1.weight"].shape[0]
+    patch = state_dict["visual.conv1.weight"].shape[-1]
+    grid = round((state_dict["visual.positional_embedding"].shape[0] - 1) ** 0.5)
+    tw = state_dict["ln_final.weight"].shape[0]
+    return dict(
+        embed_dim=state_dict["text_projection"].shape[1], image_resolution=patch * grid,
+        vision_layers=len([k for k in state_dict if k.startswith("visual.") and k.endswith(".attn.in_proj_weight")]),
+        vision_width=vw, vision_patch_size=patch, context_length=state_dict["positional_embedding"].shape[0],
+        vocab_size=state_dict["token_embedding.weight"].shape[0], transformer_width=tw, transformer_heads=tw // 64,
+        transformer_layers=len(set(k.split(".")[2] for k in state_dict if k.startswith("transformer.resblocks"))))
+
+
+def build_model(state_dict: dict, fp16: bool = True) -> CLIP:
+    """Infer the architecture from checkpoint shapes and load it (model.py:951-991)."""
+    cfg = clip_config_from_state_dict(state_dict)
+    model = CLIP(**cfg)
+    sd = {k: v for k, v in state_dict.items() if k not in ("input_resolution", "context_length", "vocab_size")}
+    if fp16:
+        convert_weights(model)
+    model.load_state_dict(sd)
+    return model.eval()
+
+
+def convert_models_to_fp32(model: nn.Module):
+    """utils.py:44-48 (`--precision amp|fp32`)."""
+    for p in model.parameters():
+        p.data = p.data.float()
+    if hasattr(model, "repack"):
+        model.repack()

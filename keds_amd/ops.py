@@ -1,0 +1,142 @@
+"""Thin torch-tensor wrappers over the primitive entry points of libkeds_hip.so.
+
+Used by the parity tests (one kernel at a time) and by the facade classes.  Every
+function launches on torch's current stream and returns device tensors; nothing
+here computes on the CPU.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, load, ptr, stream
+
+
+def _pad128(m: int) -> int:
+    return (m + 127) // 128 * 128
+
+
+def cast_bf16(x: torch.Tensor, rows_padded: Optional[int] = None) -> torch.Tensor:
+    """fp32 [..., d] -> bf16 copy made by the HIP cast kernel; optional zero row padding of a 2-D input."""
+    x = x.contiguous().float()
+    if rows_padded is not None:
+        out = torch.zeros((rows_padded, x.shape[-1]), dtype=torch.bfloat16, device=x.device)
+    else:
+        out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(load().keds_cast_bf16(ptr(x), ptr(out), x.numel(), stream()), "keds_cast_bf16")
+    return out
+
+
+def gemm_bt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epilogue: int,
+            out: Optional[torch.Tensor] = None, m: Optional[int] = None,
+            aux: Optional[torch.Tensor] = None, aux_i: int = 0) -> torch.Tensor:
+    """out[M,N] = epi(a[M,K] @ w[N,K]^T + bias).  `a` must be bf16 with rows padded to 128."""
+    assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16
+    M = a.shape[0] if m is None else m
+    N, K = w.shape
+    if a.shape[0] < _pad128(M):
+        raise ValueError("A must have its rows padded to a multiple of 128")
+    if out is None:
+        odt = torch.float32 if epilogue in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32, _lib.EPI_PATCH_F32) \
+            else torch.bfloat16
+        out = torch.zeros((_pad128(M), N), dtype=odt, device=a.device)
+    check(load().keds_gemm_bt(ptr(a), ptr(w), ptr(bias), ptr(out), M, N, K, epilogue, ptr(aux), aux_i, stream()),
+          "keds_gemm_bt")
+    return out
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
+    rows, dim = x.shape
+    out = torch.empty((rows, dim), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    check(load().keds_layernorm(ptr(x), dim, ptr(gamma), ptr(beta), ptr(out), 1 if out_f32 else 0, rows, dim, stream()),
+          "keds_layernorm")
+    return out
+
+
+def attention(qkv: torch.Tensor, B: int, S: int, heads: int, causal: bool) -> torch.Tensor:
+    """qkv bf16 [B*S, 3*heads*64] -> bf16 [B*S, heads*64]"""
+    assert qkv.dtype == torch.bfloat16
+    out = torch.empty((B * S, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    check(load().keds_attention(ptr(qkv), ptr(out), B, S, heads, 1 if causal else 0, stream()), "keds_attention")
+    return out
+
+
+def im2col(image: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
+    B, _, R, _ = image.shape
+    g = R // patch
+    out = torch.zeros((_pad128(B * g * g), kpad), dtype=torch.bfloat16, device=image.device)
+    check(load().keds_im2col(ptr(image.contiguous().float()), ptr(out), B, R, patch, kpad, stream()), "keds_im2col")
+    return out
+
+
+def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor,
+                 img_tokens: Optional[torch.Tensor] = None, insert_col: int = 0) -> torch.Tensor:
+    B, L = tokens.shape
+    d = table.shape[1]
+    x = torch.empty((B, L, d), dtype=torch.float32, device=table.device)
+    n_tok = 0 if img_tokens is None else img_tokens.shape[1]
+    check(load().keds_embed_tokens(ptr(tokens.to(torch.int32).contiguous()), ptr(table), ptr(pos),
+                                   ptr(None if img_tokens is None else img_tokens.contiguous().float()),
+                                   n_tok, insert_col, ptr(x), B, L, d, stream()), "keds_embed_tokens")
+    return x
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    x = x.contiguous().float()
+    out = torch.empty_like(x)
+    check(load().keds_l2_normalize(ptr(x), ptr(out), x.shape[0], x.shape[1], stream()), "keds_l2_normalize")
+    return out
+
+
+def mix_normalize(a: torch.Tensor, b: torch.Tensor, wa: float = 0.5, wb: float = 0.5):
+    """(normalize(a), normalize(b), normalize(wa*normalize(a) + wb*normalize(b)))  -- eval_utils.py:704-710"""
+    a = a.contiguous().float()
+    b = b.contiguous().float()
+    an, bn, mix = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    check(load().keds_mix_normalize(ptr(a), ptr(b), wa, wb, ptr(an), ptr(bn), ptr(mix), a.shape[0], a.shape[1],
+                                    stream()), "keds_mix_normalize")
+    return an, bn, mix
+
+
+def gather_rows(db: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+    flat = idx.reshape(-1).to(torch.int64).contiguous()
+    out = torch.empty((flat.numel(), db.shape[1]), dtype=torch.float32, device=db.device)
+    check(load().keds_gather_rows(ptr(db), db.shape[1], ptr(flat), flat.numel(), ptr(out), stream()), "keds_gather_rows")
+    return out.reshape(*idx.shape, db.shape[1])
+
+
+def rank_gallery(ref: torch.Tensor, gallery: torch.Tensor) -> torch.Tensor:
+    """order[q,:] = stable argsort(1 - ref[q] @ gallery.T) as int32 [Q,G]  (eval_utils.py:1042-1043)"""
+    ref = ref.contiguous().float()
+    gallery = gallery.contiguous().float()
+    nq, ng = ref.shape[0], gallery.shape[0]
+    lib = load()
+    nbytes = lib.keds_rank_gallery_workspace_bytes(nq, ng)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=ref.device)
+    order = torch.empty((nq, ng), dtype=torch.int32, device=ref.device)
+    check(lib.keds_rank_gallery(ptr(ref), nq, ptr(gallery), ng, ref.shape[1], ptr(order), ptr(ws), nbytes, stream()),
+          "keds_rank_gallery")
+    return order
+
+
+def cirr_target_rank(order: torch.Tensor, gallery_ids: torch.Tensor, ref_ids: torch.Tensor, target_ids: torch.Tensor):
+    nq, ng = order.shape
+    rank = torch.empty(nq, dtype=torch.int32, device=order.device)
+    counts = torch.empty((nq, 2), dtype=torch.int32, device=order.device)
+    check(load().keds_cirr_target_rank(ptr(order), nq, ng, ptr(gallery_ids.to(torch.int32).contiguous()),
+                                       ptr(ref_ids.to(torch.int32).contiguous()),
+                                       ptr(target_ids.to(torch.int32).contiguous()), ptr(rank), ptr(counts), stream()),
+          "keds_cirr_target_rank")
+    return rank, counts
+
+
+def topk_merge_parts(D_parts: torch.Tensor, I_parts: torch.Tensor, metric: int):
+    """[parts, nq, k] sorted partial results -> global (D [nq,k], I [nq,k]) keyed on (D, I)."""
+    parts, nq, k = D_parts.shape
+    D = torch.empty((nq, k), dtype=torch.float32, device=D_parts.device)
+    I = torch.empty((nq, k), dtype=torch.int64, device=D_parts.device)
+    check(load().keds_topk_merge_parts(ptr(D_parts.contiguous().float()), ptr(I_parts.contiguous().to(torch.int64)),
+                                       parts, nq, k, metric, ptr(D), ptr(I), stream()), "keds_topk_merge_parts")
+    return D, I

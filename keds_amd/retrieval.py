@@ -1,0 +1,122 @@
+"""Host-side mirror of the reference's retrieval glue (src/eval_utils.py) on top of the HIP path.
+
+  get_retrieved_features   eval_utils.py:153-186   (normalise, top-16 over both DBs, gather rows)
+  compose_query_features   eval_utils.py:652-714   (per-batch body of evaluate_cirr)
+  get_metrics_cirr         eval_utils.py:1040-1067 (gallery ranking, reference removal, Recall@k)
+  build_database           eval_retrieval.py:281-298 (DB tensors + two flat indices)
+
+Everything stays on the device: no .cpu().numpy() round trip, no CPU fancy-index gather.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .index import FlatIndex
+from .model import CLIP, CrossFormer, IM2TEXT, KnowledgeStream
+
+
+def build_database(image_bases: torch.Tensor, text_bases: torch.Tensor, basenames: Optional[Sequence[str]] = None,
+                   device=None) -> list:
+    """database = [image_bases, text_bases, basenames, image_index, text_index]
+    (eval_retrieval.py:287,297-298).  The fp32 rows live on the device inside the indices."""
+    d = image_bases.shape[1]
+    ii, ti = FlatIndex(d, "l2", device=device), FlatIndex(d, "l2", device=device)
+    ii.add(image_bases)
+    ti.add(text_bases)
+    return [ii.rows, ti.rows, list(basenames) if basenames is not None else None, ii, ti]
+
+
+def get_retrieved_features(feature: torch.Tensor, database, args=None, topk: int = 16, use_faiss: bool = True):
+    """eval_utils.py:153-186.  feature [B,D] (any norm) -> (topk_image [B,k,D], topk_text [B,k,D]).
+    The reference shuffles the image neighbours along K (a numerical no-op for attention over keys);
+    here they stay in rank order."""
+    image_index, text_index = database[3], database[4]
+    _, _, ti = image_index.search_gather(feature, topk, normalize=True)
+    _, _, tt = text_index.search_gather(feature, topk, normalize=True)
+    return ti, tt
+
+
+def compose_query_features(model: CLIP, stream_image: KnowledgeStream, stream_text: KnowledgeStream,
+                           ref_images: torch.Tensor, text_with_blank: torch.Tensor, database,
+                           id_split: int = 265, topk: int = 16) -> Dict[str, torch.Tensor]:
+    """Per-batch body of evaluate_cirr (eval_utils.py:652-714).
+
+    Returns the reference's three feature sets under its dict names (eval_utils.py:728-732):
+    'composed' = image-stream feature, 'image' = text-stream feature, 'mixture' = their normalised mean.
+    """
+    q = model.encode_image(ref_images).float()
+    topk_image, topk_text = get_retrieved_features(q, database, None, topk=topk)
+    tok_a = stream_image(q, topk_image, topk_text)                                   # [B,3,D]
+    comp_a = model.encode_text_img_retrieval(text_with_blank, tok_a, split_ind=id_split, repeat=False)
+    tok_b = stream_text(q, topk_image, topk_text)
+    comp_b = model.encode_text_img_retrieval(text_with_blank, tok_b, split_ind=id_split, repeat=False)
+    b_n, a_n, mix = ops.mix_normalize(comp_b.float(), comp_a.float(), 0.5, 0.5)
+    return {"composed": a_n, "image": b_n, "mixture": mix, "query_image_features": q,
+            "tokens_image_stream": tok_a, "tokens_text_stream": tok_b}
+
+
+def _intern(names: Sequence[str], table: Dict[str, int]) -> np.ndarray:
+    out = np.empty(len(names), dtype=np.int32)
+    for i, n in enumerate(names):
+        b = os.path.basename(str(n))
+        out[i] = table.setdefault(b, len(table))
+    return out
+
+
+def get_metrics_cirr(image_features: torch.Tensor, ref_features: torch.Tensor, reference_names, index_names,
+                     target_names) -> Dict[str, float]:
+    """eval_utils.py:1040-1067 with the ranking, the reference-image removal and the target look-up on
+    device.  Names are compared by basename, interned to integers once (O(Q+G) host work instead of the
+    reference's O(Q*G) Python loop)."""
+    table: Dict[str, int] = {}
+    gal = _intern(index_names, table)
+    ref = _intern(reference_names, table)
+    tgt = _intern(target_names, table)
+    dev = image_features.device
+    order = ops.rank_gallery(ref_features, image_features)
+    rank, counts = ops.cirr_target_rank(order, torch.from_numpy(gal).to(dev), torch.from_numpy(ref).to(dev),
+                                        torch.from_numpy(tgt).to(dev))
+    counts = counts.cpu()
+    if not bool((counts[:, 0] == 1).all()):
+        raise AssertionError("each reference image must appear exactly once in the gallery")
+    if not bool((counts[:, 1] == 1).all()):       # eval_utils.py:1063
+        raise AssertionError("each target must appear exactly once in the ranking")
+    rank = rank.cpu()
+    n = rank.shape[0]
+    return {f"recall_R@{k}": float((rank < k).sum().item()) / n * 100.0 for k in (1, 5, 10, 50, 100)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# checkpoint plumbing (main.py:330-341, eval_retrieval.py:171-189, eval_utils.py:59-86)
+# ---------------------------------------------------------------------------------------------------
+def _strip_module(sd):
+    if sd and next(iter(sd)).startswith("module."):
+        return {k[len("module."):]: v for k, v in sd.items()}
+    return sd
+
+
+def load_checkpoint(checkpoint: dict, model: Optional[CLIP], img2text: IM2TEXT, retrieval_fuse: CrossFormer,
+                    text_condition: CrossFormer) -> None:
+    """Load the reference's 4-part checkpoint dict {state_dict, state_dict_img2text,
+    state_dict_retrieval_fuse, state_dict_text_condition} (optional 'module.' prefixes)."""
+    if model is not None and "state_dict" in checkpoint:
+        model.load_state_dict(_strip_module(checkpoint["state_dict"]), strict=False)
+    img2text.load_state_dict(_strip_module(checkpoint["state_dict_img2text"]))
+    retrieval_fuse.load_state_dict(_strip_module(checkpoint["state_dict_retrieval_fuse"]))
+    text_condition.load_state_dict(_strip_module(checkpoint["state_dict_text_condition"]))
+
+
+def make_stream_modules(model: CLIP, middle_dim: int = 512, n_layer: int = 2, device=None):
+    """IM2TEXT + 2 x CrossFormer(num_layers=3) as instantiated at eval_retrieval.py:96-101."""
+    d = model.token_embedding.weight.shape[1]
+    a = IM2TEXT(embed_dim=model.embed_dim, middle_dim=middle_dim, output_dim=d, n_layer=n_layer).eval()
+    b = CrossFormer(q_dim=d, k_dim=d, v_dim=d, num_layers=3).eval()
+    c = CrossFormer(q_dim=d, k_dim=d, v_dim=d, num_layers=3).eval()
+    if device is not None:
+        a, b, c = a.to(device), b.to(device), c.to(device)
+    return a, b, c

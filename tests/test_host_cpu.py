@@ -1,0 +1,195 @@
+"""CPU (-m "not gpu"): the C-ABI library loads and exports every declared symbol, the facade keeps the
+reference's checkpoint contract and fails loudly without a GPU, and the multi-rank search logic
+(shard bounds, all-gather, (distance, id) merge) is exact under gloo with world_size 2."""
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import keds_amd
+from keds_amd import _lib
+from keds_amd.index import merge_partials, shard_bounds
+from oracle import keds_oracle as O
+from tests.conftest import ROOT, golden_path
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "keds_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(keds_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in keds_hip.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes SIGNATURES and keds_hip.h disagree"
+    assert lib.keds_abi_version() == _lib.ABI_VERSION
+
+
+def test_size_queries_need_no_gpu():
+    lib = _lib.load()
+    # 500k x 768: 15625 stages of (32*768*2 + 128) bytes
+    assert lib.keds_index_packed_bytes(500000, 768) == 15625 * (32 * 768 * 2 + 128)
+    assert lib.keds_index_packed_bytes(33, 128) == 2 * (32 * 128 * 2 + 128)
+    assert lib.keds_index_packed_bytes(10, 100) == 0               # unsupported dim
+    assert lib.keds_index_search_workspace_bytes(128, 768) > 16 * 1024 * 1024
+    assert lib.keds_tower_workspace_bytes(1024, 257, 128) == 32896 * 1024 * 2 + 32896 * 4096 * 2
+
+
+def test_argument_errors_are_reported():
+    lib = _lib.load()
+    rc = lib.keds_gemm_bt(None, None, None, None, 1, 1, 1, 0, None, 0, None)
+    assert rc == -1 and "null" in _lib.last_error()
+    rc = lib.keds_index_search(1, 1, 10, 768, 0, 1, 4, 0, 17, 0, 1, 1, None, 1, 0, None)   # k > 16
+    assert rc == -1 and "k must be" in _lib.last_error()
+    rc = lib.keds_attention(1, 1, 1, 400, 16, 0, None)
+    assert rc == -1 and "unsupported" in _lib.last_error()
+
+
+@pytest.fixture(scope="module")
+def ref_keys():
+    return json.load(open(golden_path("state_dict_keys.json")))
+
+
+def test_state_dict_contract_tiny_and_vitl(ref_keys):
+    """Keys and shapes equal the reference modules' (SURVEY 8b), so reference .pt files load unchanged."""
+    cfg = dict(embed_dim=128, image_resolution=56, vision_layers=2, vision_width=128, vision_patch_size=14,
+               context_length=77, vocab_size=512, transformer_width=128, transformer_heads=2, transformer_layers=2)
+    m = keds_amd.CLIP(**cfg)
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == ref_keys["clip_tiny"]
+    with torch.device("meta"):
+        big = keds_amd.CLIP(768, 224, 24, 1024, 14, 77, 49408, 768, 12, 12)
+    assert {k: list(v.shape) for k, v in big.state_dict().items()} == ref_keys["clip_vitl14"]
+    assert {k: list(v.shape) for k, v in keds_amd.IM2TEXT(768, 512, 768, 2).state_dict().items()} == ref_keys["im2text"]
+    xf = keds_amd.CrossFormer(768, 768, 768, num_layers=3)
+    assert {k: list(v.shape) for k, v in xf.state_dict().items()} == ref_keys["crossformer"]
+
+
+def test_build_model_infers_architecture_and_loads():
+    tiny = dict(embed_dim=128, image_resolution=56, vision_layers=2, vision_width=128, vision_patch_size=14,
+                context_length=77, vocab_size=512, transformer_width=128, transformer_layers=2)
+    sd = O.synth_clip_state_dict(**tiny, seed=7)
+    m = keds_amd.build_model(dict(sd), fp16=False)
+    assert m.visual.input_resolution == 56 and m.transformer.layers == 2 and m.end_id == 511
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, sd[k]), k
+    m16 = keds_amd.build_model(dict(sd))                      # reference default: fp16 weights
+    assert m16.dtype == torch.float16
+    keds_amd.convert_models_to_fp32(m16)
+    assert m16.dtype == torch.float32
+    # 4-part checkpoint dict with DDP 'module.' prefixes (main.py:330-341, eval_retrieval.py:175-182)
+    a, b, c = keds_amd.make_stream_modules(m, middle_dim=128)
+    ck = {"epoch": 3, "name": "x",
+          "state_dict": {"module." + k: v for k, v in sd.items()},
+          "state_dict_img2text": {"module." + k: v for k, v in O.synth_im2text_state_dict(128, 128, 128).items()},
+          "state_dict_retrieval_fuse": O.synth_crossformer_state_dict(128, 3, tag="f"),
+          "state_dict_text_condition": O.synth_crossformer_state_dict(128, 3, tag="c")}
+    keds_amd.load_checkpoint(ck, m, a, b, c)
+    assert torch.equal(a.fc_out.weight, ck["state_dict_img2text"]["module.fc_out.weight"])
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly without the GPU (no silent eager fallback)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    m = keds_amd.CLIP(128, 56, 2, 128, 14, 77, 512, 128, 2, 2).eval()
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m.encode_image(torch.zeros(1, 3, 56, 56))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        m.encode_text(torch.tensor([[510] + [5] * 10 + [511] + [0] * 65]))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        keds_amd.IM2TEXT(128, 128, 128).eval()(torch.zeros(2, 128))
+    with pytest.raises(RuntimeError, match="no CPU"):
+        keds_amd.CrossFormer(128, 128, 128, 3)(torch.zeros(2, 1, 128), torch.zeros(2, 16, 128), torch.zeros(2, 16, 128))
+    idx = keds_amd.IndexFlatL2(128)
+    with pytest.raises(RuntimeError, match="no CPU"):
+        idx.add(np.zeros((4, 128), np.float32))
+
+
+def test_text_argument_checks_match_reference_errors():
+    m = keds_amd.CLIP(128, 56, 2, 128, 14, 77, 512, 128, 2, 2).eval()
+    text = torch.zeros(2, 77, dtype=torch.int64)
+    text[:, 0], text[:, 1], text[:, 2] = 510, 265, 511
+    with pytest.raises(RuntimeError):                              # 4 pseudo tokens: wrong sequence length
+        m.encode_text_img_retrieval(text, torch.zeros(2, 4, 128), split_ind=265, repeat=False)
+    with pytest.raises(IndexError):                                # split token absent from row 0
+        m.encode_text_img_retrieval(text, torch.zeros(2, 3, 128), split_ind=7, repeat=False)
+    two = text.clone()
+    two[0, 9] = 511
+    with pytest.raises(IndexError):                                # two EOTs in a row
+        m.encode_text_img_retrieval(two, torch.zeros(2, 3, 128), split_ind=265, repeat=False)
+    late = text.clone()
+    late[:, 2] = 7
+    late[:, 76] = 511
+    with pytest.raises(IndexError):                                # read-out beyond the context
+        m.encode_text_img_retrieval(late, torch.zeros(2, 3, 128), split_ind=265, repeat=False)
+
+
+# ---- multi-rank search logic ---------------------------------------------------------------------
+def test_shard_bounds_cover_rows_once():
+    for n in (1, 31, 32, 33, 1000, 500000, 2000000):
+        for world in (1, 2, 3, 4, 8):
+            spans = [shard_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and a <= b and a % 32 == 0
+
+
+def test_merge_partials_matches_global_search():
+    db = O.synth_database(4000, 64, seed=1)
+    q = O.synth_database(11, 64, seed=2)
+    Dg, Ig = O.flat_l2_search(db, q, 16)
+    for world in (2, 3, 8):
+        Dp, Ip = [], []
+        for r in range(world):
+            lo, hi = shard_bounds(4000, world, r)
+            d, i = O.flat_l2_search(db[lo:hi], q, 16)
+            Dp.append(d)
+            Ip.append(i + lo)
+        D, I = merge_partials(torch.stack(Dp), torch.stack(Ip))
+        assert torch.equal(I, Ig)
+        assert torch.allclose(D, Dg)
+    # ties across shards resolve to the lower id; -1 fillers sort last
+    Dp = torch.tensor([[[0.5, 1.0]], [[0.5, float("inf")]]])
+    Ip = torch.tensor([[[7, 9]], [[3, -1]]])
+    D, I = merge_partials(Dp, Ip)
+    assert I.tolist() == [[3, 7]] and D.tolist() == [[0.5, 0.5]]
+
+
+def _gloo_worker(rank, world, port, out):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        db = O.synth_database(3000, 64, seed=9)
+        q = O.synth_database(7, 64, seed=10)
+        lo, hi = shard_bounds(3000, world, rank)
+        d, i = O.flat_l2_search(db[lo:hi], q, 10)                # stand-in for the local HIP scan
+        from keds_amd.index import exchange_and_merge
+        D, I = exchange_and_merge(d, i + lo, _lib.METRIC_L2, group=None)
+        Dg, Ig = O.flat_l2_search(db, q, 10)
+        out[rank] = bool(torch.equal(I, Ig) and torch.allclose(D, Dg))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_search_exchange_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = 29500 + os.getpid() % 2000
+        procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, out)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+        assert all(p.exitcode == 0 for p in procs)
+        assert dict(out) == {0: True, 1: True}

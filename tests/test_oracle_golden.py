@@ -95,7 +95,7 @@ def test_text_edge_cases(tiny):
         O.encode_text_img_retrieval(sd, late, torch.zeros(1, 3, 128), split_ind=265, repeat=False)
 
 
-@pytest.mark.parametrize("dim,middle", [(128, 64), (768, 512)])
+@pytest.mark.parametrize("dim,middle", [(128, 128), (768, 512)])
 def test_knowledge_modules(dim, middle):
     g = dict(np.load(golden_path(f"knowledge_d{dim}.npz")))
     sd_i = O.synth_im2text_state_dict(dim, middle, dim, 2, seed=11, tag="i2t")
@@ -118,7 +118,7 @@ def test_cirr_batch_composition(tiny):
     text_base = O.synth_database(n_db, 128, seed=2003)
 
     def stream(seed):
-        return (O.synth_im2text_state_dict(128, 64, 128, 2, seed=seed, tag="i2t"),
+        return (O.synth_im2text_state_dict(128, 128, 128, 2, seed=seed, tag="i2t"),
                 O.synth_crossformer_state_dict(128, 3, seed=seed, tag="fuse"),
                 O.synth_crossformer_state_dict(128, 3, seed=seed, tag="cond"))
 

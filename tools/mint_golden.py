@@ -231,21 +231,39 @@ def mint_metrics():
     print("metrics:", metrics)
 
 
+def mint_keys():
+    """state_dict key -> shape lists of the reference modules (the checkpoint contract)."""
+    import json
+    out = {}
+    for tag, cfg in (("tiny", TINY), ("vitl14", VITL)):
+        with torch.device("meta"):
+            m = CLIP(cfg["embed_dim"], cfg["image_resolution"], cfg["vision_layers"], cfg["vision_width"],
+                     cfg["vision_patch_size"], cfg["context_length"], cfg["vocab_size"], cfg["transformer_width"],
+                     cfg["transformer_width"] // 64, cfg["transformer_layers"])
+        out[f"clip_{tag}"] = {k: list(v.shape) for k, v in m.state_dict().items()}
+    out["im2text"] = {k: list(v.shape) for k, v in IM2TEXT(768, 512, 768, 2).state_dict().items()}
+    out["crossformer"] = {k: list(v.shape) for k, v in CrossFormer(768, 768, 768, num_layers=3).state_dict().items()}
+    json.dump(out, open(os.path.join(OUT, "state_dict_keys.json"), "w"), indent=0, sort_keys=True)
+    print("keys:", {k: len(v) for k, v in out.items()})
+
+
 TINY = dict(embed_dim=128, image_resolution=56, vision_layers=2, vision_width=128, vision_patch_size=14,
             context_length=77, vocab_size=512, transformer_width=128, transformer_layers=2)
 VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
             context_length=77, vocab_size=49408, transformer_width=768, transformer_layers=12)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "knowledge", "cirr", "search", "metrics", "vitl"]
+    which = sys.argv[1:] or ["tiny", "knowledge", "cirr", "search", "metrics", "keys", "vitl"]
+    if "keys" in which:
+        mint_keys()
     model = None
     if "tiny" in which or "cirr" in which:
         model, sd, timg, ttxt = mint_clip("tiny", TINY, batch=4, star=265)
     if "knowledge" in which:
-        mint_knowledge(128, 64)
+        mint_knowledge(128, 128)
         mint_knowledge(768, 512, batch=3)
     if "cirr" in which:
-        mint_cirr_batch(model, sd, timg, ttxt, 265, 128, 64)
+        mint_cirr_batch(model, sd, timg, ttxt, 265, 128, 128)
     if "search" in which:
         mint_search()
     if "metrics" in which:
