@@ -289,6 +289,17 @@ def flat_l2_search(db: Tensor, q: Tensor, k: int, chunk: int = 65536) -> Tuple[T
     return best_d.clamp_min(0).float(), best_i
 
 
+def flat_l2_search_f32(db: Tensor, q: Tensor, k: int) -> Tuple[Tensor, Tensor]:
+    """Same search evaluated the way a CPU library does it (fp32 GEMM expansion
+    ||q||^2 - 2 q.x + ||x||^2, then top-k): the form timed as `cpu_baseline` in bench.py.
+    Equal to flat_l2_search up to fp32 cancellation error (not used as the parity checker)."""
+    db = db.float()
+    q = q.float()
+    d = (q * q).sum(1, keepdim=True) - 2.0 * (q @ db.t()) + (db * db).sum(1)[None, :]
+    v, i = torch.topk(d, min(k, db.shape[0]), dim=1, largest=False, sorted=True)
+    return v.clamp_min(0), i
+
+
 def flat_ip_search(db: Tensor, q: Tensor, k: int) -> Tuple[Tensor, Tensor]:
     """The reference's own brute-force statement: `feature @ base.t()` then `.topk`
     (src/trainer.py:246-257).  Returns (scores desc, indices)."""

@@ -1,0 +1,197 @@
+"""GPU parity of the encoder primitives, one kernel at a time, against plain fp32 torch on the CPU.
+
+Tolerances (stated per test): the kernels take bf16 operands and accumulate in fp32, so each test
+feeds the fp32 reference the SAME bf16-rounded operands; what remains is accumulation order and the
+bf16 rounding of outputs (<= 2^-8 relative), i.e. rel-L2 <= 5e-3 for bf16 outputs and <= 1e-5 for fp32
+outputs.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from keds_amd import _lib, ops
+from oracle import keds_oracle as O
+from tests.gpu_util import bf16_round, max_abs, rel_l2, report
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, std=1.0):
+    return O.synth_tensor(f"t{seed}", list(shape), std, seed)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 192), (128, 128, 64), (1000, 384, 128), (257 * 3, 1024, 1024),
+                                   (77 * 5, 768, 3072)])
+@pytest.mark.parametrize("epi", ["bias_bf16", "qgelu", "relu", "resid", "bias_f32", "nobias"])
+def test_gemm_epilogues(M, N, K, epi):
+    a = bf16_round(_rand((M, K), 1))
+    w = bf16_round(_rand((N, K), 2, std=K ** -0.5))
+    bias = _rand((N,), 3, std=0.1)
+    ref = a @ w.t() + (0 if epi == "nobias" else bias)
+    a_d = ops.cast_bf16(a.cuda(), rows_padded=(M + 127) // 128 * 128)
+    w_d = w.cuda().to(torch.bfloat16)
+    b_d = None if epi == "nobias" else bias.cuda()
+    if epi in ("bias_bf16", "nobias"):
+        out = ops.gemm_bt(a_d, w_d, b_d, _lib.EPI_BIAS_BF16, m=M)[:M]
+        tol = 5e-3
+    elif epi == "qgelu":
+        ref = O.quick_gelu(ref)
+        out = ops.gemm_bt(a_d, w_d, b_d, _lib.EPI_BIAS_QGELU_BF16, m=M)[:M]
+        tol = 5e-3
+    elif epi == "relu":
+        ref = torch.relu(ref)
+        out = ops.gemm_bt(a_d, w_d, b_d, _lib.EPI_BIAS_RELU_BF16, m=M)[:M]
+        tol = 5e-3
+    elif epi == "resid":
+        x0 = _rand((M, N), 4)
+        ref = x0 + ref
+        xd = torch.zeros(((M + 127) // 128 * 128, N), device="cuda")
+        xd[:M] = x0.cuda()
+        out = ops.gemm_bt(a_d, w_d, b_d, _lib.EPI_BIAS_RESID_F32, out=xd, m=M)[:M]
+        tol = 1e-5
+    else:
+        out = ops.gemm_bt(a_d, w_d, b_d, _lib.EPI_BIAS_F32, m=M)[:M]
+        tol = 1e-5
+    err = rel_l2(out, ref)
+    report("gemm", M=M, N=N, K=K, epi=epi, rel_l2=err, max_abs=max_abs(out, ref))
+    assert err <= tol
+
+
+def test_gemm_identity_asymmetric():
+    """A = I against an asymmetric W catches a transposed or permuted C-write exactly (integers in bf16)."""
+    N = K = 128
+    a = torch.eye(128)
+    w = ((torch.arange(N)[:, None] + 3 * torch.arange(K)[None, :]) % 251).float()  # asymmetric, exact in bf16
+    out = ops.gemm_bt(ops.cast_bf16(a.cuda(), 128), w.cuda().to(torch.bfloat16), None, _lib.EPI_BIAS_F32, m=128)
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+def test_gemm_patch_epilogue():
+    B, G, N, K = 3, 16, 128, 640
+    a = bf16_round(_rand((B * G, K), 5))
+    w = bf16_round(_rand((N, K), 6, std=K ** -0.5))
+    pos = _rand((G + 1, N), 7)
+    out = torch.zeros((B * (G + 1), N), device="cuda")
+    ops.gemm_bt(ops.cast_bf16(a.cuda(), 128), w.cuda().to(torch.bfloat16), None, _lib.EPI_PATCH_F32, out=out, m=B * G,
+                aux=pos.cuda(), aux_i=G)
+    ref = torch.zeros(B, G + 1, N)
+    ref[:, 1:] = (a @ w.t()).reshape(B, G, N) + pos[1:]
+    err = rel_l2(out.reshape(B, G + 1, N)[:, 1:], ref[:, 1:])
+    assert err <= 1e-5 and float(out.reshape(B, G + 1, N)[:, 0].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("rows,dim", [(5, 128), (300, 768), (257 * 2, 1024), (7, 2048), (64, 256)])
+def test_layernorm(rows, dim):
+    x = _rand((rows, dim), 11) * 3 + 0.5
+    g, b = 1 + _rand((dim,), 12, 0.1), _rand((dim,), 13, 0.1)
+    ref = O.layer_norm(x, g, b)
+    out32 = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), out_f32=True)
+    out16 = ops.layernorm(x.cuda(), g.cuda(), b.cuda(), out_f32=False)
+    report("layernorm", rows=rows, dim=dim, rel_l2_f32=rel_l2(out32, ref), rel_l2_bf16=rel_l2(out16, ref))
+    assert rel_l2(out32, ref) <= 1e-5         # fp32 statistics, fp32 out
+    assert rel_l2(out16, ref) <= 5e-3         # bf16 rounding of the output only
+
+
+def _attn_ref(qkv, B, S, heads, causal):
+    d = heads * 64
+    q, k, v = qkv.reshape(B, S, 3 * d).split(d, dim=-1)
+    q = q.reshape(B, S, heads, 64).transpose(1, 2)
+    k = k.reshape(B, S, heads, 64).transpose(1, 2)
+    v = v.reshape(B, S, heads, 64).transpose(1, 2)
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s.masked_fill(torch.ones(S, S, dtype=torch.bool).triu(1), float("-inf"))
+    return (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B * S, d)
+
+
+@pytest.mark.parametrize("B,S,heads,causal", [(2, 257, 16, False), (3, 77, 12, True), (2, 17, 2, False),
+                                              (1, 5, 2, True), (2, 96, 2, True), (1, 288, 2, False), (2, 33, 2, False)])
+def test_attention(B, S, heads, causal):
+    """P is rounded to bf16 before PV (flash-attention practice): tolerance rel-L2 1e-2."""
+    qkv = bf16_round(_rand((B * S, 3 * heads * 64), 21, std=1.5))
+    ref = _attn_ref(qkv, B, S, heads, causal)
+    out = ops.attention(qkv.cuda().to(torch.bfloat16), B, S, heads, causal)
+    err = rel_l2(out, ref)
+    report("attention", B=B, S=S, heads=heads, causal=causal, rel_l2=err, max_abs=max_abs(out, ref))
+    assert err <= 1e-2
+
+
+def test_attention_peaked_rows():
+    """One dominant key per query (softmax ~ one-hot) and large logits: exercises the max subtraction."""
+    B, S, heads = 1, 257, 2
+    qkv = bf16_round(_rand((B * S, 3 * heads * 64), 22, std=6.0))
+    ref = _attn_ref(qkv, B, S, heads, False)
+    out = ops.attention(qkv.cuda().to(torch.bfloat16), B, S, heads, False)
+    assert torch.isfinite(out.float()).all()
+    assert rel_l2(out, ref) <= 2e-2
+
+
+def test_im2col_matches_conv():
+    B, R, P, width = 2, 56, 14, 128
+    img = _rand((B, 3, R, R), 31)
+    w = _rand((width, 3, P, P), 32, std=0.05)
+    kpad = 640
+    col = ops.im2col(img.cuda(), P, kpad)[: B * 16].float().cpu()
+    wf = torch.zeros(width, kpad)
+    wf[:, : 3 * P * P] = w.reshape(width, -1)
+    ref = torch.nn.functional.conv2d(bf16_round(img), w, stride=P).reshape(B, width, -1).permute(0, 2, 1).reshape(B * 16, width)
+    assert rel_l2(col @ wf.t(), ref) <= 1e-5
+    assert float(col[:, 3 * P * P:].abs().max()) == 0.0
+
+
+def test_embed_tokens_splice():
+    B, L, d, vocab = 3, 77, 128, 512
+    table, pos = _rand((vocab, d), 41, 0.02), _rand((L, d), 42, 0.01)
+    rs = np.random.RandomState(0)
+    tokens = torch.from_numpy(rs.randint(0, vocab, size=(B, L)).astype(np.int64))
+    x = ops.embed_tokens(tokens.cuda(), table.cuda(), pos.cuda()).cpu()
+    assert torch.equal(x, table[tokens] + pos)
+    for n_tok in (2, 3):
+        it = _rand((B, n_tok, d), 43)
+        ins = 4
+        emb = table[tokens]
+        ref = torch.cat([emb[:, :ins], it, emb[:, ins + 1: L - (n_tok - 1)]], dim=1) + pos     # model.py:832-837
+        x = ops.embed_tokens(tokens.cuda(), table.cuda(), pos.cuda(), it.cuda(), ins).cpu()
+        assert torch.equal(x, ref)
+
+
+def test_normalise_and_mixture():
+    a, b = _rand((9, 768), 51), _rand((9, 768), 52)
+    an, bn, mix = ops.mix_normalize(a.cuda(), b.cuda())
+    ra, rb = O.l2_normalize(a), O.l2_normalize(b)
+    assert rel_l2(an, ra) <= 1e-6 and rel_l2(bn, rb) <= 1e-6
+    assert rel_l2(mix, O.l2_normalize(0.5 * ra + 0.5 * rb)) <= 1e-6            # eval_utils.py:704-710
+    assert rel_l2(ops.l2_normalize(a.cuda()), ra) <= 1e-6
+
+
+def test_gallery_ranking_and_recall_metric():
+    import keds_amd
+    g = dict(np.load(__import__("tests.conftest", fromlist=["golden_path"]).golden_path("metrics_cirr.npz")))
+    G = g["gallery"].shape[0]
+    index_names = [f"/data/cirr/dev/img_{i:05d}.png" for i in range(G)]
+    ref_names = [f"img_{i:05d}.png" for i in g["ref_idx"]]
+    tgt_names = [f"img_{i:05d}.png" for i in g["tgt_idx"]]
+    gal, ref = torch.from_numpy(g["gallery"]).cuda(), torch.from_numpy(g["ref"]).cuda()
+    order = ops.rank_gallery(ref, gal).cpu().long()
+    dist = 1 - torch.from_numpy(g["ref"]).double() @ torch.from_numpy(g["gallery"]).double().t()
+    assert torch.equal(torch.sort(order, dim=1).values, torch.arange(G).expand(order.shape[0], G))   # a permutation
+    along = torch.gather(dist, 1, order)
+    assert float((along[:, :-1] - along[:, 1:]).max()) <= 1e-6          # ascending up to fp32 evaluation error
+    m = keds_amd.get_metrics_cirr(gal, ref, ref_names, index_names, tgt_names)
+    for k in (1, 5, 10, 50, 100):
+        assert abs(m[f"recall_R@{k}"] - float(g[f"recall_R_at_{k}"])) < 1e-4     # reference's own numbers
+    with pytest.raises(AssertionError):
+        keds_amd.get_metrics_cirr(gal, ref, ref_names, index_names, ["nope.png"] * len(tgt_names))
+    # a larger ragged case against the oracle
+    rs = np.random.RandomState(3)
+    G2, Q2 = 2297, 300
+    gal2 = O.l2_normalize(torch.from_numpy(rs.standard_normal((G2, 768)).astype(np.float32)))
+    ri, ti = rs.randint(0, G2, Q2), None
+    ti = (ri + 1 + rs.randint(0, G2 - 1, Q2)) % G2
+    ref2 = O.l2_normalize(gal2[ti] + 0.05 * torch.from_numpy(rs.standard_normal((Q2, 768)).astype(np.float32)))
+    names = [f"d/{i}.png" for i in range(G2)]
+    mo = O.get_metrics_cirr(gal2, ref2, [f"{i}.png" for i in ri], names, [f"{i}.png" for i in ti])
+    mg = keds_amd.get_metrics_cirr(gal2.cuda(), ref2.cuda(), [f"{i}.png" for i in ri], names, [f"{i}.png" for i in ti])
+    assert mo == mg

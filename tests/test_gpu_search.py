@@ -1,0 +1,158 @@
+"""GPU parity: similarity + top-k (FlatIndex) against the oracle's exact fp64 L2 search.
+
+Bar: indices bit-exact (integer work), distances within 2e-6 absolute (fp32 evaluation of
+sum (q-x)^2 on unit-norm data vs the oracle's fp64).  Full-size (0.5 M x 768) checks use
+size-independent properties plus an oracle cross-check on a query subset.
+"""
+import numpy as np
+import pytest
+import torch
+
+import keds_amd
+from keds_amd import _lib, ops
+from keds_amd.index import merge_partials, shard_bounds
+from oracle import keds_oracle as O
+from tests.conftest import golden_path
+from tests.gpu_util import max_abs, report
+
+pytestmark = pytest.mark.gpu
+D_ATOL = 2e-6
+
+
+def _check(index, db, q, k, name, normalize=False):
+    D, I, rows = index.search_gather(q.cuda(), k, normalize=normalize)
+    qq = O.l2_normalize(q) if normalize else q
+    Do, Io = O.flat_l2_search(db, qq, k)
+    I, D = I.cpu(), D.cpu()
+    mism = int((I != Io).sum())
+    report(name, n=db.shape[0], dim=db.shape[1], nq=q.shape[0], k=k, index_mismatches=mism, d_maxabs=max_abs(D, Do))
+    assert mism == 0, f"{mism} index mismatches"
+    assert max_abs(D, Do) <= D_ATOL
+    assert torch.equal(rows.cpu(), db[Io.reshape(-1)].reshape(q.shape[0], k, -1)), "gathered rows differ"
+    return D, I
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [(20000, 768, 37, 16), (20000, 768, 128, 10), (4099, 128, 5, 16),
+                                        (50001, 256, 130, 1), (3000, 512, 9, 7), (2500, 1024, 3, 16)])
+def test_search_matches_oracle(n, dim, nq, k):
+    db = O.synth_database(n, dim, seed=2002)
+    q = O.synth_database(nq, dim, seed=3003)
+    idx = keds_amd.FlatIndex(dim, "l2")
+    idx.add(db.numpy())
+    assert idx.ntotal == n
+    _check(idx, db, q, k, "search_iid")
+
+
+def test_search_clustered_and_unnormalised_queries():
+    db = O.synth_database(30000, 768, seed=2002, clustered=True, n_centroids=256)
+    q = 3.0 * db[torch.arange(0, 30000, 997)] + 0.02 * O.synth_tensor("qnoise", [31, 768], 1.0)
+    idx = keds_amd.IndexFlatL2(768)
+    idx.add(db)
+    _check(idx, db, q, 16, "search_clustered_normalize", normalize=True)     # eval_utils.py:162
+
+
+def test_search_non_unit_database_uses_l2_not_cosine():
+    """IndexFlatL2 ranks by L2 on the DB as stored (SURVEY 'L2 vs cosine'): scale rows so cosine != L2."""
+    db = O.synth_database(6000, 128, seed=5) * (0.5 + torch.rand(6000, 1, generator=torch.Generator().manual_seed(1)))
+    q = O.synth_database(17, 128, seed=6)
+    idx = keds_amd.IndexFlatL2(128)
+    idx.add(db)
+    _check(idx, db, q, 16, "search_nonunit")
+    _, Iip = O.flat_ip_search(db, q, 16)
+    _, Il2 = O.flat_l2_search(db, q, 16)
+    assert not torch.equal(Iip, Il2)                              # the case really distinguishes the metrics
+
+
+def test_search_faiss_call_shape_numpy():
+    g = dict(np.load(golden_path("search_small.npz")))              # minted from trainer.py:246-257
+    # the golden DB is 64-d; pad to the smallest supported width with zeros (distances unchanged)
+    db = torch.zeros(3000, 128)
+    db[:, :64] = O.synth_database(3000, 64, seed=31)
+    q = np.zeros((9, 128), np.float32)
+    q[:, :64] = g["q"]
+    idx = keds_amd.index_cpu_to_all_gpus(keds_amd.IndexFlatL2(128))
+    idx.add(db.numpy())
+    D, I = idx.search(q, 16)
+    assert isinstance(D, np.ndarray) and D.dtype == np.float32 and I.dtype == np.int64
+    np.testing.assert_array_equal(I, g["I_image"])
+    np.testing.assert_allclose(D, g["D_image"], atol=D_ATOL)
+
+
+def test_search_edge_cases():
+    db = O.synth_database(40, 128, seed=7)
+    q = O.synth_database(3, 128, seed=8)
+    idx = keds_amd.IndexFlatL2(128)
+    idx.add(db[:5])                                                # fewer rows than k: -1 / inf padding
+    D, I, _ = idx.search_device(q.cuda(), 16)
+    Do, Io = O.flat_l2_search(db[:5], q, 5)
+    assert torch.equal(I.cpu()[:, :5], Io) and bool((I.cpu()[:, 5:] == -1).all())
+    assert bool(torch.isinf(D.cpu()[:, 5:]).all())
+    idx.add(db[5:])                                                # incremental add re-packs
+    _check(idx, db, q, 16, "search_incremental_add")
+    dup = torch.cat([db, db[:7]])                                  # exact duplicates: lower id first
+    idx2 = keds_amd.IndexFlatL2(128)
+    idx2.add(dup)
+    D, I, _ = idx2.search_device(db[:7].cuda(), 2)
+    assert torch.equal(I.cpu()[:, 0], torch.arange(7)) and torch.equal(I.cpu()[:, 1], torch.arange(40, 47))
+    with pytest.raises(ValueError):
+        idx.search_device(q.cuda(), 17)
+    with pytest.raises(ValueError):
+        keds_amd.IndexFlatL2(100)
+    with pytest.raises(RuntimeError):
+        keds_amd.IndexFlatL2(128).search_device(q.cuda(), 1)       # empty index
+
+
+def test_inner_product_metric():
+    db = O.synth_database(9000, 256, seed=11) * 1.7
+    q = O.synth_database(20, 256, seed=12)
+    idx = keds_amd.IndexFlatIP(256)
+    idx.add(db)
+    D, I, _ = idx.search_device(q.cuda(), 16)
+    So, Io = O.flat_ip_search(db, q, 16)
+    assert torch.equal(I.cpu(), Io)
+    assert max_abs(D, So) <= 5e-6
+
+
+def test_sharded_merge_bit_identical_to_single():
+    """Row shards searched separately then merged keyed on (D, id) == one search."""
+    n, dim = 30000, 768
+    db = O.synth_database(n, dim, seed=2002)
+    q = O.synth_database(64, dim, seed=3003).cuda()
+    full = keds_amd.FlatIndex(dim)
+    full.add(db)
+    D1, I1, _ = full.search_device(q, 10)
+    for world in (2, 4, 8):
+        Dp, Ip = [], []
+        for r in range(world):
+            lo, hi = shard_bounds(n, world, r)
+            sh = keds_amd.FlatIndex(dim, row0=lo)
+            sh.add(db[lo:hi])
+            d, i, _ = sh.search_device(q, 10)
+            Dp.append(d)
+            Ip.append(i)
+        Dm, Im = ops.topk_merge_parts(torch.stack(Dp), torch.stack(Ip), _lib.METRIC_L2)
+        assert torch.equal(Im, I1) and torch.equal(Dm, D1)
+        Dh, Ih = merge_partials(torch.stack(Dp).cpu(), torch.stack(Ip).cpu())      # host twin used by gloo tests
+        assert torch.equal(Ih, I1.cpu()) and torch.equal(Dh, D1.cpu())
+
+
+def test_full_size_half_million_properties():
+    """BASELINE size: 0.5 M x 768.  Self-retrieval, sortedness, top-10 prefix of top-16, oracle on a subset."""
+    n, dim = 500000, 768
+    db = O.synth_database(n, dim, seed=2002)
+    idx = keds_amd.FlatIndex(dim)
+    idx.add(db)
+    rows = torch.arange(0, n, n // 128)[:128]
+    q = db[rows].cuda()
+    D, I, _ = idx.search_device(q, 16)
+    assert torch.equal(I[:, 0].cpu(), rows), "a database row must retrieve itself first"
+    assert float(D[:, 0].abs().max()) <= 1e-6
+    assert bool((D[:, 1:] >= D[:, :-1]).all())
+    D10, I10, _ = idx.search_device(q, 10)
+    assert torch.equal(I10, I[:, :10])
+    qq = O.synth_database(8, dim, seed=3003)
+    Dq, Iq, _ = idx.search_device(qq.cuda(), 16)
+    Do, Io = O.flat_l2_search(db, qq, 16)
+    mism = int((Iq.cpu() != Io).sum())
+    report("search_full_size", n=n, index_mismatches=mism, d_maxabs=max_abs(Dq, Do))
+    assert mism == 0 and max_abs(Dq, Do) <= D_ATOL
