@@ -123,6 +123,10 @@ int keds_cirr_target_rank(const int32_t* order, int nq, int ng, const int32_t* g
 int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                  int epilogue, const float* aux, int aux_i, void* stream);
 
+/* test/bench hook: 1 routes every GEMM through the 128x128 kernel (the 256x256 kernel is used for
+ * N % 256 == 0, M >= 1024 otherwise) */
+int keds_gemm_force_small(int on);
+
 /* y = LayerNorm(x) * gamma + beta over the last dim (fp32 statistics, eps 1e-5).
  * x fp32 [rows, dim] with row stride x_stride (elements); out bf16 (out_f32 == 0) or fp32,
  * dense [rows, dim].  dim % 256 == 0 or dim == 128; dim <= 2048. */

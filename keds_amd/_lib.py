@@ -81,6 +81,7 @@ SIGNATURES = {
     "keds_rank_gallery": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
     "keds_cirr_target_rank": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "keds_gemm_force_small": (i32, [i32]),
     "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "keds_attention": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_im2col": (i32, [vp, vp, i32, i32, i32, i32, vp]),

@@ -11,8 +11,11 @@ namespace {
 constexpr float LN_EPS = 1e-5f;
 constexpr int LN_MAXV = 8;  // f32x4 chunks per lane: dim <= 2048
 
-// one wave per output row r; source row = r*row_mul + (row_map ? row_map[r] : 0)
-template <bool OUT_F32>
+// one wave per output row r; source row = r*row_mul + (row_map ? row_map[r] : 0).
+// NV = dim/256 f32x4 chunks per lane, known at compile time so all row loads (and gamma/beta) are issued
+// back to back before the first reduction (predicated loads were being serialised: 2.6 TB/s -> see profiles/);
+// NV == 0 is the generic fallback (dim == 128 or any dim <= 2048 that is a multiple of 4).
+template <bool OUT_F32, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long x_stride,
                                                         const int* __restrict__ row_map, int row_mul,
                                                         const float* __restrict__ gamma,
@@ -23,36 +26,41 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     if (r >= rows) return;
     const long long src = (long long)r * row_mul + (row_map ? row_map[r] : 0);
     const float* p = x + src * x_stride;
-    f32x4 v[LN_MAXV];
-    float s = 0.f;
+    constexpr int MAXV = NV > 0 ? NV : LN_MAXV;
+    f32x4 v[MAXV], gg[MAXV], bb[MAXV];
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int i = j * 256 + lane * 4;
-        if (i < dim) {
-            v[j] = *reinterpret_cast<const f32x4*>(p + i);
-            s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
-        } else {
-            v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (NV > 0 || i < dim) v[j] = *reinterpret_cast<const f32x4*>(p + i);
+        else v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        const int i = j * 256 + lane * 4;
+        if (NV > 0 || i < dim) {
+            gg[j] = *reinterpret_cast<const f32x4*>(gamma + i);
+            bb[j] = *reinterpret_cast<const f32x4*>(beta + i);
         }
     }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     const float mean = wave_sum(s) / (float)dim;
     float q = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int i = j * 256 + lane * 4;
-        if (i < dim) {
+        if (NV > 0 || i < dim) {
             const f32x4 d = v[j] - mean;
             q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)dim + LN_EPS);
 #pragma unroll
-    for (int j = 0; j < LN_MAXV; ++j) {
+    for (int j = 0; j < MAXV; ++j) {
         const int i = j * 256 + lane * 4;
-        if (i < dim) {
-            const f32x4 gg = *reinterpret_cast<const f32x4*>(gamma + i);
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + i);
-            const f32x4 y = (v[j] - mean) * rstd * gg + bb;
+        if (NV > 0 || i < dim) {
+            const f32x4 y = (v[j] - mean) * rstd * gg[j] + bb[j];
             if constexpr (OUT_F32) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)r * dim + i) = y;
             } else {
@@ -168,14 +176,26 @@ bool ln_dim_ok(int dim) { return dim > 0 && dim <= 2048 && dim % 4 == 0 && (dim 
 
 }  // namespace
 
+template <bool OUT_F32>
+static void ln_launch(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
+                      const float* beta, void* out, int rows, int dim, hipStream_t st) {
+    const unsigned grid = (rows + 3) / 4;
+#define KEDS_LN(NV) layernorm_kernel<OUT_F32, NV><<<grid, 256, 0, st>>>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim)
+    switch (dim) {
+        case 256: KEDS_LN(1); break;
+        case 512: KEDS_LN(2); break;
+        case 768: KEDS_LN(3); break;
+        case 1024: KEDS_LN(4); break;
+        default: KEDS_LN(0); break;
+    }
+#undef KEDS_LN
+}
+
 int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st) {
     KedsProfScope prof(KEDS_PROF_LN, st);
-    const unsigned grid = (rows + 3) / 4;
-    if (out_f32)
-        layernorm_kernel<true><<<grid, 256, 0, st>>>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim);
-    else
-        layernorm_kernel<false><<<grid, 256, 0, st>>>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim);
+    if (out_f32) ln_launch<true>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim, st);
+    else ln_launch<false>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim, st);
     return keds_check_launch("layernorm_kernel");
 }
 
