@@ -108,7 +108,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("KEDS_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank test of the RCCL path
+    if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=dev)         # "nccl" is RCCL on ROCm
 
@@ -136,18 +137,18 @@ def main():
 
     def step():
         q = model.encode_image(images, normalize=True)          # [B,768] on device
-        if world > 1:
+        if use_dist:
             allq = [torch.empty_like(q) for _ in range(world)]
             dist.all_gather(allq, q)
             q = torch.cat(allq)
         Dk, Ik, _ = index.search_device(q, k)
-        if world > 1:
+        if use_dist:
             Dk, Ik = exchange_and_merge(Dk, Ik, index.metric)
         return Dk, Ik
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -163,7 +164,7 @@ def main():
     elapsed = time.perf_counter() - t0
     _lib.prof_enable(False)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
@@ -203,7 +204,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, N, D, k)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
