@@ -178,7 +178,11 @@ def main():
         steps = args.steps
         gemm_flops = 2.0 * GEMM_MAC_PER_IMAGE * B * steps      # this rank's GEMM launches
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        scan_bytes = (hi - lo) * D * 2.0 * scan_n               # algorithmic: N_local*D*2 B per scan launch
+        # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B); a search issues two
+        # scan launches (threshold pass over the first 1/16 of the rows + the full candidate pass): both are charged
+        # to the time, only the single pass to the bytes
+        n_search = steps * world                                 # query blocks of 128 searched by this rank
+        scan_bytes = (hi - lo) * D * 2.0 * n_search
         scan_ach = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
             "metric": "query-images/sec (encode+0.5M top-10) ViT-L/14",
@@ -197,7 +201,7 @@ def main():
                          "traffic": None, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1)},
             "roofline_scan": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_ach,
                               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": scan_ach / PEAK_HBM_GBPS, "traffic": None,
-                              "launches": scan_n, "avg_launch_ms": scan_ms / max(scan_n, 1)},
+                              "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1)},
             "stage_ms_per_step": {"gemm": gemm_ms / steps, "attention": attn_ms / steps, "layernorm": ln_ms / steps,
                                   "scan": scan_ms / steps, "other": other_ms / steps},
         }

@@ -61,6 +61,9 @@ int keds_prof_read(int klass, double* total_ms, int64_t* launches);  /* synchron
 #define KEDS_SCAN_LIST 16           /* per-lane exact list depth == max k of the fast path */
 #define KEDS_SCAN_CAND 64           /* candidates re-ranked in fp32 per query */
 
+/* timing-only ablation hook of the D=768 scan kernel (0 = product path) */
+int keds_scan_debug(int variant);
+
 /* bytes of the packed bf16 scan image for n rows of dimension dim (dim % 128 == 0) */
 size_t keds_index_packed_bytes(int64_t n, int dim);
 

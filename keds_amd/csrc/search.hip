@@ -65,9 +65,12 @@ __device__ __forceinline__ void wait_stage_and_barrier(int ahead) {
 }
 
 // ------------------------------------------------------------------------------------------
-template <int D>
+// DBG (timing-only ablations; results wrong unless 0): 1 = no list update, 2 = no MFMA (and no list update),
+// 3 = no LDS fragment reads
+// L = per-lane list depth: LISTK (16) for the candidate pass, 4 for the threshold pass
+template <int D, int L = LISTK, int DBG = 0>
 __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
-    const char* __restrict__ packed, int total_stages, const bf16_t* __restrict__ qb,
+    const char* __restrict__ packed, int stage_begin, int total_stages, const bf16_t* __restrict__ qb,
     const float* __restrict__ thr, float* __restrict__ out_val, int* __restrict__ out_idx) {
     using C = ScanCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -76,8 +79,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, c = lane & 15;
     const int nwg = gridDim.x;
-    const int s0 = (int)(((long long)blockIdx.x * total_stages) / nwg);
-    const int s1 = (int)(((long long)(blockIdx.x + 1) * total_stages) / nwg);
+    const int s0 = stage_begin + (int)(((long long)blockIdx.x * total_stages) / nwg);
+    const int s1 = stage_begin + (int)(((long long)(blockIdx.x + 1) * total_stages) / nwg);
 
     // queries of this wave as MFMA B operands: lane (g,c) holds Q[16*wave + c][32*s + 8*g .. +7]
     bf16x8 qf[C::KSTEPS];
@@ -86,10 +89,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
 #pragma unroll
         for (int s = 0; s < C::KSTEPS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s);
     }
-    float lv[LISTK];
-    int li[LISTK];
+    float lv[L];
+    int li[L];
 #pragma unroll
-    for (int j = 0; j < LISTK; ++j) {
+    for (int j = 0; j < L; ++j) {
         lv[j] = -INFINITY;
         li[j] = -1;
     }
@@ -139,10 +142,17 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
 #pragma unroll
         for (int s = 0; s < C::KSTEPS; ++s) {
             const int ch = swz_chunk(4 * s + g, c);
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sb + row_off + ch * 16);
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sb + row_off + 16 * C::ROWB + ch * 16);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[s], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[s], acc1, 0, 0, 0);
+            bf16x8 a0 = qf[s], a1 = qf[s];
+            if constexpr (DBG != 3) {
+                a0 = *reinterpret_cast<const bf16x8*>(sb + row_off + ch * 16);
+                a1 = *reinterpret_cast<const bf16x8*>(sb + row_off + 16 * C::ROWB + ch * 16);
+            }
+            if constexpr (DBG != 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[s], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[s], acc1, 0, 0, 0);
+            } else {
+                asm volatile("" ::"v"(a0), "v"(a1));
+            }
         }
         // D layout: lane (g,c) holds query c, keys 4g..4g+3 of each 16-key tile
         const int kbase = t * STAGE_KEYS + g * 4;
@@ -151,30 +161,39 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float sc = tt == 0 ? acc0[r] : acc1[r];
-                if (sc > lmin) {
-                    float cv = sc;
-                    int ci = kbase + tt * 16 + r;
+                if constexpr (DBG == 1 || DBG == 2) asm volatile("" ::"v"(sc));
+                if ((DBG == 0 || DBG == 3) && sc > lmin) {
+                    // branch-free sorted insert with no serial chain: every slot looks only at the OLD list.
+                    // new v[j] = med3(v[j-1], v[j], x); id follows the same three cases (x > v[j] strict, so an
+                    // equal score stays behind the earlier key).
+                    const int ci = kbase + tt * 16 + r;
+                    bool above = true;                      // x > v[j-1] with v[-1] = +inf: false; tracked as "prev gt"
+                    float pv = INFINITY;
+                    int pi = -1;
+                    bool pgt = false;
 #pragma unroll
-                    for (int j = 0; j < LISTK; ++j) {
-                        const bool gt = cv > lv[j];
+                    for (int j = 0; j < L; ++j) {
                         const float ov = lv[j];
                         const int oi = li[j];
-                        lv[j] = gt ? cv : ov;
-                        li[j] = gt ? ci : oi;
-                        cv = gt ? ov : cv;
-                        ci = gt ? oi : ci;
+                        const bool gt = sc > ov;
+                        lv[j] = __builtin_amdgcn_fmed3f(pv, ov, sc);
+                        li[j] = gt ? (pgt ? pi : ci) : oi;
+                        pv = ov;
+                        pi = oi;
+                        pgt = gt;
                     }
-                    lmin = fmaxf(thr0, lv[LISTK - 1]);
+                    (void)above;
+                    lmin = fmaxf(thr0, lv[L - 1]);
                 }
             }
         }
         slot = slot + 1 == C::NST ? 0 : slot + 1;
     }
 
-    // lists out: [query][wg][g][LISTK]
-    const size_t o = (((size_t)(wave * 16 + c) * nwg + blockIdx.x) * 4 + g) * LISTK;
+    // lists out: [query][wg][g][L]
+    const size_t o = (((size_t)(wave * 16 + c) * nwg + blockIdx.x) * 4 + g) * L;
 #pragma unroll
-    for (int j = 0; j < LISTK; j += 4) {
+    for (int j = 0; j < L; j += 4) {
         *reinterpret_cast<f32x4*>(out_val + o + j) = f32x4{lv[j], lv[j + 1], lv[j + 2], lv[j + 3]};
         *reinterpret_cast<int4*>(out_idx + o + j) = make_int4(li[j], li[j + 1], li[j + 2], li[j + 3]);
     }
@@ -247,96 +266,169 @@ __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q,
 }
 
 // ------------------------------------------------------------------------------------------
-// merge: one 256-thread block per query; lists sorted descending; tournament for NCAND rounds.
-// order key: (value desc, id asc); empty entries are (-inf, -1).
-__device__ __forceinline__ bool better(float va, int ia, float vb, int ib) {
-    // true if (va, ia) ranks before (vb, ib); ids are unique except the -1 fillers
-    return va > vb || (va == vb && (unsigned)ia < (unsigned)ib);
+// merge: exact top-NCAND of the per-lane lists (+ optional extra candidates) of one query by a 4-pass
+// 8-bit radix select on the order-preserving integer image of the score; ties at the cut go to the smaller id.
+// One 256-thread block per query, entries held in registers.  Output order is arbitrary (the re-rank sorts).
+// thr_out[q] = the NCAND-th best score (or -inf if fewer valid entries): the insert threshold of phase B.
+__device__ __forceinline__ unsigned ord_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-constexpr int MERGE_MAXL = 4;  // lists per thread: nwg*4 <= 1024
+constexpr int MERGE_MAXE = 66;   // entries per thread: (1024 lists * 16 + 64 extra) / 256 = 64.25
 
-__global__ __launch_bounds__(256) void merge_lists_kernel(const float* __restrict__ val, const int* __restrict__ idx,
-                                                          int nlists, int* __restrict__ cand_idx,
-                                                          float* __restrict__ cand_val) {
-    __shared__ float s_v[4];
-    __shared__ int s_i[4];
-    __shared__ int s_t[4];
-    const int q = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* v = val + (size_t)q * nlists * LISTK;
-    const int* ix = idx + (size_t)q * nlists * LISTK;
-    int pos[MERGE_MAXL];
-    float hv[MERGE_MAXL];
-    int hi[MERGE_MAXL];
+__global__ __launch_bounds__(256) void merge_select_kernel(const float* __restrict__ val, const int* __restrict__ idx,
+                                                           int nlists, int listk, const float* __restrict__ xval,
+                                                           const int* __restrict__ xidx, int nextra,
+                                                           int* __restrict__ cand_idx, float* __restrict__ cand_val,
+                                                           float* __restrict__ thr_out) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_out, s_eq;
+    __shared__ int eq_idx[256];
+    __shared__ float eq_val[256];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int nmain = nlists * listk;
+    const int total = nmain + nextra;
+    const float* v = val + (size_t)q * nmain;
+    const int* ix = idx + (size_t)q * nmain;
+    unsigned key[MERGE_MAXE];
+    int id[MERGE_MAXE];
+    unsigned nvalid = 0;
 #pragma unroll
-    for (int m = 0; m < MERGE_MAXL; ++m) {
-        const int l = tid + m * 256;
-        pos[m] = 0;
-        hv[m] = l < nlists ? v[(size_t)l * LISTK] : -INFINITY;
-        hi[m] = l < nlists ? ix[(size_t)l * LISTK] : -1;
+    for (int i = 0; i < MERGE_MAXE; ++i) {
+        const int e = tid + i * 256;
+        float f = -INFINITY;
+        int j = -1;
+        if (e < nmain) {
+            f = v[e];
+            j = ix[e];
+        } else if (e < total) {
+            f = xval[(size_t)q * nextra + (e - nmain)];
+            j = xidx[(size_t)q * nextra + (e - nmain)];
+        }
+        id[i] = j;
+        key[i] = j >= 0 ? ord_key(f) : 0u;          // 0 is below every real score's key
+        nvalid += j >= 0 ? 1u : 0u;
     }
-    for (int round = 0; round < NCAND; ++round) {
-        // thread-local best head
-        float bv = hv[0];
-        int bi = hi[0], bm = 0;
+    // block-wide reductions through 4 LDS words (one per wave); no atomics on shared bins: the scores of one
+    // query share their high bits, so histogram atomics would serialise
+    const int lane = tid & 63, wv = tid >> 6;
+    auto block_sum = [&](unsigned x) -> unsigned {
 #pragma unroll
-        for (int m = 1; m < MERGE_MAXL; ++m)
-            if (better(hv[m], hi[m], bv, bi)) {
-                bv = hv[m];
-                bi = hi[m];
-                bm = m;
-            }
-        // wave argmax
-        float wv = bv;
-        int wi = bi, wt = tid;
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+        __syncthreads();                       // previous readers of hist[0..3] are done
+        if (lane == 0) hist[wv] = x;
+        __syncthreads();
+        return hist[0] + hist[1] + hist[2] + hist[3];
+    };
+    auto block_or = [&](unsigned x) -> unsigned {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) x |= __shfl_xor(x, o, 64);
+        __syncthreads();
+        if (lane == 0) hist[wv] = x;
+        __syncthreads();
+        return hist[0] | hist[1] | hist[2] | hist[3];
+    };
+    if (tid == 0) {
+        s_out = 0;
+        s_eq = 0;
+    }
+    const unsigned V = block_sum(nvalid);
+    const unsigned want = V < (unsigned)NCAND ? V : (unsigned)NCAND;
+    unsigned T = 0;          // threshold key: entries with key > T are taken, `rem` of those with key == T
+    unsigned rem = want;
+    if (V > (unsigned)NCAND) {
+        // bits that differ between valid keys: skip the common leading bits
+        unsigned kmax = 0, kxor = 0;
+#pragma unroll
+        for (int i = 0; i < MERGE_MAXE; ++i)
+            if (id[i] >= 0) kmax = key[i] > kmax ? key[i] : kmax;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            const float ov = __shfl_xor(wv, o, 64);
-            const int oi = __shfl_xor(wi, o, 64);
-            const int ot = __shfl_xor(wt, o, 64);
-            if (better(ov, oi, wv, wi) || (ov == wv && oi == wi && ot < wt)) {
-                wv = ov;
-                wi = oi;
-                wt = ot;
-            }
-        }
-        if (lane == 0) {
-            s_v[wave] = wv;
-            s_i[wave] = wi;
-            s_t[wave] = wt;
+            const unsigned other = __shfl_xor(kmax, o, 64);
+            kmax = other > kmax ? other : kmax;
         }
         __syncthreads();
-        float gv = s_v[0];
-        int gi = s_i[0], gt = s_t[0];
-#pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (better(s_v[w], s_i[w], gv, gi) || (s_v[w] == gv && s_i[w] == gi && s_t[w] < gt)) {
-                gv = s_v[w];
-                gi = s_i[w];
-                gt = s_t[w];
-            }
+        if (lane == 0) hist[wv] = kmax;
         __syncthreads();
-        if (tid == 0) {
-            cand_idx[q * NCAND + round] = gi;
-            cand_val[q * NCAND + round] = gv;
-        }
-        if (tid == gt && gi >= 0) {
-            // advance the winning list (static indexing: no scratch)
+        kmax = hist[0];
 #pragma unroll
-            for (int m = 0; m < MERGE_MAXL; ++m)
-                if (m == bm) {
-                    const int l = tid + m * 256;
-                    pos[m] += 1;
-                    if (pos[m] < LISTK) {
-                        hv[m] = v[(size_t)l * LISTK + pos[m]];
-                        hi[m] = ix[(size_t)l * LISTK + pos[m]];
-                    } else {
-                        hv[m] = -INFINITY;
-                        hi[m] = -1;
-                    }
-                }
+        for (int w = 1; w < 4; ++w) kmax = hist[w] > kmax ? hist[w] : kmax;
+#pragma unroll
+        for (int i = 0; i < MERGE_MAXE; ++i)
+            if (id[i] >= 0) kxor |= key[i] ^ kmax;
+        kxor = block_or(kxor);
+        const int top = kxor ? 31 - __builtin_clz(kxor) : -1;      // highest differing bit
+        // T = the NCAND-th largest key: greedy bit by bit, largest T with count(key >= T) >= want
+        unsigned prefix = top >= 31 ? 0u : (kmax & ~((2u << top) - 1u));   // common high bits (top == -1: all equal)
+        if (top < 0) prefix = kmax;
+#pragma unroll 1
+        for (int bit = top; bit >= 0; --bit) {
+            const unsigned cand = prefix | (1u << bit);
+            unsigned cnt = 0;
+#pragma unroll
+            for (int i = 0; i < MERGE_MAXE; ++i) cnt += key[i] >= cand ? 1u : 0u;    // invalid keys are 0 < cand
+            if (block_sum(cnt) >= want) prefix = cand;
         }
+        T = prefix;
+        unsigned gt = 0;
+#pragma unroll
+        for (int i = 0; i < MERGE_MAXE; ++i) gt += key[i] > T ? 1u : 0u;
+        rem = want - block_sum(gt);
+        __syncthreads();
+    }
+    // collect: key > T always; key == T into the tie buffer (only when a cut exists)
+#pragma unroll
+    for (int i = 0; i < MERGE_MAXE; ++i) {
+        if (id[i] < 0) continue;
+        const unsigned k = key[i];
+        float f;
+        {
+            const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+            f = __uint_as_float(u);
+        }
+        if (V <= (unsigned)NCAND || k > T) {
+            const unsigned o = atomicAdd(&s_out, 1u);
+            cand_idx[q * NCAND + o] = id[i];
+            cand_val[q * NCAND + o] = f;
+        } else if (k == T) {
+            const unsigned o = atomicAdd(&s_eq, 1u);
+            if (o < 256) {
+                eq_idx[o] = id[i];
+                eq_val[o] = f;
+            }
+        }
+    }
+    __syncthreads();
+    if (V > (unsigned)NCAND) {
+        // ties at the threshold: take the `rem` smallest ids (rank by counting; ties are rare, <= 256 handled)
+        const unsigned neq = s_eq < 256 ? s_eq : 256;
+        const unsigned base = s_out;
+        if (tid < (int)neq) {
+            const int my = eq_idx[tid];
+            unsigned rank = 0;
+            for (unsigned j = 0; j < neq; ++j) rank += eq_idx[j] < my ? 1u : 0u;
+            if (rank < rem) {
+                cand_idx[q * NCAND + base + rank] = my;
+                cand_val[q * NCAND + base + rank] = eq_val[tid];
+            }
+        }
+    }
+    // fillers when fewer than NCAND valid entries
+    for (int o = (int)want + tid; o < NCAND; o += 256) {
+        cand_idx[q * NCAND + o] = -1;
+        cand_val[q * NCAND + o] = -INFINITY;
+    }
+    if (thr_out && tid == 0) {
+        float t = -INFINITY;
+        if (V >= (unsigned)NCAND) {
+            const unsigned k = V > (unsigned)NCAND ? T : 0u;
+            if (V > (unsigned)NCAND) {
+                const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
+                t = __uint_as_float(u);
+            }
+        }
+        thr_out[q] = t;
     }
 }
 
@@ -396,6 +488,12 @@ __global__ __launch_bounds__(64) void select_kernel(const int* __restrict__ cand
     if (rank < k) {
         D[(size_t)q * k + rank] = d;
         I[(size_t)q * k + rank] = id + id_base;
+    }
+    // fewer than k valid candidates: (inf | -inf, -1) fillers like faiss
+    const int nvalid = __popcll(__ballot(id >= 0));
+    if (lane >= nvalid && lane < k) {
+        D[(size_t)q * k + lane] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+        I[(size_t)q * k + lane] = -1;
     }
 }
 
@@ -477,6 +575,9 @@ struct SearchWs {
     int* cidx;       // [128, NCAND]
     float* cval;
     float* cdist;
+    int* aidx;       // [128, NCAND] phase-A candidates
+    float* aval;
+    float* thr;      // [128] phase-B insert thresholds
     size_t bytes;
 };
 
@@ -498,18 +599,24 @@ SearchWs carve(void* ws, int nq, int dim) {
     w.cidx = (int*)take((size_t)QBLOCK * NCAND * sizeof(int));
     w.cval = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
     w.cdist = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
+    w.aidx = (int*)take((size_t)QBLOCK * NCAND * sizeof(int));
+    w.aval = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
+    w.thr = (float*)take((size_t)QBLOCK * sizeof(float));
     w.bytes = off;
     return w;
 }
 
-template <int D>
-int launch_scan(const void* packed, int total_stages, const bf16_t* qb, float* lval, int* lidx, int nwg,
-                hipStream_t st) {
+int g_scan_debug = 0;   // timing-only ablations of the D=768 scan kernel
+int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresholds)
+
+template <int D, int L>
+int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr, float* lval,
+                int* lidx, int nwg, hipStream_t st) {
     using C = ScanCfg<D>;
     const size_t lds = (size_t)C::NST * C::LDS_STAGE;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)scan_topk_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)scan_topk_kernel<D, L>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             keds_set_error("scan: cannot raise dynamic LDS to %zu bytes", lds);
             return KEDS_E_LAUNCH;
@@ -517,7 +624,26 @@ int launch_scan(const void* packed, int total_stages, const bf16_t* qb, float* l
         attr_set = true;
     }
     KedsProfScope prof(KEDS_PROF_SCAN, st);
-    scan_topk_kernel<D><<<nwg, SCAN_THREADS, lds, st>>>((const char*)packed, total_stages, qb, nullptr, lval, lidx);
+    if constexpr (D == 768 && L == LISTK) {
+        if (g_scan_debug) {
+#define KEDS_SCAN_DBG(V)                                                                                            \
+    {                                                                                                              \
+        (void)hipFuncSetAttribute((const void*)scan_topk_kernel<D, L, V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                  (int)lds);                                                                       \
+        scan_topk_kernel<D, L, V><<<nwg, SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, \
+                                                               lval, lidx);                                        \
+    }
+            switch (g_scan_debug) {
+                case 1: KEDS_SCAN_DBG(1) break;
+                case 2: KEDS_SCAN_DBG(2) break;
+                default: KEDS_SCAN_DBG(3) break;
+            }
+#undef KEDS_SCAN_DBG
+            return keds_check_launch("scan_topk_kernel<dbg>");
+        }
+    }
+    scan_topk_kernel<D, L><<<nwg, SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, lval,
+                                                           lidx);
     return keds_check_launch("scan_topk_kernel");
 }
 
@@ -533,6 +659,12 @@ bool dim_supported(int dim) { return dim == 128 || dim == 256 || dim == 512 || d
 size_t stage_bytes(int dim) { return (size_t)STAGE_KEYS * dim * 2 + 128; }
 
 }  // namespace
+
+extern "C" int keds_scan_debug(int variant) {
+    g_scan_debug = variant & 15;          // bits 0-3: timing-only ablation
+    g_scan_phases = (variant >> 4) & 1;   // bit 4: force the single-phase scan (exact as well; for A/B tests)
+    return KEDS_OK;
+}
 
 extern "C" size_t keds_index_packed_bytes(int64_t n, int dim) {
     if (n < 0 || !dim_supported(dim)) return 0;
@@ -576,33 +708,55 @@ extern "C" int keds_index_search(const void* packed, const float* db, int64_t n,
     }
     hipStream_t st = (hipStream_t)stream;
     const int total_stages = (int)((n + STAGE_KEYS - 1) / STAGE_KEYS);
-    int nwg = device_cus();
-    if (nwg > 256) nwg = 256;
-    if (nwg > total_stages) nwg = total_stages;
-    const int nlists = nwg * 4;
+    int cus = device_cus();
+    if (cus > 256) cus = 256;
+    // Two phases so that list inserts are rare for ANY data: phase A scans the first 1/16 of the stages with empty
+    // lists (every lane fills its list: insert-heavy, but on 6 % of the bytes), the merge of phase A yields the
+    // 64th best score per query, and phase B scans the rest accepting only scores above that threshold
+    // (expected accept rate 64 / rows(A): ~0.2 % at 0.5 M rows).  Small databases use one phase.
+    const bool two_phase = g_scan_phases != 1 && total_stages >= 16 * 64;
+    const int stagesA = total_stages / 16;                         // threshold pass: first 1/16 of the rows
+    const int nwgA = stagesA < cus ? stagesA : cus;
+    const int nwgB = total_stages < cus ? total_stages : cus;
+    auto scan_thr = [&](int count, int nwg) -> int {               // depth-4 lists, no threshold
+        switch (dim) {
+            case 128: return launch_scan<128, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
+            case 256: return launch_scan<256, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
+            case 512: return launch_scan<512, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
+            case 768: return launch_scan<768, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
+            default: return launch_scan<1024, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
+        }
+    };
+    auto scan_all = [&](const float* thr, int nwg) -> int {        // depth-16 lists over every stage
+        switch (dim) {
+            case 128: return launch_scan<128, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
+            case 256: return launch_scan<256, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
+            case 512: return launch_scan<512, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
+            case 768: return launch_scan<768, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
+            default: return launch_scan<1024, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
+        }
+    };
     int rc;
-    {
-        const long long cnt = (long long)nq * k;
-        fill_invalid_kernel<<<(unsigned)((cnt + 255) / 256), 256, 0, st>>>(D, (long long*)I, cnt, metric);
-        if ((rc = keds_check_launch("fill_invalid_kernel"))) return rc;
-    }
     for (int q0 = 0; q0 < nq; q0 += QBLOCK) {
         const int nb = nq - q0 < QBLOCK ? nq - q0 : QBLOCK;
         float* qn = w.qn + (size_t)q0 * dim;
         qprep_kernel<<<QBLOCK / 4, 256, 0, st>>>(queries + (size_t)q0 * dim, nb, dim, normalize_q, qn, w.qb, QBLOCK);
         if ((rc = keds_check_launch("qprep_kernel"))) return rc;
-        switch (dim) {
-            case 128: rc = launch_scan<128>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
-            case 256: rc = launch_scan<256>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
-            case 512: rc = launch_scan<512>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
-            case 768: rc = launch_scan<768>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
-            default: rc = launch_scan<1024>(packed, total_stages, w.qb, w.lval, w.lidx, nwg, st); break;
+        if (two_phase) {
+            // Threshold pass: every lane keeps the best 4 scores of its share of the first 1/16 of the rows; the
+            // 64th best of their union is a score that 64 real rows reach, so the final 64 candidates all beat or
+            // equal it.  The candidate pass then rescans everything, inserting only above that threshold
+            // (expected accept rate 64 / rows(A): 0.2 % at 0.5 M rows), so list inserts are rare for ANY data.
+            if ((rc = scan_thr(stagesA, nwgA))) return rc;
+            KedsProfScope prof(KEDS_PROF_OTHER, st);
+            merge_select_kernel<<<nb, 256, 0, st>>>(w.lval, w.lidx, nwgA * 4, 4, nullptr, nullptr, 0, w.aidx, w.aval, w.thr);
+            if ((rc = keds_check_launch("merge_select_kernel(thr)"))) return rc;
         }
-        if (rc) return rc;
+        if ((rc = scan_all(two_phase ? w.thr : nullptr, nwgB))) return rc;
         {
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_lists_kernel<<<nb, 256, 0, st>>>(w.lval, w.lidx, nlists, w.cidx, w.cval);
-            if ((rc = keds_check_launch("merge_lists_kernel"))) return rc;
+            merge_select_kernel<<<nb, 256, 0, st>>>(w.lval, w.lidx, nwgB * 4, LISTK, nullptr, nullptr, 0, w.cidx, w.cval, nullptr);
+            if ((rc = keds_check_launch("merge_select_kernel"))) return rc;
             rerank_kernel<<<(nb * NCAND + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * NCAND);
             if ((rc = keds_check_launch("rerank_kernel"))) return rc;
             select_kernel<<<nb, 64, 0, st>>>(w.cidx, w.cdist, metric, k, (long long)id_base, D + (size_t)q0 * k,

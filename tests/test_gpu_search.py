@@ -136,6 +136,31 @@ def test_sharded_merge_bit_identical_to_single():
         assert torch.equal(Ih, I1.cpu()) and torch.equal(Dh, D1.cpu())
 
 
+def test_two_phase_thresholds_equal_single_phase():
+    """The thresholded two-phase scan (>= 32768 rows) and the single-phase scan are both exact: identical results,
+    on iid data, on clustered data, and on a database SORTED by similarity to the queries (worst case for a
+    threshold taken from the first rows)."""
+    lib = _lib.load()
+    n, dim = 70000, 768
+    dbs = {"iid": O.synth_database(n, dim, seed=41),
+           "clustered": O.synth_database(n, dim, seed=42, clustered=True, n_centroids=64)}
+    q = O.synth_database(40, dim, seed=43)
+    order = torch.argsort(dbs["iid"] @ q[0])                     # ascending similarity to query 0: best rows LAST
+    dbs["sorted_adversarial"] = dbs["iid"][order].contiguous()
+    for name, db in dbs.items():
+        idx = keds_amd.FlatIndex(dim)
+        idx.add(db)
+        D2, I2, _ = idx.search_device(q.cuda(), 16)
+        lib.keds_scan_debug(0x10)
+        try:
+            D1, I1, _ = idx.search_device(q.cuda(), 16)
+        finally:
+            lib.keds_scan_debug(0)
+        assert torch.equal(I1, I2) and torch.equal(D1, D2), name
+        Do, Io = O.flat_l2_search(db, q, 16)
+        assert torch.equal(I2.cpu(), Io), name
+
+
 def test_full_size_half_million_properties():
     """BASELINE size: 0.5 M x 768.  Self-retrieval, sortedness, top-10 prefix of top-16, oracle on a subset."""
     n, dim = 500000, 768
