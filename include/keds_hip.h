@@ -136,6 +136,9 @@ int keds_gemm_force_small(int on);
 int keds_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta,
                    void* out, int out_f32, int rows, int dim, void* stream);
 
+/* timing-only ablation hook of the S > 96 attention kernel (0 = product path) */
+int keds_attention_debug(int variant);
+
 /* multi-head self attention core on a packed qkv buffer (nn.MultiheadAttention,
  * model.py:309,319-321): qkv bf16 [B*S, 3*d] (q | k | v, head h at columns h*64),
  * out bf16 [B*S, d] = softmax(q k^T / 8 [+ causal mask, model.py:543-549]) v.  dh = 64,

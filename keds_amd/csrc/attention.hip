@@ -26,9 +26,12 @@ struct AttnCfg {
     static_assert(NKT % 2 == 0, "PV consumes key tiles in pairs");
 };
 
-template <int NKT>
+// DBG (timing-only ablations): 1 = no K/V staging, 2 = no QK^T MFMA/reads, 3 = no softmax math, 4 = no PV, 5 = no q loop
+// CAUSAL: text tower mask.  NFULL: key tiles [0, NFULL) are known at compile time to lie entirely below S and
+// need no mask (non-causal only) -- evaluating the mask for all 72 score registers cost half the loop's instructions.
+template <int NKT, bool CAUSAL, int NFULL, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
-                                                        int heads, int causal) {
+                                                        int heads) {
     using C = AttnCfg<NKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -40,27 +43,55 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     const int g = lane >> 4, c = lane & 15;
     const bf16_t* base = qkv + (size_t)b * S * ld + h * DH;
 
-    // ---- stage K (swizzled rows) and V^T (permuted key order); keys >= S are zero
-    for (int id = tid; id < C::KEYS * 8; id += 256) {
-        const int key = id >> 3, ch = id & 7;
-        bf16x8 kv = bf16x8{0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-        if (key < S) {
-            const bf16_t* row = base + (size_t)key * ld + ch * 8;
-            kv = *reinterpret_cast<const bf16x8*>(row + d);
-            vv = *reinterpret_cast<const bf16x8*>(row + 2 * d);
-        }
-        *reinterpret_cast<bf16x8*>(k_lds + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kv;
-        const int u = key >> 5, w = key & 31;
-        const int pos = (4 * u + ((w & 15) >> 2)) * 16 + ((w & 3) + ((w >> 4) << 2)) * 2;
+    // ---- stage K (swizzled rows) and V^T (permuted key order); keys >= S are zero.
+    // Work item = (4 consecutive keys, one 8-wide dh chunk): all global loads of a thread are issued before the
+    // first LDS write (one HBM round trip instead of one per item), K goes in with ds_write_b128, and the four
+    // keys of an item are adjacent in the permuted V^T row, so V^T goes in with 8-byte stores.
+    if constexpr (DBG != 1) {
+        constexpr int ITEMS = (C::KEYS / 4) * 8;
+        constexpr int PER = (ITEMS + 255) / 256;
+        bf16x8 kreg[PER][4], vreg[PER][4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            *reinterpret_cast<bf16_t*>(vt_lds + (ch * 8 + j) * C::VT_ROW + pos) = vv[j];
+        for (int it = 0; it < PER; ++it) {
+            const int id = tid + it * 256;
+            const int quad = id >> 3, ch = id & 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = quad * 4 + e;
+                kreg[it][e] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                vreg[it][e] = kreg[it][e];
+                if (id < ITEMS && key < S) {
+                    const bf16_t* row = base + (size_t)key * ld + ch * 8;
+                    kreg[it][e] = *reinterpret_cast<const bf16x8*>(row + d);
+                    vreg[it][e] = *reinterpret_cast<const bf16x8*>(row + 2 * d);
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int id = tid + it * 256;
+            if (id >= ITEMS) continue;
+            const int quad = id >> 3, ch = id & 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = quad * 4 + e;
+                *reinterpret_cast<bf16x8*>(k_lds + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kreg[it][e];
+            }
+            // keys 4*quad .. 4*quad+3: u = key>>5, w = key&31, chunk (4u + ((w&15)>>2)), element 4*(w>>4) + (w&3)
+            const int k0 = quad * 4;
+            const int u = k0 >> 5, w = k0 & 31;
+            const int pos = (4 * u + ((w & 15) >> 2)) * 16 + ((w >> 4) << 2) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<bf16x4*>(vt_lds + (ch * 8 + j) * C::VT_ROW + pos) =
+                    bf16x4{vreg[it][0][j], vreg[it][1][j], vreg[it][2][j], vreg[it][3][j]};
+        }
     }
     __syncthreads();
 
     const float sl2 = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
     const int nqt = (S + 15) >> 4;
-    for (int qt = wave; qt < nqt; qt += 4) {
+    for (int qt = wave; qt < (DBG == 5 ? 0 : nqt); qt += 4) {
         const int qidx = qt * 16 + c;
         const int qrow = qidx < S ? qidx : S - 1;
         bf16x8 qf[2];
@@ -79,10 +110,14 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(kr + ((g ^ f) << 4));
             const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(kr + (((4 + g) ^ f) << 4));
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], acc, 0, 0, 0);
+            if constexpr (DBG != 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], acc, 0, 0, 0);
+            } else {
+                acc[0] = (float)qf[0][kt & 7];
+            }
             sc[kt] = acc;
-            __builtin_amdgcn_sched_barrier(0);   // keep the LDS reads of later tiles from being hoisted (VGPR pressure)
+            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound how far LDS reads are hoisted (VGPR pressure)
         }
         // ---- mask + row max (lane holds query qidx, keys kt*16 + 4g + r)
         float mx = -INFINITY;
@@ -90,20 +125,24 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int kidx = kt * 16 + 4 * g + r;
-                const bool ok = kidx < S && (!causal || kidx <= qidx);
-                const float v = ok ? sc[kt][r] : -INFINITY;
-                sc[kt][r] = v;
+                float v = sc[kt][r];
+                if (CAUSAL || kt >= NFULL) {      // resolved at compile time once the kt loop is unrolled
+                    const int kidx = kt * 16 + 4 * g + r;
+                    const bool ok = kidx < S && (!CAUSAL || kidx <= qidx);
+                    v = ok ? v : -INFINITY;
+                    sc[kt][r] = v;
+                }
                 mx = fmaxf(mx, v);
             }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmx = -mx * sl2;
         float sum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float p = exp2f((sc[kt][r] - mx) * sl2);   // exp2(-inf) = 0 for masked keys
+                const float p = DBG == 3 ? sc[kt][r] : __builtin_amdgcn_exp2f(fmaf(sc[kt][r], sl2, nmx));   // exp2(-inf) = 0
                 sc[kt][r] = p;
                 sum += p;
             }
@@ -120,11 +159,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
                                      (bf16_t)p1[0], (bf16_t)p1[1], (bf16_t)p1[2], (bf16_t)p1[3]};
 #pragma unroll
             for (int dt = 0; dt < 4; ++dt) {
-                const bf16x8 a =
-                    *reinterpret_cast<const bf16x8*>(vt_lds + (dt * 16 + c) * C::VT_ROW + (4 * u + g) * 16);
-                o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf, o[dt], 0, 0, 0);
+                if constexpr (DBG != 4) {
+                    const bf16x8 a =
+                        *reinterpret_cast<const bf16x8*>(vt_lds + (dt * 16 + c) * C::VT_ROW + (4 * u + g) * 16);
+                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf, o[dt], 0, 0, 0);
+                } else {
+                    o[dt][0] += (float)pf[dt];
+                }
             }
-            __builtin_amdgcn_sched_barrier(0);
+            if (u % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
         if (qidx < S) {
             const float inv = 1.0f / sum;
@@ -138,30 +181,62 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
 }
 
-template <int NKT>
-int launch_attn(const void* qkv, void* out, int B, int S, int heads, int causal, hipStream_t st) {
+int g_attn_debug = 0;   // timing-only ablations (ViT kernel)
+
+template <int NKT, bool CAUSAL, int NFULL>
+int launch_attn(const void* qkv, void* out, int B, int S, int heads, hipStream_t st) {
     using C = AttnCfg<NKT>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attention_kernel<NKT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                C::LDS) != hipSuccess) {
+        if (hipFuncSetAttribute((const void*)attention_kernel<NKT, CAUSAL, NFULL>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
             keds_set_error("attention: cannot set dynamic LDS size %d", C::LDS);
             return KEDS_E_LAUNCH;
         }
         attr_set = true;
     }
     KedsProfScope prof(KEDS_PROF_ATTN, st);
-    attention_kernel<NKT><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, causal);
+    if constexpr (NKT == 18 && !CAUSAL && NFULL == 16) {
+        if (g_attn_debug) {
+#define KEDS_ATTN_DBG(V)                                                                                          \
+    {                                                                                                            \
+        (void)hipFuncSetAttribute((const void*)attention_kernel<NKT, CAUSAL, NFULL, V>,                          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);                           \
+        attention_kernel<NKT, CAUSAL, NFULL, V><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads); \
+    }
+            switch (g_attn_debug) {
+                case 1: KEDS_ATTN_DBG(1) break;
+                case 2: KEDS_ATTN_DBG(2) break;
+                case 3: KEDS_ATTN_DBG(3) break;
+                case 4: KEDS_ATTN_DBG(4) break;
+                default: KEDS_ATTN_DBG(5) break;
+            }
+#undef KEDS_ATTN_DBG
+            return keds_check_launch("attention_kernel<dbg>");
+        }
+    }
+    attention_kernel<NKT, CAUSAL, NFULL><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads);
     return keds_check_launch("attention_kernel");
 }
 
 }  // namespace
 
+extern "C" int keds_attention_debug(int variant) {
+    g_attn_debug = variant;
+    return KEDS_OK;
+}
+
 extern "C" int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream) {
     KEDS_REQUIRE(qkv && out && B > 0 && heads > 0, "keds_attention: bad argument");
     KEDS_REQUIRE(S >= 1 && S <= 288, "keds_attention: S=%d unsupported (1..288)", S);
     hipStream_t st = (hipStream_t)stream;
-    if (S <= 32) return launch_attn<2>(qkv, out, B, S, heads, causal, st);
-    if (S <= 96) return launch_attn<6>(qkv, out, B, S, heads, causal, st);
-    return launch_attn<18>(qkv, out, B, S, heads, causal, st);
+    if (causal) {
+        if (S <= 32) return launch_attn<2, true, 0>(qkv, out, B, S, heads, st);
+        if (S <= 96) return launch_attn<6, true, 0>(qkv, out, B, S, heads, st);
+        return launch_attn<18, true, 0>(qkv, out, B, S, heads, st);
+    }
+    if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, st);
+    if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, st);
+    if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, st);   // ViT-L/14: 257 tokens
+    return launch_attn<18, false, 0>(qkv, out, B, S, heads, st);
 }
