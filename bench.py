@@ -31,6 +31,19 @@ VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=
 GEMM_MAC_PER_IMAGE = 256 * 588 * 1024 + 24 * (257 * 1024 * 3072 + 257 * 1024 * 1024 + 2 * 257 * 1024 * 4096) + 1024 * 768
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md
+PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def pmc_traffic(kernel_key, batch, rows, world):
+    """HBM bytes per launch of `kernel_key` from the committed PMC passes (tools/pmc_step.py + tools/parse_pmc.py:
+    separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same workload, FETCH_SIZE doubled per the gfx950
+    rule of MI355X_MICROARCH.md).  Only valid for the configuration they were taken on; otherwise None."""
+    if batch != 128 or rows != 500000 or world != 1 or not os.path.exists(PMC_FILE):
+        return None
+    e = json.load(open(PMC_FILE)).get(kernel_key)
+    if not e:
+        return None
+    return e.get("hbm_read_bytes_per_launch", 0.0) + e.get("hbm_write_bytes_per_launch", 0.0)
 
 
 def random_clip(device):
@@ -198,9 +211,12 @@ def main():
                        "db_shards": world, "parallelism": f"dp{world} encoders + {world}-way row-sharded scan"},
             "roofline": {"kernel": "gemm_bt_kernel (all ViT GEMMs of the step)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
-                         "traffic": None, "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1)},
+                         "traffic": pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
+                         "over the 256x256 GEMM launches)", "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1)},
             "roofline_scan": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_ach,
-                              "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": scan_ach / PEAK_HBM_GBPS, "traffic": None,
+                              "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": scan_ach / PEAK_HBM_GBPS,
+                              "traffic": pmc_traffic("scan_topk_kernel<768, 16", B, N, world),
+                              "algorithmic_bytes_per_search": (hi - lo) * D * 2.0,
                               "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1)},
             "stage_ms_per_step": {"gemm": gemm_ms / steps, "attention": attn_ms / steps, "layernorm": ln_ms / steps,
                                   "scan": scan_ms / steps, "other": other_ms / steps},
