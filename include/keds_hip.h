@@ -126,6 +126,11 @@ int keds_cirr_target_rank(const int32_t* order, int nq, int ng, const int32_t* g
 int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                  int epilogue, const float* aux, int aux_i, void* stream);
 
+/* Optional split-K scratch (fp32, 32 MiB is enough for every shape of the path).  Launches with fewer than ~64 output
+ * tiles (remainder rows, M <= 256) then split K over up to 16 workgroups per tile and reduce in a second tiny kernel;
+ * without it they run unsplit.  The buffer must stay valid until it is replaced; pass NULL to unregister. */
+int keds_gemm_set_workspace(void* ptr, size_t bytes);
+
 /* test/bench hook: 1 routes every GEMM through the 128x128 kernel (the 256x256 kernel is used for
  * N % 256 == 0, M >= 1024 otherwise) */
 int keds_gemm_force_small(int on);

@@ -82,6 +82,7 @@ SIGNATURES = {
     "keds_rank_gallery": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
     "keds_cirr_target_rank": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
+    "keds_gemm_set_workspace": (i32, [vp, sz]),
     "keds_gemm_force_small": (i32, [i32]),
     "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "keds_attention_debug": (i32, [i32]),
@@ -180,6 +181,21 @@ class Workspace:
         if self.buf is None or self.buf.numel() < nbytes or self.buf.device != torch.device(device):
             self.buf = torch.zeros(int(nbytes) + 256, dtype=torch.uint8, device=device)
         return self.buf
+
+
+_gemm_ws = {}
+
+
+def ensure_gemm_workspace(device=None) -> None:
+    """Register a 32 MiB split-K scratch buffer for the current device (idempotent)."""
+    require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _gemm_ws:
+        buf = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
+        _gemm_ws.clear()                      # one registration at a time (the library keeps a single pointer)
+        _gemm_ws[key] = buf
+        check(load().keds_gemm_set_workspace(buf.data_ptr(), buf.numel()), "keds_gemm_set_workspace")
 
 
 def prof_enable(on: bool) -> None:

@@ -93,13 +93,20 @@ __device__ __forceinline__ void small_wait_stage(int ahead) {   // `ahead` stage
 
 // NST = LDS ring depth: 2 (64 KiB, two workgroups per CU: throughput regime, many tiles) or 4 (128 KiB, counted
 // vmcnt keeps 2 K-tiles in flight: latency regime, a handful of workgroups such as remainder rows / M <= 128)
+// Split-K (part != nullptr): workgroup (tile, ks) accumulates K range [ks*k_len, (ks+1)*k_len) and stores its raw fp32
+// tile to part[ks][m][n]; gemm_splitk_reduce_kernel sums the slices and applies the epilogue.  Used when a launch has
+// too few tiles to fill the chip (remainder rows, M <= 256): one CU streams only ~60 GB/s through LDS-DMA.
 template <int EPI, int NST>
 __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                          const float* __restrict__ bias, void* __restrict__ out,
                                                          int M, int N, int K, int n_tiles,
-                                                         const float* __restrict__ aux, int aux_i) {
+                                                         const float* __restrict__ aux, int aux_i,
+                                                         float* __restrict__ part, int k_len, int tiles, int m_pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = part ? bid_all / tiles : 0;
+    const int bid = part ? bid_all - ks * tiles : bid_all;
+    const int k_begin = ks * k_len;
     const int tm = bid / n_tiles, tn = bid - tm * n_tiles;
     const int m0 = tm * BM, n0 = tn * BN;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     auto stage = [&](int buf, int kt) {
         char* xb = smem + buf * BUF_BYTES + (32 * wave) * 128;
         char* wb = xb + TILE_BYTES;
-        const int koff = kt * BK * 2;
+        const int koff = (k_begin + kt * BK) * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + koff),
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             xoff[kk] = xr * 128 + (((4 * kk + g) ^ swz_f(xr)) << 4);
-            woff[kk] = wr * 128 + (((4 * kk + g) ^ swz_f(wr)) << 4);
+            woff[kk] = TILE_BYTES + wr * 128 + (((4 * kk + g) ^ swz_f(wr)) << 4);
         }
     }
 
@@ -148,43 +155,83 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    // Software pipeline (same scheme as the 256^2 kernel): fragments are register double-buffered; the 8 reads
+    // of K-step s+1 are issued between the 16 MFMAs of K-step s.  K-tile t occupies ring slot t % NST; it is
+    // fully read into registers by the end of its kk=0 step, so at the kk=1 step (after one counted wait +
+    // barrier that also retires K-tile t+1) its slot is refilled with K-tile t+NST.
+    const int nk = (part ? k_len : K) / BK;
 #pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
+    for (int s = 0; s < NST; ++s)
         if (s < nk) stage(s, s);
+    {
+        int ahead = nk - 1;
+        if (ahead > NST - 1) ahead = NST - 1;
+        small_wait_stage<NST - 1>(ahead);                         // K-tile 0 landed
+    }
+    bf16x8 xa[4], wa[4], xb[4], wb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        xa[i] = *reinterpret_cast<const bf16x8*>(smem + xoff[0] + i * 2048);
+        wa[i] = *reinterpret_cast<const bf16x8*>(smem + woff[0] + i * 2048);
+    }
+#define KEDS_SMALL_MFMA(xc, wc, xn, wn_, nb, kkn, PREFETCH)                                                    \
+    {                                                                                                          \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                     \
+            _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
+                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);   \
+            if (PREFETCH) {                                                                                    \
+                xn[mi] = *reinterpret_cast<const bf16x8*>((nb) + xoff[kkn] + mi * 2048);                       \
+                wn_[mi] = *reinterpret_cast<const bf16x8*>((nb) + woff[kkn] + mi * 2048);                      \
+            }                                                                                                  \
+        }                                                                                                      \
+        if (PREFETCH) {                                                                                        \
+            KEDS_SM_G KEDS_SM_G KEDS_SM_G KEDS_SM_G                                                            \
+        }                                                                                                      \
+    }
+#define KEDS_SM_G                                                                                              \
+    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                         \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+
     int slot = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        int ahead = nk - 1 - kt;
-        if (ahead > NST - 2) ahead = NST - 2;
-        small_wait_stage<NST - 2>(ahead);          // K-tile kt landed for every wave; K-tile kt-1 fully consumed
-        {
-            int ns = slot + NST - 1;
-            if (ns >= NST) ns -= NST;
-            if (kt + NST - 1 < nk) stage(ns, kt + NST - 1);
+        const char* cb = smem + slot * BUF_BYTES;
+        int nslot = slot + 1 == NST ? 0 : slot + 1;
+        const char* ob = smem + nslot * BUF_BYTES;
+        // K-step (kt, 0): prefetch (kt, 1) from the same slot; no synchronisation needed
+        __builtin_amdgcn_sched_barrier(0);
+        KEDS_SMALL_MFMA(xa, wa, xb, wb, cb, 1, true)
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < nk) {
+            // K-step (kt, 1): retire K-tile kt+1 (younger tiles stay in flight), free slot of kt, refill it
+            int ahead = nk - 2 - kt;
+            if (ahead > NST - 2) ahead = NST - 2;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            small_wait_stage<NST - 2>(ahead);
+            if (kt + NST < nk) stage(slot, kt + NST);
+            __builtin_amdgcn_sched_barrier(0);
+            KEDS_SMALL_MFMA(xb, wb, xa, wa, ob, 0, true)
+        } else {
+            KEDS_SMALL_MFMA(xb, wb, xa, wa, ob, 0, false)
         }
-        const char* xt = smem + slot * BUF_BYTES;
-        const char* wt = xt + TILE_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 xf[4], wf[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xf[i] = *reinterpret_cast<const bf16x8*>(xt + xoff[kk] + i * 16 * 128);
-                wf[i] = *reinterpret_cast<const bf16x8*>(wt + woff[kk] + i * 16 * 128);
-            }
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
-        }
-        slot = slot + 1 == NST ? 0 : slot + 1;
+        slot = nslot;
     }
+#undef KEDS_SMALL_MFMA
+#undef KEDS_SM_G
 
     // ---- epilogue: lane (g,c) owns rows m = m0 + 64*wm + 16*mi + c, columns n0 + 64*wn + 32*p + 8*g + 0..7
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int n = n0 + 64 * wn + 32 * p + 8 * g;
+        if (part) {   // split-K slice: raw fp32 accumulators
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = m0 + 64 * wm + 16 * mi + c;
+                float* o = part + ((size_t)ks * m_pad + m) * N + n;
+                *reinterpret_cast<f32x4*>(o) = acc[2 * p][mi];
+                *reinterpret_cast<f32x4*>(o + 4) = acc[2 * p + 1][mi];
+            }
+            continue;
+        }
         f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
         if (bias) {
             b0 = *reinterpret_cast<const f32x4*>(bias + n);
@@ -199,6 +246,27 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     }
 }
 
+// sum the split-K slices, add bias, apply the epilogue; one thread per 8 consecutive outputs of one row
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
+                                                                 const float* __restrict__ bias, void* __restrict__ out,
+                                                                 int M, int N, const float* __restrict__ aux, int aux_i) {
+    const int per_row = N >> 3;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= M * per_row) return;
+    const int m = id / per_row, n = (id - m * per_row) << 3;
+    f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
+    if (bias) {
+        v0 = *reinterpret_cast<const f32x4*>(bias + n);
+        v1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+    }
+    for (int s = 0; s < splits; ++s) {
+        const float* p = part + ((size_t)s * m_pad + m) * N + n;
+        v0 += *reinterpret_cast<const f32x4*>(p);
+        v1 += *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    epilogue_store<EPI>(v0, v1, out, m, n, N, aux, aux_i);
+}
 
 // ==========================================================================================
 // Large-problem kernel: 256(m) x 256(n) x 32 tile, 8 waves (2 along m x 4 along n, 128 x 64 each =
@@ -372,9 +440,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_big_kernel(const bf16_t* __res
     }
 }
 
+float* g_ws = nullptr;      // caller-registered split-K workspace (keds_gemm_set_workspace)
+size_t g_ws_bytes = 0;
+
 template <int EPI, int NST>
 int launch_small_nst(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-                     int aux_i, hipStream_t st) {
+                     int aux_i, int splits, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)gemm_bt_kernel<EPI, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -385,18 +456,40 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
         attr_set = true;
     }
     const int m_tiles = (M + BM - 1) / BM, n_tiles = N / BN;
-    gemm_bt_kernel<EPI, NST><<<m_tiles * n_tiles, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias,
-                                                                              out, M, N, K, n_tiles, aux, aux_i);
+    const int tiles = m_tiles * n_tiles;
+    if (splits > 1) {
+        const int m_pad = m_tiles * BM;
+        gemm_bt_kernel<EPI, NST><<<tiles * splits, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
+                                                                               M, N, K, n_tiles, aux, aux_i, g_ws,
+                                                                               K / splits, tiles, m_pad);
+        int rc = keds_check_launch("gemm_bt_kernel(split-K)");
+        if (rc) return rc;
+        const int threads = M * (N / 8);
+        gemm_splitk_reduce_kernel<EPI><<<(threads + 255) / 256, 256, 0, st>>>(g_ws, splits, m_pad, bias, out, M, N, aux,
+                                                                              aux_i);
+        return keds_check_launch("gemm_splitk_reduce_kernel");
+    }
+    gemm_bt_kernel<EPI, NST><<<tiles, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
+                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0);
     return keds_check_launch("gemm_bt_kernel");
 }
+
+int g_no_split = 0;   // test hook
 
 template <int EPI>
 int launch_small(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                  int aux_i, hipStream_t st) {
-    // fewer workgroups than 2 per CU: nothing else hides the DMA latency, so use the deep ring
     const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
-    if (tiles < 512) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, st);
-    return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, st);
+    // too few tiles to fill 256 CUs: split K so that ~128+ workgroups stream the weights in parallel
+    if (tiles <= 64 && K >= 2048 && !g_no_split && g_ws) {   // at K = 1024 the second launch costs what the split saves
+        int splits = 1;
+        while (splits < 16 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
+        const size_t need = (size_t)splits * ((M + BM - 1) / BM * BM) * N * sizeof(float);
+        if (splits > 1 && need <= g_ws_bytes) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, splits, st);
+    }
+    // fewer workgroups than 2 per CU: nothing else hides the DMA latency, so use the deep ring
+    if (tiles < 512) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, 1, st);
+    return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, 1, st);
 }
 
 namespace pr {
@@ -406,6 +499,11 @@ constexpr int PBUF_BYTES = 2 * OP_BYTES;        // X | W
 constexpr int LDS_BYTES = 2 * PBUF_BYTES;       // 128 KiB
 }  // namespace pr
 
+// NOTE (measured, round 1): a persistent variant of this kernel (one workgroup per CU walking its tiles, next tile's
+// first two K-tiles issued during the last two K-steps so they land under the epilogue) was built, passed parity and was
+// SLOWER (out-proj main part 59 -> 67 us).  vmcnt retires in order and counts stores on gfx950, so every s_waitcnt that
+// guards a later K-tile also waits for the tile's epilogue store burst to drain (256 CUs x 128 KiB at once, ~8 us);
+// a freshly dispatched workgroup does not inherit that dependency.  Kept per-tile.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
@@ -531,6 +629,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     }
 }
 
+int device_cus_gemm() {
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
 int g_debug_variant = 0;  // timing-only ablations of the big kernel (EPI_BIAS_BF16 only)
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
 
@@ -609,8 +719,15 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
 
 }  // namespace
 
+extern "C" int keds_gemm_set_workspace(void* ptr, size_t bytes) {
+    g_ws = (float*)ptr;
+    g_ws_bytes = ptr ? bytes : 0;
+    return KEDS_OK;
+}
+
 extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
+    g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_debug_variant = (on >> 4) & 15;   // bits 4-7: timing-only ablation of the 256^2 kernel (0 = product path)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
     return KEDS_OK;

@@ -194,6 +194,7 @@ class CLIP(nn.Module):
             raise RuntimeError("keds_amd.CLIP: move the model to the GPU first (model.cuda()); no CPU path exists")
         if self._packed is None:
             self._packed = _Packed(self)
+        _lib.ensure_gemm_workspace(self._packed.device)
         return self._packed
 
     # ---- encoders ------------------------------------------------------------------------------------
@@ -327,6 +328,7 @@ class IM2TEXT(nn.Module):
             keep += [ow, ob]
             p.out_w, p.out_b = ptr(ow), ptr(ob)
             self._packed = (p, keep)
+        _lib.ensure_gemm_workspace(self.fc_out.weight.device)
         return self._packed[0]
 
     def forward(self, x: torch.Tensor):
@@ -397,6 +399,7 @@ class CrossFormer(nn.Module):
                 keep.append(t)
             p = _lib.CrossFormerParams(self.dim, self.heads, self._num_layers, arr)
             self._packed = (p, keep, arr)
+        _lib.ensure_gemm_workspace(self.cross_layers[0].to_q.weight.device)
         return self._packed[0]
 
     def forward(self, q, k, v):

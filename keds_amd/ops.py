@@ -42,6 +42,7 @@ def gemm_bt(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], epil
         odt = torch.float32 if epilogue in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32, _lib.EPI_PATCH_F32) \
             else torch.bfloat16
         out = torch.zeros((_pad128(M), N), dtype=odt, device=a.device)
+    _lib.ensure_gemm_workspace(a.device)
     check(load().keds_gemm_bt(ptr(a), ptr(w), ptr(bias), ptr(out), M, N, K, epilogue, ptr(aux), aux_i, stream()),
           "keds_gemm_bt")
     return out
