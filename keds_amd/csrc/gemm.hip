@@ -512,7 +512,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     using namespace pr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / n_tiles, tn = bid - tm * n_tiles;
+    // The 32 workgroups that run together on one XCD take consecutive logical ids.  Map each run of 32 ids to a
+    // block of 8 m-tiles x 4 n-tiles (12 distinct operand panels per K-tile in that XCD's L2 instead of up to 18
+    // with a plain n-fastest order) when the tile grid allows it.
+    int tm, tn;
+    const int m_tiles = gridDim.x / n_tiles;
+    if ((m_tiles & 7) == 0 && (n_tiles & 3) == 0) {
+        const int grp = bid >> 5, within = bid & 31;
+        const int gcols = n_tiles >> 2;
+        const int gm = grp / gcols, gn = grp - gm * gcols;
+        tm = gm * 8 + (within & 7);
+        tn = gn * 4 + (within >> 3);
+    } else {
+        tm = bid / n_tiles;
+        tn = bid - tm * n_tiles;
+    }
     const int m0 = tm * TM, n0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
