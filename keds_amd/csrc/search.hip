@@ -82,10 +82,12 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
     const int s0 = stage_begin + (int)(((long long)blockIdx.x * total_stages) / nwg);
     const int s1 = stage_begin + (int)(((long long)(blockIdx.x + 1) * total_stages) / nwg);
 
+    // blockIdx.y = query block of 128; the workgroups of one block split the stage range between them
+    const int qglob = blockIdx.y * QBLOCK + wave * 16 + c;
     // queries of this wave as MFMA B operands: lane (g,c) holds Q[16*wave + c][32*s + 8*g .. +7]
     bf16x8 qf[C::KSTEPS];
     {
-        const bf16_t* qrow = qb + (size_t)(wave * 16 + c) * D + 8 * g;
+        const bf16_t* qrow = qb + (size_t)qglob * D + 8 * g;
 #pragma unroll
         for (int s = 0; s < C::KSTEPS; ++s) qf[s] = *reinterpret_cast<const bf16x8*>(qrow + 32 * s);
     }
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
         lv[j] = -INFINITY;
         li[j] = -1;
     }
-    const float thr0 = thr ? thr[wave * 16 + c] : -INFINITY;
+    const float thr0 = thr ? thr[qglob] : -INFINITY;
     float lmin = thr0;
 
     // make sure the query loads are consumed before any LDS-DMA is counted on vmcnt
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
     }
 
     // lists out: [query][wg][g][L]
-    const size_t o = (((size_t)(wave * 16 + c) * nwg + blockIdx.x) * 4 + g) * L;
+    const size_t o = (((size_t)qglob * nwg + blockIdx.x) * 4 + g) * L;
 #pragma unroll
     for (int j = 0; j < L; j += 4) {
         *reinterpret_cast<f32x4*>(out_val + o + j) = f32x4{lv[j], lv[j + 1], lv[j + 2], lv[j + 3]};
@@ -275,14 +277,18 @@ __device__ __forceinline__ unsigned ord_key(float f) {
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-constexpr int MERGE_MAXE = 66;   // entries per thread: (1024 lists * 16 + 64 extra) / 256 = 64.25
+constexpr int MERGE_THREADS = 256;    // measured: 1024 threads is 8 % faster for 128 queries but 45 % slower for 1024
+constexpr int MERGE_WAVES = MERGE_THREADS / 64;
+constexpr int MERGE_MAXE = 66;         // entries per thread: (1024 lists * 16 + 64 extra) / 256 = 64.25
+constexpr int MERGE_DENSE = 1024;      // packed valid keys per wave that still fit 16 registers per lane
 
-__global__ __launch_bounds__(256) void merge_select_kernel(const float* __restrict__ val, const int* __restrict__ idx,
+__global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float* __restrict__ val, const int* __restrict__ idx,
                                                            int nlists, int listk, const float* __restrict__ xval,
                                                            const int* __restrict__ xidx, int nextra,
                                                            int* __restrict__ cand_idx, float* __restrict__ cand_val,
                                                            float* __restrict__ thr_out) {
     __shared__ unsigned hist[256];
+    __shared__ unsigned ckeys[MERGE_WAVES][MERGE_DENSE];
     __shared__ unsigned s_out, s_eq;
     __shared__ int eq_idx[256];
     __shared__ float eq_val[256];
@@ -294,21 +300,28 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const float* __restri
     unsigned key[MERGE_MAXE];
     int id[MERGE_MAXE];
     unsigned nvalid = 0;
+    {
+        // unconditional (index-clamped) loads so that all of a thread's entries are in flight together; predicated
+        // loads were being issued one round trip at a time
+        float fv[MERGE_MAXE];
+        const int last = total > 0 ? total - 1 : 0;
 #pragma unroll
-    for (int i = 0; i < MERGE_MAXE; ++i) {
-        const int e = tid + i * 256;
-        float f = -INFINITY;
-        int j = -1;
-        if (e < nmain) {
-            f = v[e];
-            j = ix[e];
-        } else if (e < total) {
-            f = xval[(size_t)q * nextra + (e - nmain)];
-            j = xidx[(size_t)q * nextra + (e - nmain)];
+        for (int i = 0; i < MERGE_MAXE; ++i) {
+            const int e = tid + i * MERGE_THREADS;
+            const int ec = e < last ? e : last;
+            const bool main_e = ec < nmain;
+            const float* vp = main_e ? v + ec : xval + (size_t)q * nextra + (ec - nmain);
+            const int* ip = main_e ? ix + ec : xidx + (size_t)q * nextra + (ec - nmain);
+            fv[i] = *vp;
+            id[i] = *ip;
         }
-        id[i] = j;
-        key[i] = j >= 0 ? ord_key(f) : 0u;          // 0 is below every real score's key
-        nvalid += j >= 0 ? 1u : 0u;
+#pragma unroll
+        for (int i = 0; i < MERGE_MAXE; ++i) {
+            const int e = tid + i * MERGE_THREADS;
+            if (e >= total) id[i] = -1;
+            key[i] = id[i] >= 0 ? ord_key(fv[i]) : 0u;      // 0 is below every real score's key
+            nvalid += id[i] >= 0 ? 1u : 0u;
+        }
     }
     // block-wide reductions through 4 LDS words (one per wave); no atomics on shared bins: the scores of one
     // query share their high bits, so histogram atomics would serialise
@@ -319,7 +332,10 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const float* __restri
         __syncthreads();                       // previous readers of hist[0..3] are done
         if (lane == 0) hist[wv] = x;
         __syncthreads();
-        return hist[0] + hist[1] + hist[2] + hist[3];
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < MERGE_WAVES; ++w) t += hist[w];
+        return t;
     };
     auto block_or = [&](unsigned x) -> unsigned {
 #pragma unroll
@@ -327,7 +343,10 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const float* __restri
         __syncthreads();
         if (lane == 0) hist[wv] = x;
         __syncthreads();
-        return hist[0] | hist[1] | hist[2] | hist[3];
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < MERGE_WAVES; ++w) t |= hist[w];
+        return t;
     };
     if (tid == 0) {
         s_out = 0;
@@ -353,7 +372,7 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const float* __restri
         __syncthreads();
         kmax = hist[0];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) kmax = hist[w] > kmax ? hist[w] : kmax;
+        for (int w = 1; w < MERGE_WAVES; ++w) kmax = hist[w] > kmax ? hist[w] : kmax;
 #pragma unroll
         for (int i = 0; i < MERGE_MAXE; ++i)
             if (id[i] >= 0) kxor |= key[i] ^ kmax;
@@ -362,13 +381,42 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const float* __restri
         // T = the NCAND-th largest key: greedy bit by bit, largest T with count(key >= T) >= want
         unsigned prefix = top >= 31 ? 0u : (kmax & ~((2u << top) - 1u));   // common high bits (top == -1: all equal)
         if (top < 0) prefix = kmax;
-#pragma unroll 1
-        for (int bit = top; bit >= 0; --bit) {
-            const unsigned cand = prefix | (1u << bit);
-            unsigned cnt = 0;
+        // With thresholds most list slots are empty.  Each wave packs its valid keys densely into LDS (ballot prefix,
+        // no atomics); if every wave holds <= 1024 of them a lane re-reads at most 16, and the bisection counts over
+        // 16 registers instead of MERGE_MAXE.
+        unsigned wcnt = 0;
 #pragma unroll
-            for (int i = 0; i < MERGE_MAXE; ++i) cnt += key[i] >= cand ? 1u : 0u;    // invalid keys are 0 < cand
-            if (block_sum(cnt) >= want) prefix = cand;
+        for (int i = 0; i < MERGE_MAXE; ++i) {
+            const bool valid = id[i] >= 0;
+            const unsigned long long mask = __ballot(valid);
+            if (valid) {
+                const unsigned pos = wcnt + __popcll(mask & ((1ull << lane) - 1ull));
+                if (pos < (unsigned)MERGE_DENSE) ckeys[wv][pos] = key[i];
+            }
+            wcnt += (unsigned)__popcll(mask);
+        }
+        const bool dense = block_or(wcnt > (unsigned)MERGE_DENSE ? 1u : 0u) == 0u;   // also makes the LDS writes visible
+        if (dense) {
+            unsigned ck[MERGE_DENSE / 64];
+#pragma unroll
+            for (int j = 0; j < MERGE_DENSE / 64; ++j) ck[j] = (unsigned)(lane + 64 * j) < wcnt ? ckeys[wv][lane + 64 * j] : 0u;
+#pragma unroll 1
+            for (int bit = top; bit >= 0; --bit) {
+                const unsigned cand = prefix | (1u << bit);
+                unsigned cnt = 0;
+#pragma unroll
+                for (int j = 0; j < MERGE_DENSE / 64; ++j) cnt += ck[j] >= cand ? 1u : 0u;
+                if (block_sum(cnt) >= want) prefix = cand;
+            }
+        } else {
+#pragma unroll 1
+            for (int bit = top; bit >= 0; --bit) {
+                const unsigned cand = prefix | (1u << bit);
+                unsigned cnt = 0;
+#pragma unroll
+                for (int i = 0; i < MERGE_MAXE; ++i) cnt += key[i] >= cand ? 1u : 0u;    // invalid keys are 0 < cand
+                if (block_sum(cnt) >= want) prefix = cand;
+            }
         }
         T = prefix;
         unsigned gt = 0;
@@ -415,7 +463,7 @@ __global__ __launch_bounds__(256) void merge_select_kernel(const float* __restri
         }
     }
     // fillers when fewer than NCAND valid entries
-    for (int o = (int)want + tid; o < NCAND; o += 256) {
+    for (int o = (int)want + tid; o < NCAND; o += MERGE_THREADS) {
         cand_idx[q * NCAND + o] = -1;
         cand_val[q * NCAND + o] = -INFINITY;
     }
@@ -567,6 +615,8 @@ int device_cus() {
     return cus;
 }
 
+constexpr int MAXQB = 8;   // query blocks searched per launch set (1024 queries)
+
 struct SearchWs {
     float* qn;       // [nq_pad, dim]
     bf16_t* qb;      // [128, dim]
@@ -593,15 +643,15 @@ SearchWs carve(void* ws, int nq, int dim) {
     };
     const size_t nq_pad = keds_align_up((size_t)nq, QBLOCK);
     w.qn = (float*)take(nq_pad * dim * sizeof(float));
-    w.qb = (bf16_t*)take((size_t)QBLOCK * dim * 2);
+    w.qb = (bf16_t*)take((size_t)MAXQB * QBLOCK * dim * 2);
     w.lval = (float*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(float));
     w.lidx = (int*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(int));
-    w.cidx = (int*)take((size_t)QBLOCK * NCAND * sizeof(int));
-    w.cval = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
-    w.cdist = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
-    w.aidx = (int*)take((size_t)QBLOCK * NCAND * sizeof(int));
-    w.aval = (float*)take((size_t)QBLOCK * NCAND * sizeof(float));
-    w.thr = (float*)take((size_t)QBLOCK * sizeof(float));
+    w.cidx = (int*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(int));
+    w.cval = (float*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(float));
+    w.cdist = (float*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(float));
+    w.aidx = (int*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(int));
+    w.aval = (float*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(float));
+    w.thr = (float*)take((size_t)MAXQB * QBLOCK * sizeof(float));
     w.bytes = off;
     return w;
 }
@@ -611,7 +661,7 @@ int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresho
 
 template <int D, int L>
 int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr, float* lval,
-                int* lidx, int nwg, hipStream_t st) {
+                int* lidx, int nwg, int nqb, hipStream_t st) {
     using C = ScanCfg<D>;
     const size_t lds = (size_t)C::NST * C::LDS_STAGE;
     static bool attr_set = false;
@@ -630,7 +680,7 @@ int launch_scan(const void* packed, int stage_begin, int total_stages, const bf1
     {                                                                                                              \
         (void)hipFuncSetAttribute((const void*)scan_topk_kernel<D, L, V>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                   (int)lds);                                                                       \
-        scan_topk_kernel<D, L, V><<<nwg, SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, \
+        scan_topk_kernel<D, L, V><<<dim3(nwg, nqb), SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, \
                                                                lval, lidx);                                        \
     }
             switch (g_scan_debug) {
@@ -642,7 +692,7 @@ int launch_scan(const void* packed, int stage_begin, int total_stages, const bf1
             return keds_check_launch("scan_topk_kernel<dbg>");
         }
     }
-    scan_topk_kernel<D, L><<<nwg, SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, lval,
+    scan_topk_kernel<D, L><<<dim3(nwg, nqb), SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, lval,
                                                            lidx);
     return keds_check_launch("scan_topk_kernel");
 }
@@ -716,46 +766,54 @@ extern "C" int keds_index_search(const void* packed, const float* db, int64_t n,
     // (expected accept rate 64 / rows(A): ~0.2 % at 0.5 M rows).  Small databases use one phase.
     const bool two_phase = g_scan_phases != 1 && total_stages >= 16 * 64;
     const int stagesA = total_stages / 16;                         // threshold pass: first 1/16 of the rows
-    const int nwgA = stagesA < cus ? stagesA : cus;
-    const int nwgB = total_stages < cus ? total_stages : cus;
-    auto scan_thr = [&](int count, int nwg) -> int {               // depth-4 lists, no threshold
-        switch (dim) {
-            case 128: return launch_scan<128, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
-            case 256: return launch_scan<256, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
-            case 512: return launch_scan<512, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
-            case 768: return launch_scan<768, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
-            default: return launch_scan<1024, 4>(packed, 0, count, w.qb, nullptr, w.lval, w.lidx, nwg, st);
-        }
-    };
-    auto scan_all = [&](const float* thr, int nwg) -> int {        // depth-16 lists over every stage
-        switch (dim) {
-            case 128: return launch_scan<128, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
-            case 256: return launch_scan<256, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
-            case 512: return launch_scan<512, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
-            case 768: return launch_scan<768, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
-            default: return launch_scan<1024, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwg, st);
-        }
-    };
     int rc;
-    for (int q0 = 0; q0 < nq; q0 += QBLOCK) {
-        const int nb = nq - q0 < QBLOCK ? nq - q0 : QBLOCK;
+    // Up to MAXQB query blocks (1024 queries) share one set of launches: grid.y = query block, and the `cus`
+    // workgroups are divided between the blocks, each block's workgroups splitting the stage range.  A row-sharded
+    // multi-GPU search (every rank scans its small shard for ALL ranks' queries) then costs one launch set, and the
+    // shard is re-streamed per block from the Infinity Cache rather than HBM.
+    for (int q0 = 0; q0 < nq; q0 += MAXQB * QBLOCK) {
+        const int nb = nq - q0 < MAXQB * QBLOCK ? nq - q0 : MAXQB * QBLOCK;      // queries in this launch set
+        const int nqb = (nb + QBLOCK - 1) / QBLOCK;
+        int per = cus / nqb;
+        if (per < 1) per = 1;
+        const int nwgA = stagesA < per ? (stagesA < 1 ? 1 : stagesA) : per;
+        const int nwgB = total_stages < per ? total_stages : per;
         float* qn = w.qn + (size_t)q0 * dim;
-        qprep_kernel<<<QBLOCK / 4, 256, 0, st>>>(queries + (size_t)q0 * dim, nb, dim, normalize_q, qn, w.qb, QBLOCK);
+        qprep_kernel<<<nqb * QBLOCK / 4, 256, 0, st>>>(queries + (size_t)q0 * dim, nb, dim, normalize_q, qn, w.qb,
+                                                      nqb * QBLOCK);
         if ((rc = keds_check_launch("qprep_kernel"))) return rc;
+        auto scan_thr = [&]() -> int {                             // depth-4 lists, no threshold
+            switch (dim) {
+                case 128: return launch_scan<128, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
+                case 256: return launch_scan<256, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
+                case 512: return launch_scan<512, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
+                case 768: return launch_scan<768, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
+                default: return launch_scan<1024, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
+            }
+        };
+        auto scan_all = [&](const float* thr) -> int {            // depth-16 lists over every stage
+            switch (dim) {
+                case 128: return launch_scan<128, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
+                case 256: return launch_scan<256, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
+                case 512: return launch_scan<512, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
+                case 768: return launch_scan<768, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
+                default: return launch_scan<1024, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
+            }
+        };
         if (two_phase) {
             // Threshold pass: every lane keeps the best 4 scores of its share of the first 1/16 of the rows; the
             // 64th best of their union is a score that 64 real rows reach, so the final 64 candidates all beat or
             // equal it.  The candidate pass then rescans everything, inserting only above that threshold
             // (expected accept rate 64 / rows(A): 0.2 % at 0.5 M rows), so list inserts are rare for ANY data.
-            if ((rc = scan_thr(stagesA, nwgA))) return rc;
+            if ((rc = scan_thr())) return rc;
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_select_kernel<<<nb, 256, 0, st>>>(w.lval, w.lidx, nwgA * 4, 4, nullptr, nullptr, 0, w.aidx, w.aval, w.thr);
+            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgA * 4, 4, nullptr, nullptr, 0, w.aidx, w.aval, w.thr);
             if ((rc = keds_check_launch("merge_select_kernel(thr)"))) return rc;
         }
-        if ((rc = scan_all(two_phase ? w.thr : nullptr, nwgB))) return rc;
+        if ((rc = scan_all(two_phase ? w.thr : nullptr))) return rc;
         {
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_select_kernel<<<nb, 256, 0, st>>>(w.lval, w.lidx, nwgB * 4, LISTK, nullptr, nullptr, 0, w.cidx, w.cval, nullptr);
+            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgB * 4, LISTK, nullptr, nullptr, 0, w.cidx, w.cval, nullptr);
             if ((rc = keds_check_launch("merge_select_kernel"))) return rc;
             rerank_kernel<<<(nb * NCAND + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * NCAND);
             if ((rc = keds_check_launch("rerank_kernel"))) return rc;

@@ -20,20 +20,30 @@ D_ATOL = 2e-6
 
 
 def _check(index, db, q, k, name, normalize=False):
+    """Indices equal to the oracle's, except that two rows whose exact (fp64) distances agree within 1e-6 may swap
+    ranks: the GPU orders the final candidates by fp32 distances (error ~1e-7), the oracle by fp64."""
     D, I, rows = index.search_gather(q.cuda(), k, normalize=normalize)
     qq = O.l2_normalize(q) if normalize else q
     Do, Io = O.flat_l2_search(db, qq, k)
     I, D = I.cpu(), D.cpu()
     mism = int((I != Io).sum())
     report(name, n=db.shape[0], dim=db.shape[1], nq=q.shape[0], k=k, index_mismatches=mism, d_maxabs=max_abs(D, Do))
-    assert mism == 0, f"{mism} index mismatches"
     assert max_abs(D, Do) <= D_ATOL
-    assert torch.equal(rows.cpu(), db[Io.reshape(-1)].reshape(q.shape[0], k, -1)), "gathered rows differ"
+    if mism:
+        bad_rows = torch.nonzero((I != Io).any(dim=1)).flatten()
+        assert len(bad_rows) <= max(1, q.shape[0] // 200), f"{len(bad_rows)} rows differ"
+        for r in bad_rows.tolist():
+            exact = ((qq[r].double()[None, :] - db[I[r]].double()) ** 2).sum(1)      # fp64 distances of OUR ids
+            assert float((exact - Do[r].double()).abs().max()) <= 1e-6, "not a near-tie swap"
+            assert len(set(I[r].tolist())) == k
+    assert torch.equal(rows.cpu(), db[I.reshape(-1)].reshape(q.shape[0], k, -1)), "gathered rows differ"
     return D, I
 
 
 @pytest.mark.parametrize("n,dim,nq,k", [(20000, 768, 37, 16), (20000, 768, 128, 10), (4099, 128, 5, 16),
-                                        (50001, 256, 130, 1), (3000, 512, 9, 7), (2500, 1024, 3, 16)])
+                                        (50001, 256, 130, 1), (3000, 512, 9, 7), (2500, 1024, 3, 16),
+                                        (62500, 768, 1024, 10),      # one 8-GPU shard searched for 8 ranks' queries
+                                        (40000, 768, 1300, 16)])     # more than one launch set (> 1024 queries)
 def test_search_matches_oracle(n, dim, nq, k):
     db = O.synth_database(n, dim, seed=2002)
     q = O.synth_database(nq, dim, seed=3003)
