@@ -27,8 +27,13 @@ if ROOT not in sys.path:
 VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
             context_length=77, vocab_size=49408, transformer_width=768, transformer_heads=12, transformer_layers=12)
 
-# algorithmic GEMM work of one ViT-L/14 image: patch embed + 24 x (qkv, out, fc, proj) + read-out
-GEMM_MAC_PER_IMAGE = 256 * 588 * 1024 + 24 * (257 * 1024 * 3072 + 257 * 1024 * 1024 + 2 * 257 * 1024 * 4096) + 1024 * 768
+# GEMM work EXECUTED per ViT-L/14 image (SURVEY.md App. A shapes): patch embed + 24 x qkv + 23 x (out, fc, proj) on all
+# 257 tokens + the last block's (out, fc, proj) on the CLS token only (nothing else is read after the last block,
+# model.py:412; the reference computes those 256 unused rows) + read-out.  The reference-equivalent count
+# (all 24 blocks on 257 tokens) is 77.77 GMAC; executed: 75.18 GMAC.
+_PER_TOKEN_TAIL = 1024 * 1024 + 2 * 1024 * 4096                     # out-proj + fc + proj MACs per token
+GEMM_MAC_PER_IMAGE = (256 * 588 * 1024 + 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL + 1 * _PER_TOKEN_TAIL
+                      + 1024 * 768)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes

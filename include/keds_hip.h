@@ -125,6 +125,10 @@ int keds_cirr_target_rank(const int32_t* order, int nq, int ng, const int32_t* g
  * aux: EPI_PATCH: fp32 positional embedding [G+1, N], aux_i = G (patches per image). */
 int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                  int epilogue, const float* aux, int aux_i, void* stream);
+/* same with row strides (elements) of A and out: rows need not be contiguous (CLS-row-only last layer); A rows
+ * past M are never read */
+int keds_gemm_bt_ex(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                    int M, int N, int K, int epilogue, const float* aux, int aux_i, void* stream);
 
 /* Optional split-K scratch (fp32, 32 MiB is enough for every shape of the path).  Launches with fewer than ~64 output
  * tiles (remainder rows, M <= 256) then split K over up to 16 workgroups per tile and reduce in a second tiny kernel;
@@ -149,6 +153,8 @@ int keds_attention_debug(int variant);
  * out bf16 [B*S, d] = softmax(q k^T / 8 [+ causal mask, model.py:543-549]) v.  dh = 64,
  * S <= 288. */
 int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream);
+/* same, computing and storing only the first q_limit query rows of every sample (keys/values: all S rows) */
+int keds_attention_ex(const void* qkv, void* out, int B, int S, int heads, int causal, int q_limit, void* stream);
 
 /* patch im2col for conv1 (model.py:381,394-396): image fp32 [B,3,R,R] -> bf16 [B*G, Kpad],
  * column c*P*P + ky*P + kx, zero padded to Kpad (a multiple of 64). */
@@ -192,6 +198,9 @@ typedef struct {
     int width, layers, heads, seq;                  /* seq = tokens per sample (257 / 77) */
     int causal;
     const keds_block_params* blocks;                /* HOST array [layers] of device pointers */
+    int last_cls_only;                              /* 1: after the LAST block only token 0 of every sample is
+                                                       defined (ViT read-out): its attention queries, out-proj, ln_2
+                                                       and MLP run on B rows instead of B*seq */
 } keds_tower_params;
 
 typedef struct {

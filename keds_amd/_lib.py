@@ -33,7 +33,7 @@ class BlockParams(C.Structure):
 
 class TowerParams(C.Structure):
     _fields_ = [("width", i32), ("layers", i32), ("heads", i32), ("seq", i32), ("causal", i32),
-                ("blocks", C.POINTER(BlockParams))]
+                ("blocks", C.POINTER(BlockParams)), ("last_cls_only", i32)]
 
 
 class VitParams(C.Structure):
@@ -84,8 +84,10 @@ SIGNATURES = {
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "keds_gemm_set_workspace": (i32, [vp, sz]),
     "keds_gemm_force_small": (i32, [i32]),
+    "keds_gemm_bt_ex": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "keds_attention_debug": (i32, [i32]),
+    "keds_attention_ex": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "keds_attention": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_im2col": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_embed_tokens": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),

@@ -31,7 +31,7 @@ struct AttnCfg {
 // need no mask (non-causal only) -- evaluating the mask for all 72 score registers cost half the loop's instructions.
 template <int NKT, bool CAUSAL, int NFULL, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
-                                                        int heads) {
+                                                        int heads, int q_limit) {
     using C = AttnCfg<NKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     __syncthreads();
 
     const float sl2 = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-    const int nqt = (S + 15) >> 4;
+    const int nqt = (q_limit + 15) >> 4;      // only the first q_limit query rows are computed and stored
     for (int qt = wave; qt < (DBG == 5 ? 0 : nqt); qt += 4) {
         const int qidx = qt * 16 + c;
         const int qrow = qidx < S ? qidx : S - 1;
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
             }
             if (u % 3 == 2) __builtin_amdgcn_sched_barrier(0);
         }
-        if (qidx < S) {
+        if (qidx < q_limit) {
             const float inv = 1.0f / sum;
             bf16_t* op = out + ((size_t)b * S + qidx) * d + h * DH + 4 * g;
 #pragma unroll
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 int g_attn_debug = 0;   // timing-only ablations (ViT kernel)
 
 template <int NKT, bool CAUSAL, int NFULL>
-int launch_attn(const void* qkv, void* out, int B, int S, int heads, hipStream_t st) {
+int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit, hipStream_t st) {
     using C = AttnCfg<NKT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -202,7 +202,7 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, hipStream_t
     {                                                                                                            \
         (void)hipFuncSetAttribute((const void*)attention_kernel<NKT, CAUSAL, NFULL, V>,                          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);                           \
-        attention_kernel<NKT, CAUSAL, NFULL, V><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads); \
+        attention_kernel<NKT, CAUSAL, NFULL, V><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit); \
     }
             switch (g_attn_debug) {
                 case 1: KEDS_ATTN_DBG(1) break;
@@ -215,7 +215,7 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, hipStream_t
             return keds_check_launch("attention_kernel<dbg>");
         }
     }
-    attention_kernel<NKT, CAUSAL, NFULL><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads);
+    attention_kernel<NKT, CAUSAL, NFULL><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit);
     return keds_check_launch("attention_kernel");
 }
 
@@ -226,17 +226,23 @@ extern "C" int keds_attention_debug(int variant) {
     return KEDS_OK;
 }
 
-extern "C" int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream) {
+extern "C" int keds_attention_ex(const void* qkv, void* out, int B, int S, int heads, int causal, int q_limit,
+                                 void* stream) {
     KEDS_REQUIRE(qkv && out && B > 0 && heads > 0, "keds_attention: bad argument");
     KEDS_REQUIRE(S >= 1 && S <= 288, "keds_attention: S=%d unsupported (1..288)", S);
+    if (q_limit <= 0 || q_limit > S) q_limit = S;
     hipStream_t st = (hipStream_t)stream;
     if (causal) {
-        if (S <= 32) return launch_attn<2, true, 0>(qkv, out, B, S, heads, st);
-        if (S <= 96) return launch_attn<6, true, 0>(qkv, out, B, S, heads, st);
-        return launch_attn<18, true, 0>(qkv, out, B, S, heads, st);
+        if (S <= 32) return launch_attn<2, true, 0>(qkv, out, B, S, heads, q_limit, st);
+        if (S <= 96) return launch_attn<6, true, 0>(qkv, out, B, S, heads, q_limit, st);
+        return launch_attn<18, true, 0>(qkv, out, B, S, heads, q_limit, st);
     }
-    if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, st);
-    if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, st);
-    if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, st);   // ViT-L/14: 257 tokens
-    return launch_attn<18, false, 0>(qkv, out, B, S, heads, st);
+    if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, q_limit, st);
+    if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, q_limit, st);
+    if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, q_limit, st);   // ViT-L/14: 257 tokens
+    return launch_attn<18, false, 0>(qkv, out, B, S, heads, q_limit, st);
+}
+
+extern "C" int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream) {
+    return keds_attention_ex(qkv, out, B, S, heads, causal, S, stream);
 }

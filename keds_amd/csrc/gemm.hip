@@ -38,7 +38,7 @@ __device__ __forceinline__ float qgelu(float x) {
 // one lane's 8 consecutive output columns [n, n+8) of row m
 template <int EPI>
 __device__ __forceinline__ void epilogue_store(f32x4 v0, f32x4 v1, void* __restrict__ out, int m, int n, int N,
-                                               const float* __restrict__ aux, int aux_i) {
+                                               const float* __restrict__ aux, int aux_i, long long ldc) {
     if constexpr (EPI == KEDS_EPI_BIAS_QGELU_BF16) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -56,15 +56,15 @@ __device__ __forceinline__ void epilogue_store(f32x4 v0, f32x4 v1, void* __restr
     if constexpr (EPI == KEDS_EPI_BIAS_BF16 || EPI == KEDS_EPI_BIAS_QGELU_BF16 || EPI == KEDS_EPI_BIAS_RELU_BF16) {
         bf16x8 o = bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
                           (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * N + n) = o;
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * ldc + n) = o;
     } else if constexpr (EPI == KEDS_EPI_BIAS_RESID_F32) {
-        float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
+        float* o = reinterpret_cast<float*>(out) + (size_t)m * ldc + n;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(o);
         const f32x4 r1 = *reinterpret_cast<const f32x4*>(o + 4);
         *reinterpret_cast<f32x4*>(o) = r0 + v0;
         *reinterpret_cast<f32x4*>(o + 4) = r1 + v1;
     } else if constexpr (EPI == KEDS_EPI_BIAS_F32) {
-        float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
+        float* o = reinterpret_cast<float*>(out) + (size_t)m * ldc + n;
         *reinterpret_cast<f32x4*>(o) = v0;
         *reinterpret_cast<f32x4*>(o + 4) = v1;
     } else {  // KEDS_EPI_PATCH_F32: token row (m/G)*(G+1) + 1 + m%G, plus positional embedding
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
                                                          const float* __restrict__ bias, void* __restrict__ out,
                                                          int M, int N, int K, int n_tiles,
                                                          const float* __restrict__ aux, int aux_i,
-                                                         float* __restrict__ part, int k_len, int tiles, int m_pad) {
+                                                         float* __restrict__ part, int k_len, int tiles, int m_pad,
+                                                         long long lda, long long ldc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = part ? bid_all / tiles : 0;
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     for (int i = 0; i < 4; ++i) {
         const int R = 32 * wave + 8 * i + srow;
         const int ch = sslot ^ swz_f(R);
-        xsrc[i] = reinterpret_cast<const char*>(X + (size_t)(m0 + R) * K) + ch * 16;
+        const int xr = m0 + R < M ? m0 + R : M - 1;     // rows past M re-read row M-1 (results discarded): A needs no padding
+        xsrc[i] = reinterpret_cast<const char*>(X + (size_t)xr * lda) + ch * 16;
         wsrc[i] = reinterpret_cast<const char*>(W + (size_t)(n0 + perm_w(R)) * K) + ch * 16;
     }
     auto stage = [&](int buf, int kt) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
         for (int mi = 0; mi < 4; ++mi) {
             const int m = m0 + 64 * wm + 16 * mi + c;
             if (m >= M) continue;
-            epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i);
+            epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
         }
     }
 }
@@ -250,7 +252,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
                                                                  const float* __restrict__ bias, void* __restrict__ out,
-                                                                 int M, int N, const float* __restrict__ aux, int aux_i) {
+                                                                 int M, int N, const float* __restrict__ aux, int aux_i,
+                                                                 long long ldc) {
     const int per_row = N >> 3;
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= M * per_row) return;
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
         v0 += *reinterpret_cast<const f32x4*>(p);
         v1 += *reinterpret_cast<const f32x4*>(p + 4);
     }
-    epilogue_store<EPI>(v0, v1, out, m, n, N, aux, aux_i);
+    epilogue_store<EPI>(v0, v1, out, m, n, N, aux, aux_i, ldc);
 }
 
 // ==========================================================================================
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_big_kernel(const bf16_t* __res
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + 128 * wm + 16 * mi + c;
             if (m >= M) continue;
-            epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i);
+            epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, N);
         }
     }
 }
@@ -445,7 +448,7 @@ size_t g_ws_bytes = 0;
 
 template <int EPI, int NST>
 int launch_small_nst(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-                     int aux_i, int splits, hipStream_t st) {
+                     int aux_i, int splits, long long lda, long long ldc, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)gemm_bt_kernel<EPI, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -461,16 +464,16 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
         const int m_pad = m_tiles * BM;
         gemm_bt_kernel<EPI, NST><<<tiles * splits, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
                                                                                M, N, K, n_tiles, aux, aux_i, g_ws,
-                                                                               K / splits, tiles, m_pad);
+                                                                               K / splits, tiles, m_pad, lda, ldc);
         int rc = keds_check_launch("gemm_bt_kernel(split-K)");
         if (rc) return rc;
         const int threads = M * (N / 8);
         gemm_splitk_reduce_kernel<EPI><<<(threads + 255) / 256, 256, 0, st>>>(g_ws, splits, m_pad, bias, out, M, N, aux,
-                                                                              aux_i);
+                                                                              aux_i, ldc);
         return keds_check_launch("gemm_splitk_reduce_kernel");
     }
     gemm_bt_kernel<EPI, NST><<<tiles, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0);
+                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0, lda, ldc);
     return keds_check_launch("gemm_bt_kernel");
 }
 
@@ -478,18 +481,19 @@ int g_no_split = 0;   // test hook
 
 template <int EPI>
 int launch_small(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-                 int aux_i, hipStream_t st) {
+                 int aux_i, long long lda, long long ldc, hipStream_t st) {
     const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
     // too few tiles to fill 256 CUs: split K so that ~128+ workgroups stream the weights in parallel
     if (tiles <= 64 && K >= 2048 && !g_no_split && g_ws) {   // at K = 1024 the second launch costs what the split saves
         int splits = 1;
         while (splits < 16 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
         const size_t need = (size_t)splits * ((M + BM - 1) / BM * BM) * N * sizeof(float);
-        if (splits > 1 && need <= g_ws_bytes) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, splits, st);
+        if (splits > 1 && need <= g_ws_bytes)
+            return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, splits, lda, ldc, st);
     }
     // fewer workgroups than 2 per CU: nothing else hides the DMA latency, so use the deep ring
-    if (tiles < 512) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, 1, st);
-    return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, 1, st);
+    if (tiles < 512) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, 1, lda, ldc, st);
+    return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, 1, lda, ldc, st);
 }
 
 namespace pr {
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + 128 * wm + 16 * mi + c;
             if (m >= M) continue;
-            epilogue_store<EPI>(acc[2 * pp][mi] + b0, acc[2 * pp + 1][mi] + b1, out, m, n, N, aux, aux_i);
+            epilogue_store<EPI>(acc[2 * pp][mi] + b0, acc[2 * pp + 1][mi] + b1, out, m, n, N, aux, aux_i, N);
         }
     }
 }
@@ -712,7 +716,7 @@ int g_force_small = 0;   // test hook: route everything through the 128^2 kernel
 
 template <int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-                int aux_i, hipStream_t st) {
+                int aux_i, long long lda, long long ldc, hipStream_t st) {
     KedsProfScope prof(KEDS_PROF_GEMM, st);
     // Large problems: full 256-row tiles go to the 256^2 kernel, the remainder rows (< 256) to the 128^2 one.
     // (ViT-L/14 at B=128: M = 32896 = 128*256 + 128, so 512..2048 big tiles = whole rounds on 256 CUs.)
@@ -720,15 +724,15 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     // with >= 85% of the last round busy; otherwise the 128^2 kernel's finer tiles quantise better
     const long bt = (long)(M / big::TM) * (N / big::TN);
     const long rounds = (bt + 255) / 256;
-    const bool big_ok = !g_force_small && N % big::TN == 0 && K % 64 == 0 && K >= 128 && bt >= 512 &&
+    const bool big_ok = !g_force_small && lda == K && ldc == N && N % big::TN == 0 && K % 64 == 0 && K >= 128 && bt >= 512 &&
                         bt * 100 >= rounds * 256 * 85 && (EPI != KEDS_EPI_PATCH_F32 || M % big::TM == 0);
-    if (!big_ok) return launch_small<EPI>(A, W, bias, out, M, N, K, aux, aux_i, st);
+    if (!big_ok) return launch_small<EPI>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
     const int m_main = M / big::TM * big::TM;
     int rc = launch_big<EPI>(A, W, bias, out, m_main, N, K, aux, aux_i, st);
     if (rc || m_main == M || g_skip_tail) return rc;
     const size_t esz = (EPI == KEDS_EPI_BIAS_RESID_F32 || EPI == KEDS_EPI_BIAS_F32) ? 4 : 2;
     return launch_small<EPI>((const char*)A + (size_t)m_main * K * 2, W, bias, (char*)out + (size_t)m_main * N * esz,
-                             M - m_main, N, K, aux, aux_i, st);
+                             M - m_main, N, K, aux, aux_i, lda, ldc, st);
 }
 
 }  // namespace
@@ -747,25 +751,32 @@ extern "C" int keds_gemm_force_small(int on) {
     return KEDS_OK;
 }
 
-extern "C" int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
-                            int epilogue, const float* aux, int aux_i, void* stream) {
+extern "C" int keds_gemm_bt_ex(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                               int M, int N, int K, int epilogue, const float* aux, int aux_i, void* stream) {
     KEDS_REQUIRE(A && W && out, "keds_gemm_bt: null pointer");
     KEDS_REQUIRE(M > 0 && N > 0 && K > 0, "keds_gemm_bt: empty problem");
     KEDS_REQUIRE(N % BN == 0, "keds_gemm_bt: N=%d must be a multiple of %d", N, BN);
     KEDS_REQUIRE(K % BK == 0, "keds_gemm_bt: K=%d must be a multiple of %d", K, BK);
+    KEDS_REQUIRE(lda >= K && ldc >= N && lda % 8 == 0 && ldc % 8 == 0, "keds_gemm_bt: bad row strides");
+    KEDS_REQUIRE(epilogue != KEDS_EPI_PATCH_F32 || ldc == N, "keds_gemm_bt: EPI_PATCH needs a dense output");
     hipStream_t st = (hipStream_t)stream;
     switch (epilogue) {
-        case KEDS_EPI_BIAS_BF16: return launch_gemm<KEDS_EPI_BIAS_BF16>(A, W, bias, out, M, N, K, aux, aux_i, st);
+        case KEDS_EPI_BIAS_BF16: return launch_gemm<KEDS_EPI_BIAS_BF16>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
         case KEDS_EPI_BIAS_QGELU_BF16:
-            return launch_gemm<KEDS_EPI_BIAS_QGELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, st);
+            return launch_gemm<KEDS_EPI_BIAS_QGELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
         case KEDS_EPI_BIAS_RELU_BF16:
-            return launch_gemm<KEDS_EPI_BIAS_RELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, st);
+            return launch_gemm<KEDS_EPI_BIAS_RELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
         case KEDS_EPI_BIAS_RESID_F32:
-            return launch_gemm<KEDS_EPI_BIAS_RESID_F32>(A, W, bias, out, M, N, K, aux, aux_i, st);
-        case KEDS_EPI_BIAS_F32: return launch_gemm<KEDS_EPI_BIAS_F32>(A, W, bias, out, M, N, K, aux, aux_i, st);
+            return launch_gemm<KEDS_EPI_BIAS_RESID_F32>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
+        case KEDS_EPI_BIAS_F32: return launch_gemm<KEDS_EPI_BIAS_F32>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
         case KEDS_EPI_PATCH_F32:
             KEDS_REQUIRE(aux && aux_i > 0, "keds_gemm_bt: EPI_PATCH needs the positional embedding and G");
-            return launch_gemm<KEDS_EPI_PATCH_F32>(A, W, bias, out, M, N, K, aux, aux_i, st);
+            return launch_gemm<KEDS_EPI_PATCH_F32>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
         default: keds_set_error("keds_gemm_bt: unknown epilogue %d", epilogue); return KEDS_E_ARG;
     }
+}
+
+extern "C" int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
+                            int epilogue, const float* aux, int aux_i, void* stream) {
+    return keds_gemm_bt_ex(A, K, W, bias, out, N, M, N, K, epilogue, aux, aux_i, stream);
 }

@@ -46,6 +46,21 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         const keds_block_params& k = p->blocks[l];
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
         if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
+        if (l == p->layers - 1 && p->last_cls_only) {
+            // After the last block only token 0 of every sample is read (ln_post(x[:,0,:]), model.py:412), so the
+            // attention queries, out-proj, ln_2 and the MLP run on those B rows only (row stride S*w in x / attn).
+            const long long ld = (long long)S * w;
+            if ((rc = keds_attention_ex(qkv, att, B, S, p->heads, p->causal, 1, st))) return rc;
+            if ((rc = keds_gemm_bt_ex(att, ld, k.out_w, k.out_b, x, ld, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
+                return rc;
+            if ((rc = keds_layernorm_impl(x, w, nullptr, S, k.ln2_g, k.ln2_b, t.h, 0, B, w, st))) return rc;
+            if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st)))
+                return rc;
+            if ((rc = keds_gemm_bt_ex(hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr,
+                                      0, st)))
+                return rc;
+            break;
+        }
         if ((rc = keds_attention(qkv, att, B, S, p->heads, p->causal, st))) return rc;
         if ((rc = keds_gemm_bt(att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;

@@ -79,7 +79,7 @@ class VisualTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
 
-def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list) -> _lib.TowerParams:
+def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: bool = False) -> _lib.TowerParams:
     blocks = (_lib.BlockParams * tr.layers)()
     for i, blk in enumerate(tr.resblocks):
         t = dict(
@@ -92,7 +92,7 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list) -> _lib.Tow
             setattr(blocks[i], k, ptr(v))
         keep.append(t)
     keep.append(blocks)
-    return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks)
+    return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks, 1 if cls_only else 0)
 
 
 class _Packed:
@@ -112,7 +112,8 @@ class _Packed:
                  ln_pre_g=_f32(v.ln_pre.weight), ln_pre_b=_f32(v.ln_pre.bias), ln_post_g=_f32(v.ln_post.weight),
                  ln_post_b=_f32(v.ln_post.bias), proj_t=_bf16(v.proj.detach().t()))
         self.keep.append(t)
-        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep), v.input_resolution, P,
+        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep, cls_only=True),
+                                  v.input_resolution, P,
                                   self.kpad, v.output_dim, *[ptr(t[k]) for k in (
                                       "conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
                                       "ln_post_b", "proj_t")])

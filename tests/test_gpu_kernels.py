@@ -68,6 +68,35 @@ def test_gemm_identity_asymmetric():
     assert torch.equal(out.cpu(), w.t().contiguous())
 
 
+def test_gemm_strided_rows_and_query_limited_attention():
+    """keds_gemm_bt_ex (row strides; A rows past M never read) and keds_attention_ex (first q rows only): the pieces of
+    the CLS-row-only last ViT layer."""
+    from keds_amd._lib import check, load, ptr, stream
+    lib = load()
+    B, S, w = 5, 17, 128
+    att = bf16_round(_rand((B * S, w), 61))
+    W = bf16_round(_rand((w, w), 62, std=w ** -0.5))
+    bias = _rand((w,), 63, 0.1)
+    x0 = _rand((B * S, w), 64)
+    a_d = att.cuda().to(torch.bfloat16)                     # exactly B*S rows: no padding available
+    x_d = x0.clone().cuda()
+    _lib.ensure_gemm_workspace(a_d.device)
+    check(lib.keds_gemm_bt_ex(ptr(a_d), S * w, ptr(W.cuda().to(torch.bfloat16)), ptr(bias.cuda()), ptr(x_d), S * w, B, w, w,
+                              _lib.EPI_BIAS_RESID_F32, None, 0, stream()), "keds_gemm_bt_ex")
+    ref = x0.clone()
+    ref[::S] += att[::S] @ W.t() + bias
+    assert rel_l2(x_d, ref) <= 1e-5                         # CLS rows updated, every other row untouched
+    assert torch.equal(x_d.cpu().reshape(B, S, w)[:, 1:], x0.reshape(B, S, w)[:, 1:])
+    heads = 2
+    qkv = bf16_round(_rand((B * S, 3 * heads * 64), 65, std=1.5))
+    full = ops.attention(qkv.cuda().to(torch.bfloat16), B, S, heads, False)
+    out = torch.full((B * S, heads * 64), 7.0, dtype=torch.bfloat16, device="cuda")
+    check(lib.keds_attention_ex(ptr(qkv.cuda().to(torch.bfloat16)), ptr(out), B, S, heads, 0, 1, stream()), "keds_attention_ex")
+    o = out.float().cpu().reshape(B, S, -1)
+    assert torch.equal(o[:, 0], full.float().cpu().reshape(B, S, -1)[:, 0])      # query row 0 identical
+    assert bool((o[:, 1:] == 7.0).all())                                           # other rows not written
+
+
 def test_gemm_patch_epilogue():
     B, G, N, K = 3, 16, 128, 640
     a = bf16_round(_rand((B * G, K), 5))
