@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--db-rows", type=int, default=500000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--prof-all", action="store_true", help="hipEvent pairs around every kernel class (default: only the "
+                    "dominant GEMM class and the scan; the full breakdown costs ~1-2 %% of the step)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -174,7 +176,8 @@ def main():
         step()
     fence()
     _lib.prof_reset()
-    _lib.prof_enable(True)                                     # hipEvent pair around every kernel launch
+    # hipEvent pair around every launch of the dominant kernel class (GEMM) and of the scan, inside the timed region
+    _lib.prof_enable(True, None if args.prof_all else (_lib.PROF_GEMM, _lib.PROF_SCAN))
     t0 = time.perf_counter()
     for _ in range(args.steps):
         Dk, Ik = step()

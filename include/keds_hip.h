@@ -44,7 +44,7 @@ const char* keds_last_error(void);
 #define KEDS_PROF_LN 3
 #define KEDS_PROF_OTHER 4
 #define KEDS_PROF_NCLASS 5
-int keds_prof_enable(int on);                 /* 1: record an event pair around every launch */
+int keds_prof_enable(int on);                 /* 0 off; 1: event pair around every launch; else bit (k+1) = class k */
 int keds_prof_reset(void);
 int keds_prof_read(int klass, double* total_ms, int64_t* launches);  /* synchronises the events */
 

@@ -200,8 +200,15 @@ def ensure_gemm_workspace(device=None) -> None:
         check(load().keds_gemm_set_workspace(buf.data_ptr(), buf.numel()), "keds_gemm_set_workspace")
 
 
-def prof_enable(on: bool) -> None:
-    check(load().keds_prof_enable(1 if on else 0), "keds_prof_enable")
+def prof_enable(on, classes=None) -> None:
+    """on: False/True, or pass `classes` (iterable of PROF_* ids) to record only those kernel classes."""
+    code = 0
+    if classes is not None:
+        for k in classes:
+            code |= 1 << (k + 1)
+    elif on:
+        code = 1
+    check(load().keds_prof_enable(code), "keds_prof_enable")
 
 
 def prof_reset() -> None:

@@ -32,7 +32,7 @@ struct EvPair {
     hipEvent_t a, b;
 };
 struct ProfState {
-    bool on = false;
+    unsigned mask = 0;   // bit k: record events for class k
     std::mutex mu;
     std::vector<EvPair> used[KEDS_PROF_NCLASS];
     std::vector<EvPair> pool;
@@ -45,7 +45,7 @@ ProfState& prof() {
 
 KedsProfScope::KedsProfScope(int k, hipStream_t s) : klass(k), stream(s), slot(nullptr) {
     ProfState& p = prof();
-    if (!p.on) return;
+    if (!(p.mask >> klass & 1u)) return;
     std::lock_guard<std::mutex> g(p.mu);
     EvPair ev;
     if (!p.pool.empty()) {
@@ -67,7 +67,8 @@ KedsProfScope::~KedsProfScope() {
 }
 
 extern "C" int keds_prof_enable(int on) {
-    prof().on = on != 0;
+    // 0: off, 1: every class, otherwise a bit mask with bit (k+1) selecting class k (so 0b110 = GEMM + ATTN)
+    prof().mask = on == 0 ? 0u : (on == 1 ? 0xFFFFFFFFu : ((unsigned)on >> 1));
     return KEDS_OK;
 }
 
