@@ -30,7 +30,7 @@ VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=
 # GEMM work EXECUTED per ViT-L/14 image (SURVEY.md App. A shapes): patch embed + 24 x qkv + 23 x (out, fc, proj) on all
 # 257 tokens + the last block's (out, fc, proj) on the CLS token only (nothing else is read after the last block,
 # model.py:412; the reference computes those 256 unused rows) + read-out.  The reference-equivalent count
-# (all 24 blocks on 257 tokens) is 77.77 GMAC; executed: 75.18 GMAC.
+# (all 24 blocks on 257 tokens) is 77.77 GMAC; executed: 75.35 GMAC.
 _PER_TOKEN_TAIL = 1024 * 1024 + 2 * 1024 * 4096                     # out-proj + fc + proj MACs per token
 GEMM_MAC_PER_IMAGE = (256 * 588 * 1024 + 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL + 1 * _PER_TOKEN_TAIL
                       + 1024 * 768)
