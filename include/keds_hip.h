@@ -72,7 +72,7 @@ size_t keds_index_packed_bytes(int64_t n, int dim);
  * by 32 fp32 bias terms (-0.5*||x||^2 for L2, 0 for IP; -inf for rows >= n). */
 int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream);
 
-/* workspace bytes for keds_index_search with up to `nq` queries */
+/* workspace bytes for keds_index_search_packed with up to `nq` queries */
 size_t keds_index_search_workspace_bytes(int nq, int dim);
 
 /* `.search`: exact top-k (k <= 16) of nq fp32 queries [nq, dim] against the index.
@@ -81,7 +81,7 @@ size_t keds_index_search_workspace_bytes(int nq, int dim);
  *   rows_out (nullable) [nq,k,dim] fp32 : gathered rows db[I]  (src/eval_utils.py:171-172,179-180)
  * Pipeline: bf16 MFMA scan with per-lane exact top-16 lists -> merge to 64 candidates ->
  * exact fp32 re-rank from `db` -> top-k.  `db` is the fp32 matrix given to keds_index_pack. */
-int keds_index_search(const void* packed, const float* db, int64_t n, int dim, int metric,
+int keds_index_search_packed(const void* packed, const float* db, int64_t n, int dim, int metric,
                       const float* queries, int nq, int normalize_q, int k, int64_t id_base,
                       float* D, int64_t* I, float* rows_out,
                       void* workspace, size_t workspace_bytes, void* stream);
@@ -228,13 +228,13 @@ int keds_tower_forward(const keds_tower_params* p, float* x, int B,
 
 /* CLIP.encode_image (model.py:569-575,393-415): image fp32 [B,3,R,R] -> out fp32 [B, embed_dim] */
 size_t keds_vit_workspace_bytes(const keds_vit_params* p, int B);
-int keds_vit_forward(const keds_vit_params* p, const float* image, int B, float* out, int normalize,
+int keds_vit_run(const keds_vit_params* p, const float* image, int B, float* out, int normalize,
                      void* workspace, size_t workspace_bytes, void* stream);
 
 /* CLIP.encode_text / encode_text_img_retrieval (model.py:577-590, 808-851):
  * tokens int32 [B,L]; readout_row int32 [B]; img_tokens nullable fp32 [B,n_tok,d]. */
 size_t keds_text_workspace_bytes(const keds_text_params* p, int B);
-int keds_text_forward(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
+int keds_text_run(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
                       const float* img_tokens, int n_tok, int insert_col, int B, float* out, int normalize,
                       void* workspace, size_t workspace_bytes, void* stream);
 
@@ -277,7 +277,7 @@ size_t keds_knowledge_workspace_bytes(const keds_knowledge_params* p, int B, int
 /* one stream of eval_utils.py:661-672: q [B,dim] fp32, nbr_img / nbr_txt [B,K,dim] fp32 ->
  * tokens_out [B,3,dim] fp32 = [retrieval_fuse(m, I, I), text_condition(m, T, T), m], m = img2text(q),
  * I = img2text(nbr_img), T = img2text(nbr_txt) */
-int keds_knowledge_forward(const keds_knowledge_params* p, const float* q, const float* nbr_img,
+int keds_knowledge_run(const keds_knowledge_params* p, const float* q, const float* nbr_img,
                            const float* nbr_txt, int B, int K, float* tokens_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 

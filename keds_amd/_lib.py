@@ -64,8 +64,42 @@ class KnowledgeParams(C.Structure):
     _fields_ = [("i2t", Im2TextParams), ("fuse", CrossFormerParams), ("cond", CrossFormerParams)]
 
 
-# name -> (restype, argtypes).  Every symbol of include/keds_hip.h is listed; tests check the set.
+class Tensor(C.Structure):
+    """keds_tensor of include/keds_session.h: one named weight (host or device memory)."""
+    _fields_ = [("name", C.c_char_p), ("data", vp), ("dtype", i32), ("ndim", i32), ("shape", i64 * 4)]
+
+
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+COMM_ID_BYTES = 128
+pp = C.POINTER(vp)      # handle out-parameter
+
+# name -> (restype, argtypes).  Every symbol of include/keds_hip.h and include/keds_session.h is listed; tests
+# check the set.
 SIGNATURES = {
+    # ---- keds_session.h (handles) --------------------------------------------------------------
+    "keds_ctx_create": (i32, [i32, pp]),
+    "keds_ctx_destroy": (i32, [vp]),
+    "keds_vit_create": (i32, [vp, C.POINTER(Tensor), i32, i32, pp]),
+    "keds_vit_destroy": (i32, [vp]),
+    "keds_vit_info": (i32, [vp] + [C.POINTER(i32)] * 5),
+    "keds_vit_forward": (i32, [vp, vp, i32, i32, vp, vp]),
+    "keds_text_create": (i32, [vp, C.POINTER(Tensor), i32, i32, pp]),
+    "keds_text_destroy": (i32, [vp]),
+    "keds_text_info": (i32, [vp] + [C.POINTER(i32)] * 5),
+    "keds_text_forward": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, vp]),
+    "keds_knowledge_create": (i32, [vp, C.POINTER(Tensor), i32, C.POINTER(Tensor), i32, C.POINTER(Tensor), i32, pp]),
+    "keds_knowledge_destroy": (i32, [vp]),
+    "keds_knowledge_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
+    "keds_index_create": (i32, [vp, i32, i32, i32, pp]),
+    "keds_index_destroy": (i32, [vp]),
+    "keds_index_add": (i32, [vp, vp, i64]),
+    "keds_index_ntotal": (i64, [vp]),
+    "keds_index_set_base": (i32, [vp, i64]),
+    "keds_index_search": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
+    "keds_comm_unique_id": (i32, [vp]),
+    "keds_comm_init": (i32, [vp, i32, i32, vp]),
+    "keds_index_search_sharded": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    # ---- keds_hip.h (stateless) -----------------------------------------------------------------
     "keds_abi_version": (i32, []),
     "keds_last_error": (C.c_char_p, []),
     "keds_prof_enable": (i32, [i32]),
@@ -75,7 +109,7 @@ SIGNATURES = {
     "keds_index_packed_bytes": (sz, [i64, i32]),
     "keds_index_pack": (i32, [vp, i64, i32, i32, vp, vp]),
     "keds_index_search_workspace_bytes": (sz, [i32, i32]),
-    "keds_index_search": (i32, [vp, vp, i64, i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, sz, vp]),
+    "keds_index_search_packed": (i32, [vp, vp, i64, i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, sz, vp]),
     "keds_topk_merge_parts": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "keds_gather_rows": (i32, [vp, i32, vp, i64, vp, vp]),
     "keds_rank_gallery_workspace_bytes": (sz, [i32, i32]),
@@ -99,15 +133,15 @@ SIGNATURES = {
     "keds_tower_workspace_bytes": (sz, [i32, i32, i32]),
     "keds_tower_forward": (i32, [C.POINTER(TowerParams), vp, i32, vp, sz, vp]),
     "keds_vit_workspace_bytes": (sz, [C.POINTER(VitParams), i32]),
-    "keds_vit_forward": (i32, [C.POINTER(VitParams), vp, i32, vp, i32, vp, sz, vp]),
+    "keds_vit_run": (i32, [C.POINTER(VitParams), vp, i32, vp, i32, vp, sz, vp]),
     "keds_text_workspace_bytes": (sz, [C.POINTER(TextParams), i32]),
-    "keds_text_forward": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "keds_text_run": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "keds_im2text_workspace_bytes": (sz, [C.POINTER(Im2TextParams), i32]),
     "keds_im2text_forward": (i32, [C.POINTER(Im2TextParams), vp, i32, vp, vp, sz, vp]),
     "keds_crossformer_workspace_bytes": (sz, [C.POINTER(CrossFormerParams), i32, i32]),
     "keds_crossformer_forward": (i32, [C.POINTER(CrossFormerParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
     "keds_knowledge_workspace_bytes": (sz, [C.POINTER(KnowledgeParams), i32, i32]),
-    "keds_knowledge_forward": (i32, [C.POINTER(KnowledgeParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
+    "keds_knowledge_run": (i32, [C.POINTER(KnowledgeParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
 }
 
 _lib: Optional[C.CDLL] = None

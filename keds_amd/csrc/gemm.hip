@@ -737,6 +737,8 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
 
 }  // namespace
 
+bool keds_gemm_workspace_registered() { return g_ws != nullptr; }
+
 extern "C" int keds_gemm_set_workspace(void* ptr, size_t bytes) {
     g_ws = (float*)ptr;
     g_ws_bytes = ptr ? bytes : 0;

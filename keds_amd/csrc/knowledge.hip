@@ -1,4 +1,4 @@
-// Dual-stream knowledge injection (one stream per keds_knowledge_forward call):
+// Dual-stream knowledge injection (one stream per keds_knowledge_run call):
 //   m      = IM2TEXT(q)                                   (src/model/model.py:105-123)
 //   I', T' = IM2TEXT(neighbour image rows), IM2TEXT(neighbour text rows)
 //   fused  = CrossFormer_fuse(m, I', I');  cond = CrossFormer_cond(m, T', T')   (model.py:37-101)
@@ -243,21 +243,21 @@ extern "C" size_t keds_knowledge_workspace_bytes(const keds_knowledge_params* p,
     return carve_kn(p, B, K, nullptr).bytes;
 }
 
-extern "C" int keds_knowledge_forward(const keds_knowledge_params* p, const float* q, const float* nbr_img,
+extern "C" int keds_knowledge_run(const keds_knowledge_params* p, const float* q, const float* nbr_img,
                                       const float* nbr_txt, int B, int K, float* tokens_out, void* workspace,
                                       size_t workspace_bytes, void* stream) {
-    KEDS_REQUIRE(p && q && nbr_img && nbr_txt && tokens_out && workspace, "keds_knowledge_forward: null pointer");
-    KEDS_REQUIRE(B > 0 && K >= 1 && K <= 32, "keds_knowledge_forward: K must be in [1,32]");
+    KEDS_REQUIRE(p && q && nbr_img && nbr_txt && tokens_out && workspace, "keds_knowledge_run: null pointer");
+    KEDS_REQUIRE(B > 0 && K >= 1 && K <= 32, "keds_knowledge_run: K must be in [1,32]");
     int rc;
-    if ((rc = check_i2t(&p->i2t, "keds_knowledge_forward"))) return rc;
-    if ((rc = check_xf(&p->fuse, "keds_knowledge_forward"))) return rc;
-    if ((rc = check_xf(&p->cond, "keds_knowledge_forward"))) return rc;
+    if ((rc = check_i2t(&p->i2t, "keds_knowledge_run"))) return rc;
+    if ((rc = check_xf(&p->fuse, "keds_knowledge_run"))) return rc;
+    if ((rc = check_xf(&p->cond, "keds_knowledge_run"))) return rc;
     const int dim = p->i2t.dim_out;
     KEDS_REQUIRE(p->i2t.dim_in == dim && p->fuse.dim == dim && p->cond.dim == dim && p->fuse.heads == p->cond.heads,
-                 "keds_knowledge_forward: IM2TEXT and CrossFormer dims must agree");
+                 "keds_knowledge_run: IM2TEXT and CrossFormer dims must agree");
     KnWs w = carve_kn(p, B, K, workspace);
     if (workspace_bytes < w.bytes) {
-        keds_set_error("keds_knowledge_forward: workspace %zu < %zu", workspace_bytes, w.bytes);
+        keds_set_error("keds_knowledge_run: workspace %zu < %zu", workspace_bytes, w.bytes);
         return KEDS_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;

@@ -742,18 +742,18 @@ extern "C" size_t keds_index_search_workspace_bytes(int nq, int dim) {
     return carve(nullptr, nq, dim).bytes;
 }
 
-extern "C" int keds_index_search(const void* packed, const float* db, int64_t n, int dim, int metric,
+extern "C" int keds_index_search_packed(const void* packed, const float* db, int64_t n, int dim, int metric,
                                  const float* queries, int nq, int normalize_q, int k, int64_t id_base, float* D,
                                  int64_t* I, float* rows_out, void* workspace, size_t workspace_bytes,
                                  void* stream) {
-    KEDS_REQUIRE(packed && db && queries && D && I && workspace, "keds_index_search: null pointer");
-    KEDS_REQUIRE(dim_supported(dim), "keds_index_search: dim %d unsupported", dim);
-    KEDS_REQUIRE(n > 0 && nq > 0, "keds_index_search: empty database or query set");
-    KEDS_REQUIRE(k >= 1 && k <= LISTK, "keds_index_search: k must be in [1,%d] (got %d)", LISTK, k);
-    KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "keds_index_search: bad metric");
+    KEDS_REQUIRE(packed && db && queries && D && I && workspace, "keds_index_search_packed: null pointer");
+    KEDS_REQUIRE(dim_supported(dim), "keds_index_search_packed: dim %d unsupported", dim);
+    KEDS_REQUIRE(n > 0 && nq > 0, "keds_index_search_packed: empty database or query set");
+    KEDS_REQUIRE(k >= 1 && k <= LISTK, "keds_index_search_packed: k must be in [1,%d] (got %d)", LISTK, k);
+    KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "keds_index_search_packed: bad metric");
     SearchWs w = carve(workspace, nq, dim);
     if (workspace_bytes < w.bytes) {
-        keds_set_error("keds_index_search: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+        keds_set_error("keds_index_search_packed: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
         return KEDS_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;

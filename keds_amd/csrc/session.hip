@@ -1,0 +1,771 @@
+// Handle-based C ABI (include/keds_session.h): the library owns packed weights, the database,
+// workspaces and the RCCL communicator; every forward calls the stateless entry points of
+// keds_hip.h, so results are bit-identical to the torch-hosted path.  Architecture inference
+// follows build_model (src/model/model.py:951-991): everything is read off the tensor shapes.
+#include "keds_common.h"
+#include "../../include/keds_session.h"
+#include <dlfcn.h>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+bool keds_gemm_workspace_registered();   // gemm.hip
+
+#define HIP_TRY(call, what)                                                    \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) {                                                \
+            keds_set_error("%s: %s", what, hipGetErrorString(e_));             \
+            return KEDS_E_LAUNCH;                                              \
+        }                                                                      \
+    } while (0)
+
+namespace {
+
+// dst[r, c] = src[r*rs + c*cs] for c < cols, 0 for cols <= c < dcols   (cast / transpose / zero-pad in one pass)
+template <typename DST>
+__global__ void pack2d_kernel(const void* __restrict__ src, int sdt, long long rs, long long cs, int rows, int cols,
+                              int dcols, DST* __restrict__ dst) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)rows * dcols) return;
+    const int r = (int)(i / dcols), c = (int)(i % dcols);
+    float v = 0.f;
+    if (c < cols) {
+        const long long s = r * rs + c * cs;
+        if (sdt == KEDS_F32) v = ((const float*)src)[s];
+        else if (sdt == KEDS_BF16) v = bf16_bits_to_f32(((const unsigned short*)src)[s]);
+        else v = (float)((const _Float16*)src)[s];
+    }
+    dst[i] = (DST)v;
+}
+
+size_t dtype_size(int dt) { return dt == KEDS_F32 ? 4 : 2; }
+
+// device allocations owned by one handle
+struct Arena {
+    std::vector<void*> blocks;
+    void* alloc(size_t bytes) {
+        void* p = nullptr;
+        if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+        blocks.push_back(p);
+        return p;
+    }
+    ~Arena() {
+        for (void* p : blocks) (void)hipFree(p);
+    }
+};
+
+struct GrowBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int reserve(size_t need, hipStream_t st, const char* what) {
+        if (need <= bytes) return KEDS_OK;
+        if (p) {
+            HIP_TRY(hipStreamSynchronize(st), what);
+            HIP_TRY(hipFree(p), what);
+            p = nullptr;
+            bytes = 0;
+        }
+        HIP_TRY(hipMalloc(&p, need), what);
+        bytes = need;
+        return KEDS_OK;
+    }
+    ~GrowBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+struct Weights {
+    std::map<std::string, const keds_tensor*> by_name;
+    Weights(const keds_tensor* t, int n) {
+        for (int i = 0; i < n; ++i)
+            if (t[i].name) by_name[t[i].name] = &t[i];
+    }
+    const keds_tensor* find(const std::string& k) const {
+        auto it = by_name.find(k);
+        return it == by_name.end() ? nullptr : it->second;
+    }
+    int count_layers(const std::string& prefix, const std::string& suffix) const {
+        int n = 0;
+        while (find(prefix + std::to_string(n) + suffix)) ++n;
+        return n;
+    }
+};
+
+int64_t numel(const keds_tensor* t) {
+    int64_t n = 1;
+    for (int i = 0; i < t->ndim; ++i) n *= t->shape[i];
+    return n;
+}
+
+// Upload (host or device source) and convert one tensor viewed as [rows, cols] with element strides (rs, cs)
+// into a dense [rows, dcols] device matrix of DST.  Synchronous: load-time only.
+template <typename DST>
+int pack_tensor(Arena& mem, const keds_tensor* t, int rows, int cols, long long rs, long long cs, int dcols, DST** out,
+                const char* what) {
+    KEDS_REQUIRE(t->dtype == KEDS_F32 || t->dtype == KEDS_BF16 || t->dtype == KEDS_F16, "%s: %s has an unknown dtype",
+                 what, t->name);
+    const size_t raw = (size_t)numel(t) * dtype_size(t->dtype);
+    void* stage = nullptr;
+    HIP_TRY(hipMalloc(&stage, raw ? raw : 16), what);
+    hipError_t e = hipMemcpy(stage, t->data, raw, hipMemcpyDefault);
+    if (e != hipSuccess) {
+        (void)hipFree(stage);
+        keds_set_error("%s: copying %s: %s", what, t->name, hipGetErrorString(e));
+        return KEDS_E_LAUNCH;
+    }
+    DST* dst = (DST*)mem.alloc((size_t)rows * dcols * sizeof(DST));
+    if (!dst) {
+        (void)hipFree(stage);
+        keds_set_error("%s: out of device memory for %s", what, t->name);
+        return KEDS_E_LAUNCH;
+    }
+    const long long total = (long long)rows * dcols;
+    pack2d_kernel<DST><<<(unsigned)((total + 255) / 256), 256, 0, 0>>>(stage, t->dtype, rs, cs, rows, cols, dcols, dst);
+    e = hipDeviceSynchronize();
+    (void)hipFree(stage);
+    if (e != hipSuccess) {
+        keds_set_error("%s: packing %s: %s", what, t->name, hipGetErrorString(e));
+        return KEDS_E_LAUNCH;
+    }
+    *out = dst;
+    return KEDS_OK;
+}
+
+struct Loader {
+    const Weights& w;
+    Arena& mem;
+    const char* what;
+    int need(const std::string& key, int ndim, const keds_tensor** out) const {
+        const keds_tensor* t = w.find(key);
+        KEDS_REQUIRE(t != nullptr, "%s: missing weight '%s'", what, key.c_str());
+        KEDS_REQUIRE(t->ndim == ndim && t->data, "%s: '%s' must be a %d-d tensor", what, key.c_str(), ndim);
+        *out = t;
+        return KEDS_OK;
+    }
+    // [n] fp32 vector
+    int vec(const std::string& key, int64_t n, const float** out) const {
+        const keds_tensor* t;
+        int rc = need(key, 1, &t);
+        if (rc) return rc;
+        KEDS_REQUIRE(t->shape[0] == n, "%s: '%s' has %lld elements, expected %lld", what, key.c_str(),
+                     (long long)t->shape[0], (long long)n);
+        float* d;
+        if ((rc = pack_tensor<float>(mem, t, 1, (int)n, 0, 1, (int)n, &d, what))) return rc;
+        *out = d;
+        return KEDS_OK;
+    }
+    // [rows, cols] matrix as stored -> bf16 (GEMM operand, K contiguous) or fp32
+    template <typename DST>
+    int mat(const std::string& key, int64_t rows, int64_t cols, const DST** out, bool transpose = false) const {
+        const keds_tensor* t;
+        int rc = need(key, 2, &t);
+        if (rc) return rc;
+        const int64_t sr = transpose ? cols : rows, sc = transpose ? rows : cols;
+        KEDS_REQUIRE(t->shape[0] == sr && t->shape[1] == sc, "%s: '%s' is [%lld,%lld], expected [%lld,%lld]", what,
+                     key.c_str(), (long long)t->shape[0], (long long)t->shape[1], (long long)sr, (long long)sc);
+        DST* d;
+        if (transpose) rc = pack_tensor<DST>(mem, t, (int)rows, (int)cols, 1, rows, (int)cols, &d, what);
+        else rc = pack_tensor<DST>(mem, t, (int)rows, (int)cols, cols, 1, (int)cols, &d, what);
+        if (rc) return rc;
+        *out = d;
+        return KEDS_OK;
+    }
+};
+
+// resblocks of one tower (model.py:305-326): keys <prefix>transformer.resblocks.<i>.*
+int load_blocks(const Loader& L, const std::string& prefix, int width, int layers, std::vector<keds_block_params>& blocks) {
+    blocks.assign(layers, keds_block_params{});
+    for (int i = 0; i < layers; ++i) {
+        const std::string b = prefix + "transformer.resblocks." + std::to_string(i) + ".";
+        keds_block_params& p = blocks[i];
+        int rc;
+        const bf16_t* m;
+        if ((rc = L.vec(b + "ln_1.weight", width, &p.ln1_g)) || (rc = L.vec(b + "ln_1.bias", width, &p.ln1_b)) ||
+            (rc = L.vec(b + "ln_2.weight", width, &p.ln2_g)) || (rc = L.vec(b + "ln_2.bias", width, &p.ln2_b)) ||
+            (rc = L.vec(b + "attn.in_proj_bias", 3 * width, &p.qkv_b)) ||
+            (rc = L.vec(b + "attn.out_proj.bias", width, &p.out_b)) ||
+            (rc = L.vec(b + "mlp.c_fc.bias", 4 * width, &p.fc_b)) || (rc = L.vec(b + "mlp.c_proj.bias", width, &p.proj_b)))
+            return rc;
+        if ((rc = L.mat<bf16_t>(b + "attn.in_proj_weight", 3 * width, width, &m))) return rc;
+        p.qkv_w = m;
+        if ((rc = L.mat<bf16_t>(b + "attn.out_proj.weight", width, width, &m))) return rc;
+        p.out_w = m;
+        if ((rc = L.mat<bf16_t>(b + "mlp.c_fc.weight", 4 * width, width, &m))) return rc;
+        p.fc_w = m;
+        if ((rc = L.mat<bf16_t>(b + "mlp.c_proj.weight", width, 4 * width, &m))) return rc;
+        p.proj_w = m;
+    }
+    return KEDS_OK;
+}
+
+// ---- RCCL, bound at run time so the library has no link-time dependency on it ------------------
+struct CommId {
+    char bytes[KEDS_COMM_ID_BYTES];
+};
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(CommId*) = nullptr;
+    int (*CommInitRank)(void**, int, CommId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load() {
+    if (g_rccl.lib) return KEDS_OK;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names)          // an already loaded copy (e.g. the host framework's) wins
+        if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!h)
+        for (const char* n : names)
+            if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    KEDS_REQUIRE(h != nullptr, "keds_comm: cannot load librccl (%s)", dlerror());
+    Rccl r;
+    r.lib = h;
+    r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+    r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
+    KEDS_REQUIRE(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather, "keds_comm: librccl lacks a symbol");
+    g_rccl = r;
+    return KEDS_OK;
+}
+
+int rccl_check(int rc, const char* what) {
+    if (rc == 0) return KEDS_OK;
+    keds_set_error("%s: RCCL error %d (%s)", what, rc, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?");
+    return KEDS_E_LAUNCH;
+}
+
+}  // namespace
+
+// ---- handles ----------------------------------------------------------------------------------------
+struct keds_ctx {
+    int device = 0;
+    void* splitk = nullptr;       // registered with keds_gemm_set_workspace when nobody else has
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+struct keds_vit {
+    keds_ctx* ctx;
+    Arena mem;
+    std::vector<keds_block_params> blocks;
+    keds_vit_params p;
+    GrowBuf ws, img;
+};
+
+struct keds_text {
+    keds_ctx* ctx;
+    Arena mem;
+    std::vector<keds_block_params> blocks;
+    keds_text_params p;
+    GrowBuf ws, tok;
+};
+
+struct keds_knowledge {
+    keds_ctx* ctx;
+    Arena mem;
+    std::vector<keds_cross_layer_params> fuse, cond;
+    keds_knowledge_params p;
+    GrowBuf ws;
+};
+
+struct keds_index {
+    keds_ctx* ctx;
+    int dim, metric;
+    int64_t n = 0, row0 = 0;
+    float* rows = nullptr;
+    void* packed = nullptr;
+    GrowBuf ws, xws;
+};
+
+static int use_device(const keds_ctx* ctx, const char* what) {
+    KEDS_REQUIRE(ctx != nullptr, "%s: null context", what);
+    HIP_TRY(hipSetDevice(ctx->device), what);
+    return KEDS_OK;
+}
+
+extern "C" int keds_ctx_create(int device, keds_ctx** out) {
+    KEDS_REQUIRE(out != nullptr, "keds_ctx_create: null out");
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count), "keds_ctx_create");
+    KEDS_REQUIRE(device >= 0 && device < count, "keds_ctx_create: device %d of %d", device, count);
+    HIP_TRY(hipSetDevice(device), "keds_ctx_create");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device), "keds_ctx_create");
+    KEDS_REQUIRE(strncmp(prop.gcnArchName, "gfx950", 6) == 0, "keds_ctx_create: device %d is %s, this library is gfx950 only",
+                 device, prop.gcnArchName);
+    keds_ctx* c = new keds_ctx();
+    c->device = device;
+    if (!keds_gemm_workspace_registered()) {
+        const size_t bytes = 32u << 20;
+        if (hipMalloc(&c->splitk, bytes) == hipSuccess) keds_gemm_set_workspace(c->splitk, bytes);
+    }
+    *out = c;
+    return KEDS_OK;
+}
+
+extern "C" int keds_ctx_destroy(keds_ctx* ctx) {
+    if (!ctx) return KEDS_OK;
+    if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+    if (ctx->splitk) {
+        keds_gemm_set_workspace(nullptr, 0);
+        (void)hipFree(ctx->splitk);
+    }
+    delete ctx;
+    return KEDS_OK;
+}
+
+// ---- image tower ------------------------------------------------------------------------------------
+extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_vit** out) {
+    const char* what = "keds_vit_create";
+    KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
+    KEDS_REQUIRE(compute == KEDS_BF16, "%s: compute dtype must be KEDS_BF16 (bf16 operands, fp32 accumulate)", what);
+    int rc = use_device(ctx, what);
+    if (rc) return rc;
+    Weights W(weights, n);
+    const keds_tensor *conv, *pos, *proj;
+    keds_vit* v = new keds_vit();
+    v->ctx = ctx;
+    Loader L{W, v->mem, what};
+    auto fail = [&](int code) {
+        delete v;
+        return code;
+    };
+    if ((rc = L.need("visual.conv1.weight", 4, &conv)) || (rc = L.need("visual.positional_embedding", 2, &pos)) ||
+        (rc = L.need("visual.proj", 2, &proj)))
+        return fail(rc);
+    // model.py:955-961: width = conv1.shape[0], patch = conv1.shape[-1], grid = round(sqrt(pos.shape[0]-1))
+    const int width = (int)conv->shape[0], patch = (int)conv->shape[3];
+    const int grid = (int)std::lround(std::sqrt((double)(pos->shape[0] - 1)));
+    const int layers = W.count_layers("visual.transformer.resblocks.", ".attn.in_proj_weight");
+    const int embed = (int)proj->shape[1];
+    if (conv->shape[1] != 3 || conv->shape[2] != patch || grid * grid + 1 != pos->shape[0] || pos->shape[1] != width ||
+        proj->shape[0] != width || layers < 1 || width % 128 != 0) {
+        keds_set_error("%s: inconsistent visual.* shapes (width %d, patch %d, grid %d, layers %d)", what, width, patch, grid,
+                       layers);
+        return fail(KEDS_E_ARG);
+    }
+    if ((rc = load_blocks(L, "visual.", width, layers, v->blocks))) return fail(rc);
+    keds_vit_params& p = v->p;
+    memset(&p, 0, sizeof(p));
+    p.tower.width = width;
+    p.tower.layers = layers;
+    p.tower.heads = width / 64;
+    p.tower.seq = grid * grid + 1;
+    p.tower.causal = 0;
+    p.tower.blocks = v->blocks.data();
+    p.tower.last_cls_only = 1;
+    p.resolution = grid * patch;
+    p.patch = patch;
+    const int kreal = 3 * patch * patch;
+    p.kpad = (kreal + 63) / 64 * 64;
+    p.embed_dim = embed;
+    bf16_t* conv_w;   // [width, 3*P*P] zero padded to kpad columns (im2col order == the conv weight's own order)
+    if ((rc = pack_tensor<bf16_t>(v->mem, conv, width, kreal, kreal, 1, p.kpad, &conv_w, what))) return fail(rc);
+    p.conv_w = conv_w;
+    const bf16_t* proj_t;
+    if ((rc = L.vec("visual.class_embedding", width, &p.class_emb)) ||
+        (rc = L.mat<float>("visual.positional_embedding", p.tower.seq, width, &p.pos_emb)) ||
+        (rc = L.vec("visual.ln_pre.weight", width, &p.ln_pre_g)) || (rc = L.vec("visual.ln_pre.bias", width, &p.ln_pre_b)) ||
+        (rc = L.vec("visual.ln_post.weight", width, &p.ln_post_g)) ||
+        (rc = L.vec("visual.ln_post.bias", width, &p.ln_post_b)) ||
+        (rc = L.mat<bf16_t>("visual.proj", embed, width, &proj_t, /*transpose=*/true)))
+        return fail(rc);
+    p.proj_t = proj_t;
+    *out = v;
+    return KEDS_OK;
+}
+
+extern "C" int keds_vit_destroy(keds_vit* vit) {
+    if (vit) {
+        (void)hipSetDevice(vit->ctx->device);
+        delete vit;
+    }
+    return KEDS_OK;
+}
+
+extern "C" int keds_vit_info(const keds_vit* vit, int* width, int* layers, int* resolution, int* patch, int* embed_dim) {
+    KEDS_REQUIRE(vit != nullptr, "keds_vit_info: null handle");
+    if (width) *width = vit->p.tower.width;
+    if (layers) *layers = vit->p.tower.layers;
+    if (resolution) *resolution = vit->p.resolution;
+    if (patch) *patch = vit->p.patch;
+    if (embed_dim) *embed_dim = vit->p.embed_dim;
+    return KEDS_OK;
+}
+
+extern "C" int keds_vit_forward(keds_vit* vit, const void* image, int img_dtype, int B, void* out, void* stream) {
+    const char* what = "keds_vit_forward";
+    KEDS_REQUIRE(vit && image && out && B > 0, "%s: bad argument", what);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    const float* img = (const float*)image;
+    if (img_dtype != KEDS_F32) {
+        KEDS_REQUIRE(img_dtype == KEDS_BF16 || img_dtype == KEDS_F16, "%s: unknown image dtype", what);
+        const long long count = (long long)B * 3 * vit->p.resolution * vit->p.resolution;
+        if ((rc = vit->img.reserve((size_t)count * 4, st, what))) return rc;
+        pack2d_kernel<float><<<(unsigned)((count + 255) / 256), 256, 0, st>>>(image, img_dtype, 0, 1, 1, (int)count,
+                                                                                (int)count, (float*)vit->img.p);
+        if ((rc = keds_check_launch(what))) return rc;
+        img = (const float*)vit->img.p;
+    }
+    const size_t need = keds_vit_workspace_bytes(&vit->p, B);
+    if ((rc = vit->ws.reserve(need, st, what))) return rc;
+    return keds_vit_run(&vit->p, img, B, (float*)out, 0, vit->ws.p, vit->ws.bytes, stream);
+}
+
+// ---- text tower -------------------------------------------------------------------------------------
+extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_text** out) {
+    const char* what = "keds_text_create";
+    KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
+    KEDS_REQUIRE(compute == KEDS_BF16, "%s: compute dtype must be KEDS_BF16", what);
+    int rc = use_device(ctx, what);
+    if (rc) return rc;
+    Weights W(weights, n);
+    keds_text* t = new keds_text();
+    t->ctx = ctx;
+    Loader L{W, t->mem, what};
+    auto fail = [&](int code) {
+        delete t;
+        return code;
+    };
+    const keds_tensor *emb, *pos, *proj;
+    if ((rc = L.need("token_embedding.weight", 2, &emb)) || (rc = L.need("positional_embedding", 2, &pos)) ||
+        (rc = L.need("text_projection", 2, &proj)))
+        return fail(rc);
+    // model.py:977-982: embed_dim = text_projection.shape[1], context = positional_embedding.shape[0],
+    // vocab = token_embedding.shape[0], width = ln_final.shape[0], heads = width // 64
+    const int vocab = (int)emb->shape[0], width = (int)emb->shape[1], context = (int)pos->shape[0];
+    const int embed = (int)proj->shape[1];
+    const int layers = W.count_layers("transformer.resblocks.", ".attn.in_proj_weight");
+    if (pos->shape[1] != width || proj->shape[0] != width || layers < 1 || width % 128 != 0) {
+        keds_set_error("%s: inconsistent text tower shapes (width %d, context %d, layers %d)", what, width, context, layers);
+        return fail(KEDS_E_ARG);
+    }
+    if ((rc = load_blocks(L, "", width, layers, t->blocks))) return fail(rc);
+    keds_text_params& p = t->p;
+    memset(&p, 0, sizeof(p));
+    p.tower.width = width;
+    p.tower.layers = layers;
+    p.tower.heads = width / 64;
+    p.tower.seq = context;
+    p.tower.causal = 1;
+    p.tower.blocks = t->blocks.data();
+    p.tower.last_cls_only = 0;
+    p.vocab = vocab;
+    p.embed_dim = embed;
+    const bf16_t* proj_t;
+    if ((rc = L.mat<float>("token_embedding.weight", vocab, width, &p.token_emb)) ||
+        (rc = L.mat<float>("positional_embedding", context, width, &p.pos_emb)) ||
+        (rc = L.vec("ln_final.weight", width, &p.ln_final_g)) || (rc = L.vec("ln_final.bias", width, &p.ln_final_b)) ||
+        (rc = L.mat<bf16_t>("text_projection", embed, width, &proj_t, /*transpose=*/true)))
+        return fail(rc);
+    p.proj_t = proj_t;
+    *out = t;
+    return KEDS_OK;
+}
+
+extern "C" int keds_text_destroy(keds_text* txt) {
+    if (txt) {
+        (void)hipSetDevice(txt->ctx->device);
+        delete txt;
+    }
+    return KEDS_OK;
+}
+
+extern "C" int keds_text_info(const keds_text* txt, int* width, int* layers, int* context, int* vocab, int* embed_dim) {
+    KEDS_REQUIRE(txt != nullptr, "keds_text_info: null handle");
+    if (width) *width = txt->p.tower.width;
+    if (layers) *layers = txt->p.tower.layers;
+    if (context) *context = txt->p.tower.seq;
+    if (vocab) *vocab = txt->p.vocab;
+    if (embed_dim) *embed_dim = txt->p.embed_dim;
+    return KEDS_OK;
+}
+
+extern "C" int keds_text_forward(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
+                                 int insert_idx, const int32_t* readout_idx, int B, void* out, void* stream) {
+    const char* what = "keds_text_forward";
+    KEDS_REQUIRE(txt && tokens && readout_idx && out && B > 0, "%s: bad argument", what);
+    KEDS_REQUIRE((img_tokens == nullptr) == (n_img_tok == 0), "%s: img_tokens and n_img_tok disagree", what);
+    KEDS_REQUIRE(n_img_tok == 0 || n_img_tok == 2 || n_img_tok == 3, "%s: 2 or 3 pseudo tokens (model.py:831-834)", what);
+    KEDS_REQUIRE(n_img_tok == 0 || (insert_idx >= 0 && insert_idx + n_img_tok <= txt->p.tower.seq),
+                 "%s: insert_idx out of range", what);
+    int rc;
+    const size_t need = keds_text_workspace_bytes(&txt->p, B);
+    if ((rc = txt->ws.reserve(need, (hipStream_t)stream, what))) return rc;
+    return keds_text_run(&txt->p, tokens, readout_idx, (const float*)img_tokens, n_img_tok, insert_idx, B, (float*)out, 0,
+                         txt->ws.p, txt->ws.bytes, stream);
+}
+
+// ---- knowledge injection ------------------------------------------------------------------------------
+namespace {
+int load_crossformer(const Loader& L, const Weights& W, std::vector<keds_cross_layer_params>& layers,
+                     keds_crossformer_params* out) {
+    const int n = W.count_layers("cross_layers.", ".to_q.weight");
+    KEDS_REQUIRE(n >= 1, "%s: no cross_layers.*.to_q.weight", L.what);
+    const keds_tensor* q0;
+    int rc = L.need("cross_layers.0.to_q.weight", 2, &q0);
+    if (rc) return rc;
+    const int inner = (int)q0->shape[0], dim = (int)q0->shape[1];     // model.py:41-47: inner = heads * dim_head(64)
+    KEDS_REQUIRE(inner % 64 == 0, "%s: inner dim %d is not heads x 64", L.what, inner);
+    layers.assign(n, keds_cross_layer_params{});
+    for (int i = 0; i < n; ++i) {
+        const std::string b = "cross_layers." + std::to_string(i) + ".";
+        keds_cross_layer_params& c = layers[i];
+        const bf16_t* m;
+        if ((rc = L.mat<bf16_t>(b + "to_q.weight", inner, dim, &m))) return rc;
+        c.wq = m;
+        if ((rc = L.mat<bf16_t>(b + "to_k.weight", inner, dim, &m))) return rc;
+        c.wk = m;
+        if ((rc = L.mat<bf16_t>(b + "to_v.weight", inner, dim, &m))) return rc;
+        c.wv = m;
+        if ((rc = L.mat<bf16_t>(b + "to_out.0.weight", dim, inner, &m))) return rc;
+        c.wo = m;
+        if ((rc = L.vec(b + "to_q.bias", inner, &c.bq)) || (rc = L.vec(b + "to_k.bias", inner, &c.bk)) ||
+            (rc = L.vec(b + "to_v.bias", inner, &c.bv)) || (rc = L.vec(b + "to_out.0.bias", dim, &c.bo)))
+            return rc;
+    }
+    out->dim = dim;
+    out->heads = inner / 64;
+    out->layers = n;
+    out->layer = layers.data();
+    return KEDS_OK;
+}
+}  // namespace
+
+extern "C" int keds_knowledge_create(keds_ctx* ctx, const keds_tensor* im2text, int n_im2text, const keds_tensor* fuse,
+                                     int n_fuse, const keds_tensor* cond, int n_cond, keds_knowledge** out) {
+    const char* what = "keds_knowledge_create";
+    KEDS_REQUIRE(im2text && fuse && cond && n_im2text > 0 && n_fuse > 0 && n_cond > 0 && out, "%s: bad argument", what);
+    int rc = use_device(ctx, what);
+    if (rc) return rc;
+    keds_knowledge* k = new keds_knowledge();
+    k->ctx = ctx;
+    memset(&k->p, 0, sizeof(k->p));
+    auto fail = [&](int code) {
+        delete k;
+        return code;
+    };
+    {   // IM2TEXT (model.py:105-123): layers.{i}.0 = Linear, fc_out
+        Weights W(im2text, n_im2text);
+        Loader L{W, k->mem, what};
+        const int nl = W.count_layers("layers.", ".0.weight");
+        const keds_tensor *w0, *wo;
+        if (nl < 1 || nl > 4) {
+            keds_set_error("%s: IM2TEXT with %d hidden layers (1..4 supported)", what, nl);
+            return fail(KEDS_E_ARG);
+        }
+        if ((rc = L.need("layers.0.0.weight", 2, &w0)) || (rc = L.need("fc_out.weight", 2, &wo))) return fail(rc);
+        keds_im2text_params& p = k->p.i2t;
+        p.dim_in = (int)w0->shape[1];
+        p.middle = (int)w0->shape[0];
+        p.dim_out = (int)wo->shape[0];
+        p.n_layer = nl;
+        for (int i = 0; i < nl; ++i) {
+            const std::string b = "layers." + std::to_string(i) + ".0.";
+            const bf16_t* m;
+            if ((rc = L.mat<bf16_t>(b + "weight", p.middle, i == 0 ? p.dim_in : p.middle, &m)) ||
+                (rc = L.vec(b + "bias", p.middle, &p.b[i])))
+                return fail(rc);
+            p.w[i] = m;
+        }
+        const bf16_t* m;
+        if ((rc = L.mat<bf16_t>("fc_out.weight", p.dim_out, p.middle, &m)) || (rc = L.vec("fc_out.bias", p.dim_out, &p.out_b)))
+            return fail(rc);
+        p.out_w = m;
+    }
+    {
+        Weights W(fuse, n_fuse);
+        Loader L{W, k->mem, what};
+        if ((rc = load_crossformer(L, W, k->fuse, &k->p.fuse))) return fail(rc);
+    }
+    {
+        Weights W(cond, n_cond);
+        Loader L{W, k->mem, what};
+        if ((rc = load_crossformer(L, W, k->cond, &k->p.cond))) return fail(rc);
+    }
+    *out = k;
+    return KEDS_OK;
+}
+
+extern "C" int keds_knowledge_destroy(keds_knowledge* kn) {
+    if (kn) {
+        (void)hipSetDevice(kn->ctx->device);
+        delete kn;
+    }
+    return KEDS_OK;
+}
+
+extern "C" int keds_knowledge_forward(keds_knowledge* kn, const float* q, const float* nbr_img, const float* nbr_txt, int B,
+                                      int K, void* tokens_out, void* stream) {
+    const char* what = "keds_knowledge_forward";
+    KEDS_REQUIRE(kn && q && nbr_img && nbr_txt && tokens_out && B > 0 && K > 0, "%s: bad argument", what);
+    int rc;
+    const size_t need = keds_knowledge_workspace_bytes(&kn->p, B, K);
+    KEDS_REQUIRE(need > 0, "%s: unsupported shape (B %d, K %d)", what, B, K);
+    if ((rc = kn->ws.reserve(need, (hipStream_t)stream, what))) return rc;
+    return keds_knowledge_run(&kn->p, q, nbr_img, nbr_txt, B, K, (float*)tokens_out, kn->ws.p, kn->ws.bytes, stream);
+}
+
+// ---- index ----------------------------------------------------------------------------------------------
+extern "C" int keds_index_create(keds_ctx* ctx, int dim, int metric, int storage, keds_index** out) {
+    const char* what = "keds_index_create";
+    KEDS_REQUIRE(out != nullptr, "%s: null out", what);
+    KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "%s: unknown metric", what);
+    KEDS_REQUIRE(storage == KEDS_BF16, "%s: the scan image is bf16 (KEDS_BF16)", what);
+    KEDS_REQUIRE(keds_index_packed_bytes(32, dim) > 0, "%s: unsupported dimension %d", what, dim);
+    int rc = use_device(ctx, what);
+    if (rc) return rc;
+    keds_index* idx = new keds_index();
+    idx->ctx = ctx;
+    idx->dim = dim;
+    idx->metric = metric;
+    *out = idx;
+    return KEDS_OK;
+}
+
+extern "C" int keds_index_destroy(keds_index* idx) {
+    if (idx) {
+        (void)hipSetDevice(idx->ctx->device);
+        if (idx->rows) (void)hipFree(idx->rows);
+        if (idx->packed) (void)hipFree(idx->packed);
+        delete idx;
+    }
+    return KEDS_OK;
+}
+
+extern "C" int64_t keds_index_ntotal(const keds_index* idx) { return idx ? idx->n : -1; }
+
+extern "C" int keds_index_set_base(keds_index* idx, int64_t row0) {
+    KEDS_REQUIRE(idx && row0 >= 0, "keds_index_set_base: bad argument");
+    idx->row0 = row0;
+    return KEDS_OK;
+}
+
+extern "C" int keds_index_add(keds_index* idx, const float* rows, int64_t n) {
+    const char* what = "keds_index_add";
+    KEDS_REQUIRE(idx && rows && n > 0, "%s: bad argument", what);
+    int rc = use_device(idx->ctx, what);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize(), what);          // searches in flight still read the old buffers
+    const int64_t total = idx->n + n;
+    const size_t row_bytes = (size_t)idx->dim * sizeof(float);
+    float* grown = nullptr;
+    HIP_TRY(hipMalloc((void**)&grown, (size_t)total * row_bytes), what);
+    hipError_t e = hipSuccess;
+    if (idx->n) e = hipMemcpy(grown, idx->rows, (size_t)idx->n * row_bytes, hipMemcpyDeviceToDevice);
+    if (e == hipSuccess) e = hipMemcpy(grown + (size_t)idx->n * idx->dim, rows, (size_t)n * row_bytes, hipMemcpyDefault);
+    void* packed = nullptr;
+    if (e == hipSuccess) e = hipMalloc(&packed, keds_index_packed_bytes(total, idx->dim));
+    if (e != hipSuccess) {
+        (void)hipFree(grown);
+        keds_set_error("%s: %s", what, hipGetErrorString(e));
+        return KEDS_E_LAUNCH;
+    }
+    rc = keds_index_pack(grown, total, idx->dim, idx->metric, packed, nullptr);
+    if (rc == KEDS_OK && hipDeviceSynchronize() != hipSuccess) {
+        keds_set_error("%s: packing failed", what);
+        rc = KEDS_E_LAUNCH;
+    }
+    if (rc) {
+        (void)hipFree(grown);
+        (void)hipFree(packed);
+        return rc;
+    }
+    if (idx->rows) (void)hipFree(idx->rows);
+    if (idx->packed) (void)hipFree(idx->packed);
+    idx->rows = grown;
+    idx->packed = packed;
+    idx->n = total;
+    return KEDS_OK;
+}
+
+static int index_search_local(keds_index* idx, const float* q, int nq, int k, float* D, int64_t* I, float* rows_out,
+                              hipStream_t st, const char* what) {
+    KEDS_REQUIRE(idx->n > 0, "%s: the index is empty", what);
+    const size_t need = keds_index_search_workspace_bytes(nq, idx->dim);
+    int rc = idx->ws.reserve(need, st, what);
+    if (rc) return rc;
+    return keds_index_search_packed(idx->packed, idx->rows, idx->n, idx->dim, idx->metric, q, nq, 0, k, idx->row0, D, I,
+                                    rows_out, idx->ws.p, idx->ws.bytes, st);
+}
+
+extern "C" int keds_index_search(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* rows_out,
+                                 void* stream) {
+    const char* what = "keds_index_search";
+    KEDS_REQUIRE(idx && q && D && I && B > 0, "%s: bad argument", what);
+    return index_search_local(idx, (const float*)q, B, k, D, I, (float*)rows_out, (hipStream_t)stream, what);
+}
+
+// ---- communicator ---------------------------------------------------------------------------------------
+extern "C" int keds_comm_unique_id(void* id_out) {
+    KEDS_REQUIRE(id_out != nullptr, "keds_comm_unique_id: null out");
+    int rc = rccl_load();
+    if (rc) return rc;
+    CommId id;
+    if ((rc = rccl_check(g_rccl.GetUniqueId(&id), "keds_comm_unique_id"))) return rc;
+    memcpy(id_out, id.bytes, KEDS_COMM_ID_BYTES);
+    return KEDS_OK;
+}
+
+extern "C" int keds_comm_init(keds_ctx* ctx, int rank, int world, const void* unique_id) {
+    const char* what = "keds_comm_init";
+    KEDS_REQUIRE(ctx && unique_id && world >= 1 && rank >= 0 && rank < world, "%s: bad argument", what);
+    KEDS_REQUIRE(ctx->comm == nullptr, "%s: the context already has a communicator", what);
+    int rc = use_device(ctx, what);
+    if (rc) return rc;
+    if ((rc = rccl_load())) return rc;
+    CommId id;
+    memcpy(id.bytes, unique_id, KEDS_COMM_ID_BYTES);
+    void* comm = nullptr;
+    if ((rc = rccl_check(g_rccl.CommInitRank(&comm, world, id, rank), what))) return rc;
+    ctx->comm = comm;
+    ctx->rank = rank;
+    ctx->world = world;
+    return KEDS_OK;
+}
+
+extern "C" int keds_index_search_sharded(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* stream) {
+    const char* what = "keds_index_search_sharded";
+    KEDS_REQUIRE(idx && q && D && I && B > 0 && k >= 1 && k <= KEDS_SCAN_LIST, "%s: bad argument", what);
+    keds_ctx* ctx = idx->ctx;
+    hipStream_t st = (hipStream_t)stream;
+    const int W = ctx->world;
+    if (W == 1 && !ctx->comm) return index_search_local(idx, (const float*)q, B, k, D, I, nullptr, st, what);
+    KEDS_REQUIRE(ctx->comm != nullptr, "%s: call keds_comm_init first", what);
+    const int nq = B * W;
+    // exchange buffers: q_all [nq,dim] f32 | Dp [nq,k] f32 | Ip [nq,k] i64 | Dg [W,nq,k] | Ig [W,nq,k] | Dm | Im
+    const size_t qb = keds_align_up((size_t)nq * idx->dim * 4, 256), db = keds_align_up((size_t)nq * k * 4, 256),
+                 ib = keds_align_up((size_t)nq * k * 8, 256);
+    int rc = idx->xws.reserve(qb + 2 * (db + ib) + (size_t)W * (db + ib), st, what);
+    if (rc) return rc;
+    char* p = (char*)idx->xws.p;
+    float* q_all = (float*)p;
+    float* Dp = (float*)(p + qb);
+    int64_t* Ip = (int64_t*)(p + qb + db);
+    float* Dm = (float*)(p + qb + db + ib);
+    int64_t* Im = (int64_t*)(p + qb + 2 * db + ib);
+    char* g = p + qb + 2 * (db + ib);
+    float* Dg = (float*)g;
+    int64_t* Ig = (int64_t*)(g + (size_t)W * db);
+    const size_t dpart = (size_t)nq * k * 4, ipart = (size_t)nq * k * 8;
+    if ((rc = rccl_check(g_rccl.AllGather(q, q_all, (size_t)B * idx->dim * 4, /*ncclInt8*/ 0, ctx->comm, st), what))) return rc;
+    if ((rc = index_search_local(idx, q_all, nq, k, Dp, Ip, nullptr, st, what))) return rc;
+    // the gathered parts must be dense [W, nq, k]: gather with the exact part size (no padding between ranks)
+    if ((rc = rccl_check(g_rccl.AllGather(Dp, Dg, dpart, 0, ctx->comm, st), what))) return rc;
+    if ((rc = rccl_check(g_rccl.AllGather(Ip, Ig, ipart, 0, ctx->comm, st), what))) return rc;
+    if ((rc = keds_topk_merge_parts(Dg, Ig, W, nq, k, idx->metric, Dm, Im, stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(D, Dm + (size_t)ctx->rank * B * k, (size_t)B * k * 4, hipMemcpyDeviceToDevice, st), what);
+    HIP_TRY(hipMemcpyAsync(I, Im + (size_t)ctx->rank * B * k, (size_t)B * k * 8, hipMemcpyDeviceToDevice, st), what);
+    return KEDS_OK;
+}

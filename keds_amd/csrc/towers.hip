@@ -1,7 +1,7 @@
 // Whole-tower forward passes built from the kernels in gemm/attention/elementwise:
 //   keds_tower_forward : N pre-LN residual blocks        (src/model/model.py:305-326,372-373)
-//   keds_vit_forward   : CLIP.encode_image, ViT branch   (src/model/model.py:569-575,393-415)
-//   keds_text_forward  : CLIP.encode_text / encode_text_img_retrieval (src/model/model.py:577-590,808-851)
+//   keds_vit_run   : CLIP.encode_image, ViT branch   (src/model/model.py:569-575,393-415)
+//   keds_text_run  : CLIP.encode_text / encode_text_img_retrieval (src/model/model.py:577-590,808-851)
 // Host code only: every launch is asynchronous on the caller's stream, the caller owns the
 // workspace, nothing is allocated or synchronised here.
 #include "keds_common.h"
@@ -137,19 +137,19 @@ extern "C" size_t keds_vit_workspace_bytes(const keds_vit_params* p, int B) {
     return carve_vit(p, B, nullptr).bytes;
 }
 
-extern "C" int keds_vit_forward(const keds_vit_params* p, const float* image, int B, float* out, int normalize,
+extern "C" int keds_vit_run(const keds_vit_params* p, const float* image, int B, float* out, int normalize,
                                 void* workspace, size_t workspace_bytes, void* stream) {
-    KEDS_REQUIRE(p && image && out && workspace && B > 0, "keds_vit_forward: bad argument");
-    int rc = check_tower(&p->tower, "keds_vit_forward");
+    KEDS_REQUIRE(p && image && out && workspace && B > 0, "keds_vit_run: bad argument");
+    int rc = check_tower(&p->tower, "keds_vit_run");
     if (rc) return rc;
     const int w = p->tower.width, S = p->tower.seq, G = S - 1;
     const int g = p->resolution / p->patch;
-    KEDS_REQUIRE(p->resolution % p->patch == 0 && g * g == G, "keds_vit_forward: seq must be (res/patch)^2 + 1");
-    KEDS_REQUIRE(p->kpad % 64 == 0 && p->kpad >= 3 * p->patch * p->patch, "keds_vit_forward: bad kpad");
-    KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_vit_forward: embed_dim must be a multiple of 128");
+    KEDS_REQUIRE(p->resolution % p->patch == 0 && g * g == G, "keds_vit_run: seq must be (res/patch)^2 + 1");
+    KEDS_REQUIRE(p->kpad % 64 == 0 && p->kpad >= 3 * p->patch * p->patch, "keds_vit_run: bad kpad");
+    KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_vit_run: embed_dim must be a multiple of 128");
     VitWs v = carve_vit(p, B, workspace);
     if (workspace_bytes < v.bytes) {
-        keds_set_error("keds_vit_forward: workspace %zu < %zu", workspace_bytes, v.bytes);
+        keds_set_error("keds_vit_run: workspace %zu < %zu", workspace_bytes, v.bytes);
         return KEDS_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -194,16 +194,16 @@ extern "C" size_t keds_text_workspace_bytes(const keds_text_params* p, int B) {
     return carve_text(p, B, nullptr).bytes;
 }
 
-extern "C" int keds_text_forward(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
+extern "C" int keds_text_run(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
                                  const float* img_tokens, int n_tok, int insert_col, int B, float* out, int normalize,
                                  void* workspace, size_t workspace_bytes, void* stream) {
-    KEDS_REQUIRE(p && tokens && readout_row && out && workspace && B > 0, "keds_text_forward: bad argument");
-    int rc = check_tower(&p->tower, "keds_text_forward");
+    KEDS_REQUIRE(p && tokens && readout_row && out && workspace && B > 0, "keds_text_run: bad argument");
+    int rc = check_tower(&p->tower, "keds_text_run");
     if (rc) return rc;
-    KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_text_forward: embed_dim must be a multiple of 128");
+    KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_text_run: embed_dim must be a multiple of 128");
     TextWs v = carve_text(p, B, workspace);
     if (workspace_bytes < v.bytes) {
-        keds_set_error("keds_text_forward: workspace %zu < %zu", workspace_bytes, v.bytes);
+        keds_set_error("keds_text_run: workspace %zu < %zu", workspace_bytes, v.bytes);
         return KEDS_E_WORKSPACE;
     }
     const int w = p->tower.width, L = p->tower.seq;

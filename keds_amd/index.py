@@ -91,9 +91,9 @@ class FlatIndex:
         D = torch.empty((B, k), dtype=torch.float32, device=self.device)
         I = torch.empty((B, k), dtype=torch.int64, device=self.device)
         rows = torch.empty((B, k, self.d), dtype=torch.float32, device=self.device) if gather else None
-        check(lib.keds_index_search(ptr(self.packed), ptr(self.rows), self.rows.shape[0], self.d, self.metric,
+        check(lib.keds_index_search_packed(ptr(self.packed), ptr(self.rows), self.rows.shape[0], self.d, self.metric,
                                     ptr(q), B, 1 if normalize else 0, k, self.row0, ptr(D), ptr(I), ptr(rows),
-                                    ptr(ws), ws.numel(), stream()), "keds_index_search")
+                                    ptr(ws), ws.numel(), stream()), "keds_index_search_packed")
         return D, I, rows
 
     def search(self, q: ArrayLike, k: int):

@@ -214,8 +214,8 @@ class CLIP(nn.Module):
         nbytes = lib.keds_vit_workspace_bytes(C.byref(eng.vit), B)
         ws = self._ws.get(nbytes, eng.device)
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
-        check(lib.keds_vit_forward(C.byref(eng.vit), ptr(img), B, ptr(out), 1 if normalize else 0, ptr(ws), ws.numel(),
-                                   stream()), "keds_vit_forward")
+        check(lib.keds_vit_run(C.byref(eng.vit), ptr(img), B, ptr(out), 1 if normalize else 0, ptr(ws), ws.numel(),
+                                   stream()), "keds_vit_run")
         return out.to(self.dtype)
 
     def _eot_columns(self, text: torch.Tensor) -> torch.Tensor:
@@ -236,8 +236,8 @@ class CLIP(nn.Module):
         nbytes = lib.keds_text_workspace_bytes(C.byref(eng.text), B)
         ws = self._ws.get(nbytes, eng.device)
         out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
-        check(lib.keds_text_forward(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, ptr(out),
-                                    1 if normalize else 0, ptr(ws), ws.numel(), stream()), "keds_text_forward")
+        check(lib.keds_text_run(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, ptr(out),
+                                    1 if normalize else 0, ptr(ws), ws.numel(), stream()), "keds_text_run")
         return out.to(self.dtype)
 
     def encode_text(self, text, normalize: bool = False):
@@ -441,8 +441,8 @@ class KnowledgeStream:
         nbytes = lib.keds_knowledge_workspace_bytes(C.byref(kp), B, K)
         ws = self._ws.get(nbytes, qf.device)
         out = torch.empty((B, 3, dim), dtype=torch.float32, device=qf.device)
-        check(lib.keds_knowledge_forward(C.byref(kp), ptr(qf), ptr(ni), ptr(nt), B, K, ptr(out), ptr(ws), ws.numel(),
-                                         stream()), "keds_knowledge_forward")
+        check(lib.keds_knowledge_run(C.byref(kp), ptr(qf), ptr(ni), ptr(nt), B, K, ptr(out), ptr(ws), ws.numel(),
+                                         stream()), "keds_knowledge_run")
         return out
 
 

@@ -17,9 +17,12 @@ from tests.conftest import ROOT, golden_path
 
 
 def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "keds_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(keds_[a-z0-9_]+)\s*\(", text)))
+    names = set()
+    for header in ("keds_hip.h", "keds_session.h"):
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(keds_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -27,11 +30,25 @@ def test_library_exports_every_declared_symbol():
         _lib.build()
     lib = _lib.load()
     declared = _declared_symbols()
-    assert len(declared) >= 30
+    assert len(declared) >= 60
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in keds_hip.h but not exported"
-    assert sorted(_lib.SIGNATURES) == declared, "ctypes SIGNATURES and keds_hip.h disagree"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes SIGNATURES and include/*.h disagree"
     assert lib.keds_abi_version() == _lib.ABI_VERSION
+
+
+def test_session_abi_fails_loudly_without_a_gpu():
+    """The handle layer (keds_session.h) reports errors instead of computing anywhere else."""
+    import ctypes as C
+    lib = _lib.load()
+    h = C.c_void_p()
+    if not torch.cuda.is_available():
+        assert lib.keds_ctx_create(0, C.byref(h)) != 0 and not h.value
+        assert _lib.last_error() != ""
+    assert lib.keds_vit_create(None, None, 0, _lib.DT_BF16, C.byref(h)) == -1
+    assert lib.keds_index_create(None, 768, 0, _lib.DT_BF16, C.byref(h)) == -1 and "null context" in _lib.last_error()
+    assert lib.keds_index_ntotal(None) == -1
+    assert lib.keds_index_search_sharded(None, None, 0, 0, None, None, None) == -1
 
 
 def test_size_queries_need_no_gpu():
@@ -48,7 +65,7 @@ def test_argument_errors_are_reported():
     lib = _lib.load()
     rc = lib.keds_gemm_bt(None, None, None, None, 1, 1, 1, 0, None, 0, None)
     assert rc == -1 and "null" in _lib.last_error()
-    rc = lib.keds_index_search(1, 1, 10, 768, 0, 1, 4, 0, 17, 0, 1, 1, None, 1, 0, None)   # k > 16
+    rc = lib.keds_index_search_packed(1, 1, 10, 768, 0, 1, 4, 0, 17, 0, 1, 1, None, 1, 0, None)   # k > 16
     assert rc == -1 and "k must be" in _lib.last_error()
     rc = lib.keds_attention(1, 1, 1, 400, 16, 0, None)
     assert rc == -1 and "unsupported" in _lib.last_error()
