@@ -108,6 +108,13 @@ int keds_cirr_target_rank(const int32_t* order, int nq, int ng, const int32_t* g
                           int32_t* counts_out /* nullable [nq,2]: reference matches, target matches */,
                           void* stream);
 
+/* get_metrics_imgnet (src/eval_utils.py:1090-1134): hits_out[q,j] = number of gallery items among the first
+ * ks[j] of order[q,:] whose label equals query_labels[q]; total_out[q] = that count over the whole gallery.
+ * ks is a HOST array of nk <= 8 cut-offs. */
+int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery_labels,
+                    const int32_t* query_labels, const int32_t* ks, int nk, int32_t* hits_out,
+                    int32_t* total_out, void* stream);
+
 /* =====================================================================================
  * 2. Encoder primitives (src/model/model.py:291-326).  bf16 GEMM inputs, fp32 accumulate,
  *    fp32 residual stream, fp32 LayerNorm / softmax statistics.

@@ -115,6 +115,7 @@ SIGNATURES = {
     "keds_rank_gallery_workspace_bytes": (sz, [i32, i32]),
     "keds_rank_gallery": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),
     "keds_cirr_target_rank": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "keds_label_hits": (i32, [vp, i32, i32, vp, vp, C.POINTER(i32), i32, vp, vp, vp]),
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "keds_gemm_set_workspace": (i32, [vp, sz]),
     "keds_gemm_force_small": (i32, [i32]),

@@ -116,6 +116,39 @@ __global__ __launch_bounds__(256) void cirr_rank_kernel(const int* __restrict__ 
     }
 }
 
+struct KList {
+    int k[8];
+};
+
+// One wave per query: hits[q, j] = #{ i < ks[j] : label[order[q,i]] == qlabel[q] },  total[q] = same over all i.
+// (get_metrics_imgnet, src/eval_utils.py:1090-1134: the consistency / num_correct / num_total sums)
+__global__ void label_hits_kernel(const int32_t* __restrict__ order, int nq, int ng,
+                                  const int32_t* __restrict__ gallery_labels, const int32_t* __restrict__ query_labels,
+                                  KList ks, int nk, int32_t* __restrict__ hits_out, int32_t* __restrict__ total_out) {
+    const int lane = threadIdx.x & 63;
+    const int q = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (q >= nq) return;
+    const int ql = query_labels[q];
+    int hits[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int total = 0;
+    for (int i = lane; i < ng; i += 64) {
+        const int m = gallery_labels[order[(size_t)q * ng + i]] == ql ? 1 : 0;
+        total += m;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hits[j] += (j < nk && i < ks.k[j]) ? m : 0;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        total += __shfl_xor(total, o, 64);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) hits[j] += __shfl_xor(hits[j], o, 64);
+    }
+    if (lane == 0) {
+        total_out[q] = total;
+        for (int j = 0; j < nk; ++j) hits_out[(size_t)q * nk + j] = hits[j];
+    }
+}
+
 int next_pow2(int n) {
     int p = 1;
     while (p < n) p <<= 1;
@@ -166,4 +199,17 @@ extern "C" int keds_cirr_target_rank(const int32_t* order, int nq, int ng, const
     cirr_rank_kernel<<<(nq + 3) / 4, 256, 0, (hipStream_t)stream>>>(order, nq, ng, gallery_ids, ref_ids, target_ids,
                                                                     rank_out, counts_out);
     return keds_check_launch("cirr_rank_kernel");
+}
+
+extern "C" int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery_labels,
+                               const int32_t* query_labels, const int32_t* ks, int nk, int32_t* hits_out,
+                               int32_t* total_out, void* stream) {
+    KEDS_REQUIRE(order && gallery_labels && query_labels && ks && hits_out && total_out && nq > 0 && ng > 0,
+                 "keds_label_hits: bad argument");
+    KEDS_REQUIRE(nk >= 1 && nk <= 8, "keds_label_hits: 1..8 cut-offs");
+    KList kl;
+    for (int j = 0; j < 8; ++j) kl.k[j] = j < nk ? ks[j] : 0;
+    label_hits_kernel<<<(nq + 3) / 4, 256, 0, (hipStream_t)stream>>>(order, nq, ng, gallery_labels, query_labels, kl, nk,
+                                                                     hits_out, total_out);
+    return keds_check_launch("label_hits_kernel");
 }

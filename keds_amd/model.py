@@ -271,6 +271,32 @@ class CLIP(nn.Module):
             raise IndexError("read-out row beyond the context length")
         return self._run_text(text, readout, img_tokens, ins, normalize)
 
+    def encode_text_img_train(self, text, img_tokens, split_ind=4, repeat=True, normalize: bool = False):
+        """model.py:853-892 (the splice evaluate_fashion calls, eval_utils.py:957,969): the THREE token positions
+        starting at the first `split_ind` of row 0 are overwritten by the pseudo tokens, nothing shifts, read-out at
+        the EOT column.  Identical to the retrieval splice of a token row with positions ins+1, ins+2 deleted, which
+        is how it runs here (integer column shuffling on the host side, same kernels).  `repeat` is ignored, as in
+        the reference."""
+        if img_tokens.dim() != 3 or img_tokens.shape[1] != 3:
+            raise RuntimeError("encode_text_img_train needs exactly 3 pseudo tokens per row (sequence length would not "
+                               f"be {self.context_length})")               # reference: size mismatch at model.py:883
+        if text.dim() != 2 or text.shape[0] != img_tokens.shape[0] or text.shape[1] != self.context_length:
+            raise RuntimeError(f"token rows {tuple(text.shape)} do not match {img_tokens.shape[0]} pseudo-token rows")
+        where = (text[0] == int(split_ind)).nonzero()
+        if where.numel() == 0:
+            raise IndexError("split token not present in text[0]")
+        ins = int(where[0])
+        if ins + 3 > self.context_length:
+            raise RuntimeError("no room for 3 pseudo tokens after the split token")
+        eot = self._eot_columns(text)
+        if bool(((eot >= ins) & (eot < ins + 3)).any()):
+            raise IndexError("the EOT token lies inside the overwritten span")
+        L = self.context_length
+        squeezed = torch.zeros_like(text)
+        squeezed[:, :ins + 1] = text[:, :ins + 1]
+        squeezed[:, ins + 1:L - 2] = text[:, ins + 3:]
+        return self._run_text(squeezed, eot, img_tokens, ins, normalize)
+
     def get_text_tokens(self, text):
         raise NotImplementedError("get_text_tokens is not on the retrieval path")
 

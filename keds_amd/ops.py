@@ -133,6 +133,19 @@ def cirr_target_rank(order: torch.Tensor, gallery_ids: torch.Tensor, ref_ids: to
     return rank, counts
 
 
+def label_hits(order: torch.Tensor, gallery_labels: torch.Tensor, query_labels: torch.Tensor, ks):
+    """(hits [Q,len(ks)], total [Q]) int32: same-label items among the first k of every ranking / in the gallery."""
+    import ctypes as C
+    nq, ng = order.shape
+    hits = torch.empty((nq, len(ks)), dtype=torch.int32, device=order.device)
+    total = torch.empty(nq, dtype=torch.int32, device=order.device)
+    karr = (C.c_int * len(ks))(*[int(k) for k in ks])
+    check(load().keds_label_hits(ptr(order), nq, ng, ptr(gallery_labels.to(order.device, torch.int32).contiguous()),
+                                 ptr(query_labels.to(order.device, torch.int32).contiguous()), karr, len(ks), ptr(hits),
+                                 ptr(total), stream()), "keds_label_hits")
+    return hits, total
+
+
 def topk_merge_parts(D_parts: torch.Tensor, I_parts: torch.Tensor, metric: int):
     """[parts, nq, k] sorted partial results -> global (D [nq,k], I [nq,k]) keyed on (D, I)."""
     parts, nq, k = D_parts.shape

@@ -3,6 +3,7 @@
   get_retrieved_features   eval_utils.py:153-186   (normalise, top-16 over both DBs, gather rows)
   compose_query_features   eval_utils.py:652-714   (per-batch body of evaluate_cirr)
   get_metrics_cirr         eval_utils.py:1040-1067 (gallery ranking, reference removal, Recall@k)
+  get_metrics_fashion / _coco / _imgnet, get_cirr_testoutput   eval_utils.py:1008-1134 (the other drivers' metrics)
   build_database           eval_retrieval.py:281-298 (DB tensors + two flat indices)
 
 Everything stays on the device: no .cpu().numpy() round trip, no CPU fancy-index gather.
@@ -43,8 +44,11 @@ def get_retrieved_features(feature: torch.Tensor, database, args=None, topk: int
 
 def compose_query_features(model: CLIP, stream_image: KnowledgeStream, stream_text: KnowledgeStream,
                            ref_images: torch.Tensor, text_with_blank: torch.Tensor, database,
-                           id_split: int = 265, topk: int = 16) -> Dict[str, torch.Tensor]:
-    """Per-batch body of evaluate_cirr (eval_utils.py:652-714).
+                           id_split: int = 265, topk: int = 16, repeat: bool = False,
+                           w_text_stream: float = 0.5) -> Dict[str, torch.Tensor]:
+    """Per-batch body of evaluate_cirr (eval_utils.py:652-714).  evaluate_coco (:511-548) is the same body with
+    mixture weight w = 0.05 j for the text stream, evaluate_imgnet_retrieval (:372-415) passes ONE prompt row with
+    repeat=True and w = 0.1 j.
 
     Returns the reference's three feature sets under its dict names (eval_utils.py:728-732):
     'composed' = image-stream feature, 'image' = text-stream feature, 'mixture' = their normalised mean.
@@ -52,10 +56,10 @@ def compose_query_features(model: CLIP, stream_image: KnowledgeStream, stream_te
     q = model.encode_image(ref_images).float()
     topk_image, topk_text = get_retrieved_features(q, database, None, topk=topk)
     tok_a = stream_image(q, topk_image, topk_text)                                   # [B,3,D]
-    comp_a = model.encode_text_img_retrieval(text_with_blank, tok_a, split_ind=id_split, repeat=False)
+    comp_a = model.encode_text_img_retrieval(text_with_blank, tok_a, split_ind=id_split, repeat=repeat)
     tok_b = stream_text(q, topk_image, topk_text)
-    comp_b = model.encode_text_img_retrieval(text_with_blank, tok_b, split_ind=id_split, repeat=False)
-    b_n, a_n, mix = ops.mix_normalize(comp_b.float(), comp_a.float(), 0.5, 0.5)
+    comp_b = model.encode_text_img_retrieval(text_with_blank, tok_b, split_ind=id_split, repeat=repeat)
+    b_n, a_n, mix = ops.mix_normalize(comp_b.float(), comp_a.float(), float(w_text_stream), 1.0 - float(w_text_stream))
     return {"composed": a_n, "image": b_n, "mixture": mix, "query_image_features": q,
             "tokens_image_stream": tok_a, "tokens_text_stream": tok_b}
 
@@ -89,6 +93,78 @@ def get_metrics_cirr(image_features: torch.Tensor, ref_features: torch.Tensor, r
     rank = rank.cpu()
     n = rank.shape[0]
     return {f"recall_R@{k}": float((rank < k).sum().item()) / n * 100.0 for k in (1, 5, 10, 50, 100)}
+
+
+def _intern_whole(names: Sequence[str], table: Dict[str, int]) -> np.ndarray:
+    return np.fromiter((table.setdefault(str(n), len(table)) for n in names), dtype=np.int32, count=len(names))
+
+
+def get_metrics_fashion(image_features: torch.Tensor, ref_features: torch.Tensor, target_names, answer_names
+                        ) -> Dict[str, float]:
+    """eval_utils.py:1025-1037: Recall@k (percent) of the answer image in the gallery ranking, on device."""
+    table: Dict[str, int] = {}
+    gal = _intern_whole(target_names, table)
+    ans = _intern_whole(answer_names, table)
+    dev = image_features.device
+    order = ops.rank_gallery(ref_features, image_features)
+    none = torch.full((len(ans),), -1, dtype=torch.int32, device=dev)          # nothing is removed from the ranking
+    rank, counts = ops.cirr_target_rank(order, torch.from_numpy(gal).to(dev), none, torch.from_numpy(ans).to(dev))
+    if not bool((counts[:, 1] == 1).all()):                                    # eval_utils.py:1033
+        raise AssertionError("each answer must appear exactly once in the gallery")
+    rank = rank.cpu()
+    n = rank.shape[0]
+    return {f"R@{k}": float((rank < k).sum().item()) / n * 100.0 for k in (1, 5, 10, 50, 100)}
+
+
+def get_metrics_coco(image_features: torch.Tensor, ref_features: torch.Tensor, logit_scale=None) -> Dict[str, float]:
+    """eval_utils.py:1008-1022: paired (image, composed) features, both retrieval directions; the positive
+    logit_scale does not change a ranking, so it is accepted and unused."""
+    n = ref_features.shape[0]
+    if image_features.shape[0] != n:
+        raise RuntimeError("get_metrics_coco needs paired features")
+    dev = image_features.device
+    ids = torch.arange(n, dtype=torch.int32, device=dev)
+    none = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    out: Dict[str, float] = {}
+    for name, a, b in (("image_to_ref", image_features, ref_features), ("ref_to_image", ref_features, image_features)):
+        order = ops.rank_gallery(a, b)                 # ascending 1 - a.b == descending logits
+        rank, _ = ops.cirr_target_rank(order, ids, none, ids)
+        preds = rank.cpu().numpy()
+        out[f"{name}_mean_rank"] = float(preds.mean() + 1)
+        out[f"{name}_median_rank"] = float(np.floor(np.median(preds)) + 1)
+        for k in (1, 5, 10, 50, 100):
+            out[f"{name}_R@{k}"] = float(np.mean(preds < k))
+    return out
+
+
+def get_metrics_imgnet(query_features: torch.Tensor, image_features: torch.Tensor, query_labels, target_labels
+                       ) -> Dict[str, float]:
+    """eval_utils.py:1090-1134: multi-positive P@k / R@k for k in {1,5,10,50,100,200}; ranking and label counting
+    on device (one-hot label matrices of the reference are never built)."""
+    ks = (1, 5, 10, 50, 100, 200)
+    order = ops.rank_gallery(query_features, image_features)
+    hits, total = ops.label_hits(order, torch.as_tensor(target_labels), torch.as_tensor(query_labels), ks)
+    hits, total = hits.cpu().float(), total.cpu().float()
+    ng = image_features.shape[0]
+    out: Dict[str, float] = {}
+    for j, k in enumerate(ks):
+        out[f"Real2Sketch_R@{k}"] = float((hits[:, j] / (total + 1e-5)).mean())
+        out[f"Real2Sketch_P@{k}"] = float((hits[:, j] / float(min(k, ng))).mean())
+    return out
+
+
+def get_cirr_testoutput(image_features: torch.Tensor, ref_features: torch.Tensor, reference_names, index_names,
+                        id_names) -> Dict[str, object]:
+    """eval_utils.py:1070-1087: CIRR test-server submission: per pair id the 50 best gallery names with the
+    reference image removed and '.png' stripped.  Ranking on device, 51 ids per query come back to the host."""
+    order = ops.rank_gallery(ref_features, image_features)[:, :51].cpu().numpy()
+    names = [str(n) for n in index_names]
+    out: Dict[str, object] = {"version": "rc2", "metric": "recall"}
+    for i in range(len(id_names)):
+        ref = str(reference_names[i])
+        ranked = [names[j] for j in order[i] if names[j] != ref][:50]
+        out[str(int(id_names[i]))] = [n.replace(".png", "") for n in ranked]
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------

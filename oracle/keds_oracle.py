@@ -214,6 +214,27 @@ def encode_text_img_retrieval(sd: SD, text: Tensor, img_tokens: Tensor,
     return _text_tower(sd, x, readout)
 
 
+def encode_text_img_train(sd: SD, text: Tensor, img_tokens: Tensor, split_ind: int = 4,
+                          repeat: bool = True) -> Tensor:
+    """CLIP.encode_text_img_train (src/model/model.py:853-892), the splice evaluate_fashion calls
+    (src/eval_utils.py:957,969): THREE token positions starting at the first `split_ind` of row 0 are
+    overwritten by the pseudo tokens (:880), nothing shifts, read-out at the EOT column (:891).
+    Any other token count makes the sequence length differ from the positional table, which fails in
+    the reference too (:883).  `repeat` is accepted and ignored, as in the reference."""
+    if img_tokens.shape[1] != 3:
+        raise RuntimeError("encode_text_img_train needs exactly 3 pseudo tokens (sequence length would not be "
+                           f"{text.shape[1]})")
+    end_id = sd["token_embedding.weight"].shape[0] - 1
+    eot = _eot_column(text, end_id)
+    where = (text[0] == split_ind).nonzero()
+    if where.numel() == 0:
+        raise IndexError("split token not present in text[0]")
+    ins = int(where[0])
+    emb = sd["token_embedding.weight"].float()[text]
+    x = torch.cat([emb[:, :ins], img_tokens.float(), emb[:, ins + 3:]], dim=1)
+    return _text_tower(sd, x, eot)
+
+
 # ----------------------------------------------------------------------------
 # knowledge injection modules
 # ----------------------------------------------------------------------------
@@ -337,8 +358,10 @@ def knowledge_tokens(sd_i2t: SD, sd_fuse: SD, sd_cond: SD, q_feat: Tensor,
 def compose_query(sd_clip: SD, stream_img: Sequence[SD], stream_txt: Sequence[SD],
                   ref_images: Tensor, text_with_blank: Tensor,
                   image_base: Tensor, text_base: Tensor, split_ind: int = 265,
-                  topk: int = 16) -> Dict[str, Tensor]:
-    """Per-batch body of evaluate_cirr (src/eval_utils.py:652-714).
+                  topk: int = 16, repeat: bool = False, w_text_stream: float = 0.5) -> Dict[str, Tensor]:
+    """Per-batch body of evaluate_cirr (src/eval_utils.py:652-714).  The other drivers run the same body with
+    a different prompt broadcast and mixture weight: evaluate_coco (:511-548, repeat=False, w = 0.05 j) and
+    evaluate_imgnet_retrieval (:372-415, one prompt row repeated over the batch, w = 0.1 j).
 
     stream_* = (img2text, retrieval_fuse, text_condition) state dicts of the image
     stream and of the text stream ('_tb').  Returns the three normalised feature sets
@@ -347,12 +370,12 @@ def compose_query(sd_clip: SD, stream_img: Sequence[SD], stream_txt: Sequence[SD
     q_feat = encode_image(sd_clip, ref_images)
     ti, tt, ii, it = get_retrieved_features(q_feat, image_base, text_base, topk)
     tok_a = knowledge_tokens(*stream_img, q_feat, ti, tt)
-    comp_a = encode_text_img_retrieval(sd_clip, text_with_blank, tok_a, split_ind=split_ind, repeat=False)
+    comp_a = encode_text_img_retrieval(sd_clip, text_with_blank, tok_a, split_ind=split_ind, repeat=repeat)
     tok_b = knowledge_tokens(*stream_txt, q_feat, ti, tt)
-    comp_b = encode_text_img_retrieval(sd_clip, text_with_blank, tok_b, split_ind=split_ind, repeat=False)
+    comp_b = encode_text_img_retrieval(sd_clip, text_with_blank, tok_b, split_ind=split_ind, repeat=repeat)
     a = l2_normalize(comp_a)
     b = l2_normalize(comp_b)
-    mix = l2_normalize(0.5 * b + 0.5 * a)
+    mix = l2_normalize(w_text_stream * b + (1.0 - w_text_stream) * a)
     return {"composed": a, "image": b, "mixture": mix, "query_image_features": q_feat,
             "tokens_image_stream": tok_a, "tokens_text_stream": tok_b,
             "topk_image_indices": ii, "topk_text_indices": it}
@@ -381,6 +404,68 @@ def get_metrics_cirr(image_features: Tensor, ref_features: Tensor, reference_nam
     out = {}
     for k in (1, 5, 10, 50, 100):
         out[f"recall_R@{k}"] = float(hit[:, :k].sum()) / hit.shape[0] * 100.0
+    return out
+
+
+def get_metrics_fashion(image_features: Tensor, ref_features: Tensor, target_names: Sequence[str],
+                        answer_names: Sequence[str]) -> Dict[str, float]:
+    """get_metrics_fashion (src/eval_utils.py:1025-1037): rank the gallery by 1 - cosine, Recall@k in
+    percent of the answer image (names compared whole, no reference removal)."""
+    dist = 1.0 - ref_features.float() @ image_features.float().t()
+    order = torch.sort(dist, dim=1, stable=True).indices.numpy()
+    ranked = np.array(list(target_names))[order]
+    hit = ranked == np.array(list(answer_names))[:, None]
+    if not (hit.sum(1) == 1).all():                                      # :1033
+        raise AssertionError("each answer must appear exactly once in the gallery")
+    return {f"R@{k}": float(hit[:, :k].sum()) / hit.shape[0] * 100.0 for k in (1, 5, 10, 50, 100)}
+
+
+def get_metrics_coco(image_features: Tensor, ref_features: Tensor, logit_scale) -> Dict[str, float]:
+    """get_metrics_coco (src/eval_utils.py:1008-1022): paired features, both directions; rank of the
+    pair partner (0-based `preds`), mean/median rank (1-based) and R@k as fractions."""
+    logits = (float(logit_scale) * image_features.float() @ ref_features.float().t())
+    out: Dict[str, float] = {}
+    gt = torch.arange(len(ref_features)).view(-1, 1)
+    for name, lg in (("image_to_ref", logits), ("ref_to_image", logits.t())):
+        ranking = torch.sort(lg, dim=1, descending=True, stable=True).indices
+        preds = torch.where(ranking == gt)[1].numpy()
+        out[f"{name}_mean_rank"] = float(preds.mean() + 1)
+        out[f"{name}_median_rank"] = float(np.floor(np.median(preds)) + 1)
+        for k in (1, 5, 10, 50, 100):
+            out[f"{name}_R@{k}"] = float(np.mean(preds < k))
+    return out
+
+
+def get_metrics_imgnet(query_features: Tensor, image_features: Tensor, query_labels: Tensor,
+                       target_labels: Tensor) -> Dict[str, float]:
+    """get_metrics_imgnet (src/eval_utils.py:1090-1134): multi-positive retrieval.  For k in
+    {1,5,10,50,100,200}: hits = same-label items among the top-k by dot product; recall = hits /
+    (#same-label targets + 1e-5), precision = hits / k, both averaged over the queries (the
+    reference's per-100 batching is a weighted mean of batch means = the plain mean)."""
+    sim = query_features.float() @ image_features.float().t()
+    ranking = torch.sort(sim, dim=1, descending=True, stable=True).indices
+    same = (target_labels[ranking] == query_labels[:, None])             # [Q,T] in rank order
+    total = same.sum(1).float()
+    out: Dict[str, float] = {}
+    for k in (1, 5, 10, 50, 100, 200):
+        hits = same[:, :k].sum(1).float()
+        out[f"Real2Sketch_R@{k}"] = float((hits / (total + 1e-5)).mean())
+        out[f"Real2Sketch_P@{k}"] = float((hits / float(min(k, same.shape[1]))).mean())
+    return out
+
+
+def get_cirr_testoutput(image_features: Tensor, ref_features: Tensor, reference_names: Sequence[str],
+                        index_names: Sequence[str], id_names) -> Dict[str, object]:
+    """get_cirr_testoutput (src/eval_utils.py:1070-1087): the CIRR test-server submission: per pair id
+    the top-50 gallery names (reference image removed, '.png' stripped)."""
+    dist = 1.0 - ref_features.float() @ image_features.float().t()
+    order = torch.sort(dist, dim=1, stable=True).indices.numpy()
+    ranked = np.array(list(index_names))[order]
+    keep = ranked != np.array(list(reference_names))[:, None]
+    ranked = ranked[keep].reshape(ranked.shape[0], ranked.shape[1] - 1)
+    out: Dict[str, object] = {"version": "rc2", "metric": "recall"}
+    for i in range(len(id_names)):
+        out[str(int(id_names[i]))] = [str(n).replace(".png", "") for n in ranked[i][:50]]
     return out
 
 

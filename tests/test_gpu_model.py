@@ -204,3 +204,67 @@ def test_recall_equal_to_cpu_reference():
     mg = keds_amd.get_metrics_cirr(gg, qg, ref, names, tgt)
     report("recall_equal", **{k.replace("@", "_at_"): v for k, v in mg.items()})
     assert mo == mg
+
+
+# ---- the other eval drivers' glue on the same kernels ---------------------------------
+def test_encode_text_img_train_fashion_splice(tiny_model):
+    """model.py:853-892 against the reference's own output (tests/golden/eval_glue.npz)."""
+    gt, sd, m = tiny_model
+    g = dict(np.load(golden_path("eval_glue.npz")))
+    text, tok3, star = torch.from_numpy(g["text"]).cuda(), torch.from_numpy(g["tok3"]).cuda(), int(g["star"])
+    _assert_close("glue.eti_train3", m.encode_text_img_train(text, tok3, split_ind=star, repeat=False), g["eti_train3"])
+    with pytest.raises(RuntimeError):                 # 2 tokens: the reference fails with a size mismatch (:883)
+        m.encode_text_img_train(text, tok3[:, :2], split_ind=star)
+    with pytest.raises(IndexError):
+        m.encode_text_img_train(text, tok3, split_ind=499)
+
+
+def test_metrics_of_the_other_drivers_match_reference_values():
+    """get_metrics_fashion / _coco / _imgnet and get_cirr_testoutput (eval_utils.py:1008-1134) with ranking and
+    counting on the GPU: the reference's own numbers for the same inputs."""
+    g = dict(np.load(golden_path("eval_glue.npz")))
+    gallery, ref = torch.from_numpy(g["gallery"]).cuda(), torch.from_numpy(g["ref"]).cuda()
+    names = [f"dress/img_{i:05d}.jpg" for i in range(gallery.shape[0])]
+    m = keds_amd.get_metrics_fashion(gallery, ref, names, [names[i] for i in g["answer_idx"]])
+    for k in (1, 5, 10, 50, 100):
+        assert abs(m[f"R@{k}"] - float(g[f"fashion_R_at_{k}"])) < 1e-4
+    with pytest.raises(AssertionError):
+        keds_amd.get_metrics_fashion(gallery, ref, names, ["missing.jpg"] * ref.shape[0])
+    m = keds_amd.get_metrics_coco(torch.from_numpy(g["coco_image"]).cuda(), torch.from_numpy(g["coco_ref"]).cuda(),
+                                  torch.tensor(100.0))
+    assert len(m) == 14
+    for key, v in m.items():
+        assert abs(v - float(g["coco_" + key.replace("@", "_at_")])) < 1e-6, key
+    m = keds_amd.get_metrics_imgnet(torch.from_numpy(g["imgnet_q"]).cuda(), torch.from_numpy(g["imgnet_t"]).cuda(),
+                                    torch.from_numpy(g["imgnet_ql"]), torch.from_numpy(g["imgnet_tl"]))
+    assert len(m) == 12
+    for key, v in m.items():
+        assert abs(v - float(g["imgnet_" + key.replace("@", "_at_")])) < 2e-6, key
+    tnames = [f"test1-{i}-img0.png" for i in range(gallery.shape[0])]
+    res = keds_amd.get_cirr_testoutput(gallery, ref, [tnames[i] for i in g["cirr_test_ref_idx"]], tnames,
+                                       torch.arange(1000, 1000 + ref.shape[0]))
+    assert res["version"] == "rc2" and res["metric"] == "recall" and len(res) == 2 + ref.shape[0]
+    for i in range(ref.shape[0]):
+        assert [int(n.split("-")[1]) for n in res[str(1000 + i)]] == g["cirr_test_top50"][i].tolist()
+
+
+def test_imgnet_and_coco_batch_bodies_against_oracle(tiny_model):
+    """evaluate_imgnet_retrieval (one prompt row, repeat=True, w = 0.1 j) and evaluate_coco (w = 0.05 j) run the CIRR
+    body with other arguments (eval_utils.py:372-415, 511-548)."""
+    gt, sd, m = tiny_model
+    n_db = 4096
+    image_base, text_base = O.synth_database(n_db, 128, seed=2002), O.synth_database(n_db, 128, seed=2003)
+    database = keds_amd.build_database(image_base, text_base, [str(i) for i in range(n_db)])
+
+    def sds(seed):
+        return (O.synth_im2text_state_dict(128, 128, 128, 2, seed=seed, tag="i2t"),
+                O.synth_crossformer_state_dict(128, 3, seed=seed, tag="fuse"),
+                O.synth_crossformer_state_dict(128, 3, seed=seed, tag="cond"))
+    img, text = torch.from_numpy(gt["image"]), torch.from_numpy(gt["text"])
+    for name, kw, txt in (("imgnet", dict(repeat=True, w_text_stream=0.3), text[:1]),
+                          ("coco", dict(repeat=False, w_text_stream=0.15), text)):
+        want = O.compose_query(sd, sds(21), sds(22), img, txt, image_base, text_base, split_ind=265, **kw)
+        got = keds_amd.compose_query_features(m, _streams(128, 128, 21), _streams(128, 128, 22), img.cuda(), txt.cuda(),
+                                              database, id_split=265, **kw)
+        for key in ("composed", "image", "mixture"):
+            _assert_close(f"glue.{name}.{key}", got[key], want[key])

@@ -180,6 +180,38 @@ def test_metrics_cirr():
                            ["nope.png"] * len(tgt_names))
 
 
+def test_eval_glue_other_drivers():
+    """encode_text_img_train + the fashion / coco / imgnet metrics + the CIRR test-server output,
+    against vectors minted from the reference functions themselves (tools/mint_golden.py::mint_eval_glue)."""
+    g = dict(np.load(golden_path("eval_glue.npz")))
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    text, tok3, star = torch.from_numpy(g["text"]), torch.from_numpy(g["tok3"]), int(g["star"])
+    _close(O.encode_text_img_train(sd, text, tok3, split_ind=star, repeat=False), g["eti_train3"], atol=2e-5, rtol=1e-4)
+    with pytest.raises(RuntimeError):                              # 2 tokens: 76 != 77 rows (model.py:880-883)
+        O.encode_text_img_train(sd, text, tok3[:, :2], split_ind=star)
+    gallery, ref = torch.from_numpy(g["gallery"]), torch.from_numpy(g["ref"])
+    names = [f"dress/img_{i:05d}.jpg" for i in range(gallery.shape[0])]
+    m = O.get_metrics_fashion(gallery, ref, names, [names[i] for i in g["answer_idx"]])
+    for k in (1, 5, 10, 50, 100):
+        assert abs(m[f"R@{k}"] - float(g[f"fashion_R_at_{k}"])) < 1e-4
+    m = O.get_metrics_coco(torch.from_numpy(g["coco_image"]), torch.from_numpy(g["coco_ref"]), torch.tensor(100.0))
+    assert len(m) == 14
+    for key, v in m.items():
+        assert abs(v - float(g["coco_" + key.replace("@", "_at_")])) < 1e-6, key
+    m = O.get_metrics_imgnet(torch.from_numpy(g["imgnet_q"]), torch.from_numpy(g["imgnet_t"]),
+                             torch.from_numpy(g["imgnet_ql"]), torch.from_numpy(g["imgnet_tl"]))
+    assert len(m) == 12
+    for key, v in m.items():
+        assert abs(v - float(g["imgnet_" + key.replace("@", "_at_")])) < 2e-6, key
+    tnames = [f"test1-{i}-img0.png" for i in range(gallery.shape[0])]
+    res = O.get_cirr_testoutput(gallery, ref, [tnames[i] for i in g["cirr_test_ref_idx"]], tnames,
+                                torch.arange(1000, 1000 + ref.shape[0]))
+    assert res["version"] == "rc2" and res["metric"] == "recall"
+    for i in range(ref.shape[0]):
+        assert [int(n.split("-")[1]) for n in res[str(1000 + i)]] == g["cirr_test_top50"][i].tolist()
+        assert all(not n.endswith(".png") for n in res[str(1000 + i)])
+
+
 @pytest.mark.skipif(not os.path.exists(golden_path("clip_vitl14.npz")), reason="ViT-L/14 golden not minted")
 def test_vitl14_full_size():
     """Full ViT-L/14 + 12-layer text tower at B=2 (about 20 s of CPU)."""

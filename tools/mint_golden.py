@@ -231,6 +231,61 @@ def mint_metrics():
     print("metrics:", metrics)
 
 
+def mint_eval_glue():
+    """(f) rank 1: the other eval drivers' glue — encode_text_img_train (model.py:853-892, evaluate_fashion's splice),
+    get_metrics_fashion / get_metrics_coco / get_metrics_imgnet / get_cirr_testoutput (eval_utils.py:1008-1134)."""
+    import torch.nn.functional as F
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    model = CLIP(TINY["embed_dim"], TINY["image_resolution"], TINY["vision_layers"], TINY["vision_width"],
+                 TINY["vision_patch_size"], TINY["context_length"], TINY["vocab_size"], TINY["transformer_width"],
+                 TINY["transformer_width"] // 64, TINY["transformer_layers"]).eval().float()
+    model.load_state_dict(sd, strict=True)
+    rs = np.random.RandomState(4242)
+    star = 265
+    text = tiny_tokens(5, TINY["vocab_size"], star, rs)
+    tok3 = (rs.standard_normal((5, 3, 128)) * 0.05).astype(np.float32)
+    out = {"text": text, "tok3": tok3, "star": np.int64(star)}
+    out["eti_train3"] = model.encode_text_img_train(torch.from_numpy(text), torch.from_numpy(tok3), split_ind=star,
+                                                    repeat=False).numpy()
+    ns = {"torch": torch, "np": np, "os": os, "F": F}
+    path = os.path.join(REF, "eval_utils.py")
+    G, Q, dim = 300, 40, 32
+    gallery = O.l2_normalize(torch.from_numpy(rs.standard_normal((G, dim)).astype(np.float32)))
+    names = [f"dress/img_{i:05d}.jpg" for i in range(G)]
+    ans = rs.randint(0, G, size=Q)
+    noise = torch.from_numpy(rs.standard_normal((Q, dim)).astype(np.float32)) * (2.7 / np.sqrt(dim))
+    ref = O.l2_normalize(gallery[ans] + noise)
+    out.update(gallery=gallery.numpy(), ref=ref.numpy(), answer_idx=ans)
+    m = extract_function(path, "get_metrics_fashion", ns)(gallery, ref, names, [names[i] for i in ans])
+    out.update({"fashion_" + k.replace("@", "_at_"): np.float64(v) for k, v in m.items()})
+    # coco: Q paired (image, composed) features
+    img = O.l2_normalize(torch.from_numpy(rs.standard_normal((60, dim)).astype(np.float32)))
+    comp = O.l2_normalize(img + torch.from_numpy(rs.standard_normal((60, dim)).astype(np.float32)) * (2.0 / np.sqrt(dim)))
+    m = extract_function(path, "get_metrics_coco", ns)(img, comp, torch.tensor(100.0))
+    out.update(coco_image=img.numpy(), coco_ref=comp.numpy())
+    out.update({"coco_" + k.replace("@", "_at_"): np.float64(v) for k, v in m.items()})
+    # imgnet: 250 queries (3 reference batches of 100/100/50), 700 targets, 20 classes
+    tl = rs.randint(0, 20, size=700)
+    ql = rs.randint(0, 20, size=250)
+    cent = rs.standard_normal((20, dim)).astype(np.float32)
+    tf = O.l2_normalize(torch.from_numpy(cent[tl] + 1.2 * rs.standard_normal((700, dim)).astype(np.float32)))
+    qf = O.l2_normalize(torch.from_numpy(cent[ql] + 1.2 * rs.standard_normal((250, dim)).astype(np.float32)))
+    m = extract_function(path, "get_metrics_imgnet", ns)(qf, tf, torch.from_numpy(ql), torch.from_numpy(tl))
+    out.update(imgnet_q=qf.numpy(), imgnet_t=tf.numpy(), imgnet_ql=ql, imgnet_tl=tl)
+    out.update({"imgnet_" + k.replace("@", "_at_"): np.float64(float(v)) for k, v in m.items()})
+    # cirr test submission: top-50 names with the reference image removed
+    tnames = [f"test1-{i}-img0.png" for i in range(G)]
+    refi = rs.randint(0, G, size=Q)
+    res = extract_function(path, "get_cirr_testoutput", ns)(gallery, ref, np.array([tnames[i] for i in refi]),
+                                                             np.array(tnames), torch.arange(1000, 1000 + Q))
+    out["cirr_test_ref_idx"] = refi
+    out["cirr_test_top50"] = np.array([[int(n.split("-")[1]) for n in res[str(1000 + i)]] for i in range(Q)], dtype=np.int64)
+    assert res["version"] == "rc2" and res["metric"] == "recall"
+    np.savez_compressed(os.path.join(OUT, "eval_glue.npz"), **out)
+    print("eval_glue:", {k: (v.shape if hasattr(v, "shape") and v.shape else float(v)) for k, v in out.items()
+                         if not k.startswith(("gallery", "ref", "coco_image", "coco_ref", "imgnet_q", "imgnet_t", "text", "tok3"))})
+
+
 def mint_keys():
     """state_dict key -> shape lists of the reference modules (the checkpoint contract)."""
     import json
@@ -253,7 +308,9 @@ VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=
             context_length=77, vocab_size=49408, transformer_width=768, transformer_layers=12)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "knowledge", "cirr", "search", "metrics", "keys", "vitl"]
+    which = sys.argv[1:] or ["tiny", "knowledge", "cirr", "search", "metrics", "glue", "keys", "vitl"]
+    if "glue" in which:
+        mint_eval_glue()
     if "keys" in which:
         mint_keys()
     model = None
