@@ -4,7 +4,9 @@
 //
 // gfx950 design.  Sequences are short (257 / 77 tokens), so one workgroup owns one (batch, head):
 // all K rows and V^T stay resident in LDS (74 KB at S=257 -> 2 workgroups per CU) and no online
-// softmax is needed.  Each wave takes 16-query tiles.  Scores are computed "swapped",
+// softmax is needed.  Each wave takes 32 queries at a time (two 16-query MFMA tiles that share every K / V^T
+// fragment read: the loop is LDS-read bound otherwise).  A start-time phase shift between the two workgroups of a
+// CU was tried and measured neutral: staging and compute already overlap across workgroups.  Scores are computed "swapped",
 // S^T = K . Q^T, so a lane holds ONE query column and 4 keys per 16-key tile: the row max / sum
 // are in-lane reductions plus two xor-shuffles, and the probabilities, packed to bf16 in
 // registers, are already the B operand of O^T = V^T . P^T (the MFMA k-slot order is permuted to
@@ -26,10 +28,149 @@ struct AttnCfg {
     static_assert(NKT % 2 == 0, "PV consumes key tiles in pairs");
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+struct AttnCtx {
+    const bf16_t* base;   // qkv of (b, h): row stride ld
+    bf16_t* out;          // out of (b, h): row stride d
+    const char* k_lds;
+    const char* vt_lds;
+    int S, q_limit, ld, d, g, c;
+};
+
+// NQ consecutive 16-query tiles starting at tile qt0, for one wave.
+template <int NKT, bool CAUSAL, int NFULL, int DBG, int NQ>
+__device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
+    using C = AttnCfg<NKT>;
+    const int g = cx.g, c = cx.c, S = cx.S;
+    const float sl2 = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
+    int qidx[NQ];
+    bf16x8 qf[NQ][2];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        qidx[t] = (qt0 + t) * 16 + c;
+        const int qrow = qidx[t] < S ? qidx[t] : S - 1;
+        const bf16_t* qp = cx.base + (size_t)qrow * cx.ld + 8 * g;
+        qf[t][0] = *reinterpret_cast<const bf16x8*>(qp);
+        qf[t][1] = *reinterpret_cast<const bf16x8*>(qp + 32);
+    }
+    // ---- S^T tiles
+    f32x4 sc[NQ][NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int key = kt * 16 + c;
+        const char* kr = cx.k_lds + key * 128;
+        const int f = (key >> 1) & 7;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(kr + ((g ^ f) << 4));
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(kr + (((4 + g) ^ f) << 4));
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (DBG != 2) {
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[t][0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[t][1], acc, 0, 0, 0);
+            } else {
+                acc[0] = (float)qf[t][0][kt & 7];
+            }
+            sc[t][kt] = acc;
+        }
+        if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound how far LDS reads are hoisted (VGPR pressure)
+    }
+    // ---- mask, row max, exp, row sum (lane holds query qidx[t], keys kt*16 + 4g + r)
+    float inv[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = sc[t][kt][r];
+                if (CAUSAL || kt >= NFULL) {      // resolved at compile time once the kt loop is unrolled
+                    const int kidx = kt * 16 + 4 * g + r;
+                    const bool ok = kidx < S && (!CAUSAL || kidx <= qidx[t]);
+                    v = ok ? v : -INFINITY;
+                    sc[t][kt][r] = v;
+                }
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float nmx = -mx * sl2;
+        // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two elements per VALU issue); v_exp_f32 stays per element
+        const f32x2 vs = f32x2{sl2, sl2}, vn = f32x2{nmx, nmx};
+        f32x2 vsum = f32x2{0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                f32x2 e = f32x2{sc[t][kt][2 * hh], sc[t][kt][2 * hh + 1]};
+                if constexpr (DBG != 3) {
+                    e = pk_fma(e, vs, vn);
+                    e[0] = __builtin_amdgcn_exp2f(e[0]);   // exp2(-inf) = 0
+                    e[1] = __builtin_amdgcn_exp2f(e[1]);
+                }
+                sc[t][kt][2 * hh] = e[0];
+                sc[t][kt][2 * hh + 1] = e[1];
+                vsum += e;
+            }
+        }
+        float sum = vsum[0] + vsum[1];
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        inv[t] = 1.0f / sum;
+    }
+    // ---- O^T = V^T . P^T
+    f32x4 o[NQ][4];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t)
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NKT / 2; ++u) {
+        bf16x8 pf[NQ];
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            const f32x4 p0 = sc[t][2 * u], p1 = sc[t][2 * u + 1];
+            pf[t] = bf16x8{(bf16_t)p0[0], (bf16_t)p0[1], (bf16_t)p0[2], (bf16_t)p0[3],
+                           (bf16_t)p1[0], (bf16_t)p1[1], (bf16_t)p1[2], (bf16_t)p1[3]};
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            if constexpr (DBG != 4) {
+                const bf16x8 a =
+                    *reinterpret_cast<const bf16x8*>(cx.vt_lds + (dt * 16 + c) * C::VT_ROW + (4 * u + g) * 16);
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) o[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[t], o[t][dt], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NQ; ++t) o[t][dt][0] += (float)pf[t][dt];
+            }
+        }
+        if (u % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        if (qidx[t] < cx.q_limit) {
+            bf16_t* op = cx.out + (size_t)qidx[t] * cx.d + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f32x4 v = o[t][dt] * inv[t];
+                *reinterpret_cast<bf16x4*>(op + dt * 16) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+            }
+        }
+    }
+}
+
 // DBG (timing-only ablations): 1 = no K/V staging, 2 = no QK^T MFMA/reads, 3 = no softmax math, 4 = no PV, 5 = no q loop
 // CAUSAL: text tower mask.  NFULL: key tiles [0, NFULL) are known at compile time to lie entirely below S and
 // need no mask (non-causal only) -- evaluating the mask for all 72 score registers cost half the loop's instructions.
-template <int NKT, bool CAUSAL, int NFULL, int DBG = 0>
+template <int NKT, bool CAUSAL, int NFULL, int DBG = 0, bool NQ2 = (NKT == 18 && !CAUSAL)>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
                                                         int heads, int q_limit) {
     using C = AttnCfg<NKT>;
@@ -89,95 +230,16 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
     __syncthreads();
 
-    const float sl2 = 0.125f * 1.4426950408889634f;  // 1/sqrt(64) * log2(e)
-    const int nqt = (q_limit + 15) >> 4;      // only the first q_limit query rows are computed and stored
-    for (int qt = wave; qt < (DBG == 5 ? 0 : nqt); qt += 4) {
-        const int qidx = qt * 16 + c;
-        const int qrow = qidx < S ? qidx : S - 1;
-        bf16x8 qf[2];
-        {
-            const bf16_t* qp = base + (size_t)qrow * ld + 8 * g;
-            qf[0] = *reinterpret_cast<const bf16x8*>(qp);
-            qf[1] = *reinterpret_cast<const bf16x8*>(qp + 32);
-        }
-        // ---- S^T tiles
-        f32x4 sc[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-            const int key = kt * 16 + c;
-            const char* kr = k_lds + key * 128;
-            const int f = (key >> 1) & 7;
-            const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(kr + ((g ^ f) << 4));
-            const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(kr + (((4 + g) ^ f) << 4));
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (DBG != 2) {
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, qf[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, qf[1], acc, 0, 0, 0);
-            } else {
-                acc[0] = (float)qf[0][kt & 7];
-            }
-            sc[kt] = acc;
-            if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound how far LDS reads are hoisted (VGPR pressure)
-        }
-        // ---- mask + row max (lane holds query qidx, keys kt*16 + 4g + r)
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float v = sc[kt][r];
-                if (CAUSAL || kt >= NFULL) {      // resolved at compile time once the kt loop is unrolled
-                    const int kidx = kt * 16 + 4 * g + r;
-                    const bool ok = kidx < S && (!CAUSAL || kidx <= qidx);
-                    v = ok ? v : -INFINITY;
-                    sc[kt][r] = v;
-                }
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float nmx = -mx * sl2;
-        float sum = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float p = DBG == 3 ? sc[kt][r] : __builtin_amdgcn_exp2f(fmaf(sc[kt][r], sl2, nmx));   // exp2(-inf) = 0
-                sc[kt][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
-        // ---- O^T = V^T . P^T
-        f32x4 o[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int u = 0; u < NKT / 2; ++u) {
-            const f32x4 p0 = sc[2 * u], p1 = sc[2 * u + 1];
-            const bf16x8 pf = bf16x8{(bf16_t)p0[0], (bf16_t)p0[1], (bf16_t)p0[2], (bf16_t)p0[3],
-                                     (bf16_t)p1[0], (bf16_t)p1[1], (bf16_t)p1[2], (bf16_t)p1[3]};
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                if constexpr (DBG != 4) {
-                    const bf16x8 a =
-                        *reinterpret_cast<const bf16x8*>(vt_lds + (dt * 16 + c) * C::VT_ROW + (4 * u + g) * 16);
-                    o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf, o[dt], 0, 0, 0);
-                } else {
-                    o[dt][0] += (float)pf[dt];
-                }
-            }
-            if (u % 3 == 2) __builtin_amdgcn_sched_barrier(0);
-        }
-        if (qidx < q_limit) {
-            const float inv = 1.0f / sum;
-            bf16_t* op = out + ((size_t)b * S + qidx) * d + h * DH + 4 * g;
-#pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const f32x4 v = o[dt] * inv;
-                *reinterpret_cast<bf16x4*>(op + dt * 16) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
-            }
-        }
+    // ---- queries: NQ = 2 tiles (32 queries) per step share every K / V^T fragment read from LDS (the loop is
+    // LDS-bandwidth bound: 72 ds_read_b128 per 16-query tile); an odd last tile runs alone on a rotating wave.
+    const int nqt = DBG == 5 ? 0 : (q_limit + 15) >> 4;      // only the first q_limit query rows are computed and stored
+    AttnCtx cx{base, out + (size_t)b * S * d + h * DH, k_lds, vt_lds, S, q_limit, ld, d, g, c};
+    if constexpr (NQ2) {
+        const int npair = nqt >> 1;
+        for (int qp = wave; qp < npair; qp += 4) attn_tiles<NKT, CAUSAL, NFULL, DBG, 2>(cx, 2 * qp);
+        if ((nqt & 1) && wave == ((blockIdx.x + npair) & 3)) attn_tiles<NKT, CAUSAL, NFULL, DBG, 1>(cx, nqt - 1);
+    } else {
+        for (int qt = wave; qt < nqt; qt += 4) attn_tiles<NKT, CAUSAL, NFULL, DBG, 1>(cx, qt);
     }
 }
 

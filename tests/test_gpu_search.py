@@ -191,3 +191,39 @@ def test_full_size_half_million_properties():
     mism = int((Iq.cpu() != Io).sum())
     report("search_full_size", n=n, index_mismatches=mism, d_maxabs=max_abs(Dq, Do))
     assert mism == 0 and max_abs(Dq, Do) <= D_ATOL
+
+
+def test_two_million_keys_sharded_like_config5():
+    """BASELINE config 5 size: 2 M x 768 keys.  Built from four 0.5 M chunks (incremental add), searched whole on one
+    GPU and as 8 row shards with the 8 ranks' queries batched (1,024 queries per shard search) + (D, id) merge:
+    both exact against the oracle on a query subset, self-retrieval on all."""
+    dim, chunk = 768, 500000
+    parts = [O.synth_database(chunk, dim, seed=2002 + i) for i in range(4)]
+    idx = keds_amd.FlatIndex(dim)
+    for p in parts:
+        idx.add(p)
+    n = idx.ntotal
+    assert n == 4 * chunk
+    rows = torch.arange(0, n, n // 1024)[:1024]
+    q = torch.stack([parts[int(r) // chunk][int(r) % chunk] for r in rows]).cuda()
+    D, I, _ = idx.search_device(q, 10)
+    assert torch.equal(I[:, 0].cpu(), rows) and float(D[:, 0].abs().max()) <= 1e-6
+    assert bool((D[:, 1:] >= D[:, :-1]).all())
+    # 8 shards, each searched for all 1,024 queries, merged
+    Dp, Ip = [], []
+    for r in range(8):
+        lo, hi = shard_bounds(n, 8, r)
+        sh = keds_amd.FlatIndex(dim, row0=lo)
+        sh.add(idx.rows[lo:hi])
+        d, i, _ = sh.search_device(q, 10)
+        Dp.append(d)
+        Ip.append(i)
+        del sh
+    Dm, Im = ops.topk_merge_parts(torch.stack(Dp), torch.stack(Ip), _lib.METRIC_L2)
+    assert torch.equal(Im, I) and torch.equal(Dm, D)
+    # oracle on 4 fresh queries (fp64 brute force over 2 M rows, ~10 s of CPU)
+    qq = O.synth_database(4, dim, seed=3003)
+    Dq, Iq, _ = idx.search_device(qq.cuda(), 10)
+    Do, Io = O.flat_l2_search(torch.cat(parts), qq, 10)
+    report("search_2M", n=n, index_mismatches=int((Iq.cpu() != Io).sum()), d_maxabs=max_abs(Dq, Do))
+    assert torch.equal(Iq.cpu(), Io) and max_abs(Dq, Do) <= D_ATOL
