@@ -30,7 +30,7 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 1
+#define KEDS_ABI_VERSION 2
 
 int keds_abi_version(void);
 const char* keds_last_error(void);
@@ -125,6 +125,17 @@ int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery
 #define KEDS_EPI_BIAS_RESID_F32 3   /* out f32 += acc + bias (in place)      (model.py:324-325) */
 #define KEDS_EPI_BIAS_F32 4         /* out f32 = acc + bias */
 #define KEDS_EPI_PATCH_F32 5        /* out f32 row (m/G)*(G+1)+1+m%G = acc + aux[1+m%G]  (model.py:394-398) */
+/* LayerNorm folded into the neighbouring GEMMs (ln_1 -> in_proj, ln_2 -> c_fc, model.py:305-326): the producer of the
+ * residual stream also emits a bf16 copy of it and per-row {sum, sum of squares}; the consumer multiplies the UN-normalised
+ * rows with W.diag(gamma) and finishes LayerNorm per output element:
+ *     LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (b + W beta),   W' = bf16(W diag(gamma))
+ * so the 2 x layers LayerNorm passes over the residual stream disappear (keds_fold_layernorm builds W', colsum, b'). */
+#define KEDS_EPI_LN_BIAS_BF16 6     /* out bf16 = rstd[m] (acc - mean[m] csum[n]) + bias'[n];  bias = [bias'(N) | csum(N)],
+                                       aux = row stats fp32 [M,2] of A's rows (LayerNorm width = K),
+                                       aux2 (nullable) = fp32 [M,2] buffer that is ZEROED for this launch's rows */
+#define KEDS_EPI_LN_QGELU_BF16 7    /* same, then QuickGELU */
+#define KEDS_EPI_RESID_STATS_F32 8  /* out f32 += acc + bias (in place); aux2 = bf16 copy [M,N] of the new rows;
+                                       aux = fp32 [M,2] += {sum, sum sq} of the new rows (atomic; zeroed by the caller) */
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W bf16 row-major (W is the nn.Linear
  * weight as stored).  N % 128 == 0, K % 64 == 0; rows of A / out up to the next multiple of
@@ -136,6 +147,19 @@ int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int
  * past M are never read */
 int keds_gemm_bt_ex(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
                     int M, int N, int K, int epilogue, const float* aux, int aux_i, void* stream);
+
+/* same with the second auxiliary pointer the KEDS_EPI_LN_* / KEDS_EPI_RESID_STATS_F32 epilogues use */
+int keds_gemm_bt_ex2(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                     int M, int N, int K, int epilogue, const float* aux, int aux_i, void* aux2, void* stream);
+
+/* Fold a LayerNorm (gamma, beta over K) into the nn.Linear that consumes it: W fp32 [N,K], bias fp32 [N] (nullable) ->
+ * w_folded bf16 [N,K] = W diag(gamma), bias_csum fp32 [2N] = [bias + W beta | row sums of w_folded (as rounded)]. */
+int keds_fold_layernorm(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                        void* w_folded, float* bias_csum, void* stream);
+
+/* Row statistics + bf16 copy of a residual stream (what KEDS_EPI_RESID_STATS_F32 emits, for the first block):
+ * x fp32 [rows, dim] dense -> xb bf16 [rows, dim], stats fp32 [rows,2] = {sum, sum of squares}. */
+int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim, void* stream);
 
 /* Optional split-K scratch (fp32, 32 MiB is enough for every shape of the path).  Launches with fewer than ~64 output
  * tiles (remainder rows, M <= 256) then split K over up to 16 workgroups per tile and reduce in a second tiny kernel;
@@ -199,6 +223,11 @@ typedef struct {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;     /* fp32 [d] */
     const void *qkv_w, *out_w, *fc_w, *proj_w;      /* bf16 [3d,d] [d,d] [4d,d] [d,4d] */
     const float *qkv_b, *out_b, *fc_b, *proj_b;     /* fp32 */
+    /* optional (all four or none): ln_1 folded into in_proj and ln_2 into c_fc by keds_fold_layernorm.  When present
+     * the tower runs without LayerNorm passes (KEDS_EPI_LN_* / KEDS_EPI_RESID_STATS_F32); qkv_w / fc_w and the ln
+     * parameters are still needed (CLS-only last block). */
+    const void *qkv_wf, *fc_wf;                     /* bf16 [3d,d], [4d,d] */
+    const float *qkv_bc, *fc_bc;                    /* fp32 [2*3d], [2*4d]: folded bias | column sums */
 } keds_block_params;
 
 typedef struct {

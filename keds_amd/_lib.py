@@ -17,9 +17,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 
 # ---- constants mirrored from keds_hip.h ------------------------------------------------------
-ABI_VERSION = 1
+ABI_VERSION = 2
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
+EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32 = 6, 7, 8
 PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
 SCAN_MAX_K = 16
 
@@ -28,7 +29,7 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 class BlockParams(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "out_w", "fc_w", "proj_w",
-                                  "qkv_b", "out_b", "fc_b", "proj_b")]
+                                  "qkv_b", "out_b", "fc_b", "proj_b", "qkv_wf", "fc_wf", "qkv_bc", "fc_bc")]
 
 
 class TowerParams(C.Structure):
@@ -119,6 +120,9 @@ SIGNATURES = {
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "keds_gemm_set_workspace": (i32, [vp, sz]),
     "keds_gemm_force_small": (i32, [i32]),
+    "keds_gemm_bt_ex2": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp]),
+    "keds_fold_layernorm": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
+    "keds_rowstats_cast": (i32, [vp, vp, vp, i32, i32, vp]),
     "keds_gemm_bt_ex": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "keds_attention_debug": (i32, [i32]),

@@ -71,6 +71,60 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// one wave per row: bf16 copy + {sum, sum of squares} of a residual-stream row (what the RESID_STATS GEMM epilogue
+// emits for every later block; this kernel provides them for the first one)
+__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb,
+                                                            float* __restrict__ stats, int rows, int dim) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    const float* p = x + (size_t)r * dim;
+    f32x4 v[LN_MAXV];
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = j * 256 + lane * 4;
+        v[j] = i < dim ? *reinterpret_cast<const f32x4*>(p + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXV; ++j) {
+        const int i = j * 256 + lane * 4;
+        s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+        q += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+        if (i < dim)
+            *reinterpret_cast<bf16x4*>(xb + (size_t)r * dim + i) =
+                bf16x4{(bf16_t)v[j][0], (bf16_t)v[j][1], (bf16_t)v[j][2], (bf16_t)v[j][3]};
+    }
+    s = wave_sum(s);
+    q = wave_sum(q);
+    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)r) = float2{s, q};
+}
+
+// one wave per output row n of W [N,K]: w_folded = bf16(W * gamma), csum = sum of the ROUNDED products (what the MFMA
+// will multiply the row mean with), bias' = bias + W . beta in fp32
+__global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int N, int K,
+                                                             bf16_t* __restrict__ wf, float* __restrict__ bias_csum) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float cs = 0.f, bb = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        const float w = W[(size_t)n * K + k];
+        const bf16_t f = (bf16_t)(w * gamma[k]);
+        wf[(size_t)n * K + k] = f;
+        cs += (float)f;
+        bb += w * beta[k];
+    }
+    cs = wave_sum(cs);
+    bb = wave_sum(bb);
+    if (lane == 0) {
+        bias_csum[n] = (bias ? bias[n] : 0.f) + bb;
+        bias_csum[N + n] = cs;
+    }
+}
+
 // one block per output row (b, patch); columns c*P*P + ky*P + kx, zero padded to Kpad
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int R,
                                                      int P, int Kpad) {
@@ -280,4 +334,21 @@ extern "C" int keds_cast_bf16(const float* x, void* out, int64_t count, void* st
     if (blocks < 1) blocks = 1;
     cast_bf16_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(x, (bf16_t*)out, count);
     return keds_check_launch("cast_bf16_kernel");
+}
+
+extern "C" int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim, void* stream) {
+    KEDS_REQUIRE(x && xb && stats && rows > 0, "keds_rowstats_cast: bad argument");
+    KEDS_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= 256 * LN_MAXV, "keds_rowstats_cast: dim %d unsupported", dim);
+    hipStream_t st = (hipStream_t)stream;
+    KedsProfScope prof(KEDS_PROF_LN, st);
+    rowstats_cast_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, (bf16_t*)xb, stats, rows, dim);
+    return keds_check_launch("rowstats_cast_kernel");
+}
+
+extern "C" int keds_fold_layernorm(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                                   void* w_folded, float* bias_csum, void* stream) {
+    KEDS_REQUIRE(W && gamma && beta && w_folded && bias_csum && N > 0 && K > 0, "keds_fold_layernorm: bad argument");
+    fold_layernorm_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(W, bias, gamma, beta, N, K, (bf16_t*)w_folded,
+                                                                        bias_csum);
+    return keds_check_launch("fold_layernorm_kernel");
 }

@@ -77,6 +77,114 @@ __device__ __forceinline__ void epilogue_store(f32x4 v0, f32x4 v1, void* __restr
     }
 }
 
+constexpr bool epi_is_ln(int e) { return e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_QGELU_BF16; }
+constexpr int epi_base(int e) {
+    return e == KEDS_EPI_LN_BIAS_BF16 ? KEDS_EPI_BIAS_BF16 : e == KEDS_EPI_LN_QGELU_BF16 ? KEDS_EPI_BIAS_QGELU_BF16 : e;
+}
+constexpr float LN_EPS = 1e-5f;
+
+// LayerNorm statistics of row m from {sum, sum of squares}: returns (rstd, -mean * rstd)
+__device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats, int m, float invk, float& rstd, float& nmr) {
+    const float s = stats[2 * (size_t)m], ss = stats[2 * (size_t)m + 1];
+    const float mean = s * invk;
+    const float var = fmaxf(ss * invk - mean * mean, 0.f);
+    rstd = rsqrtf(var + LN_EPS);
+    nmr = -mean * rstd;
+}
+
+__device__ __forceinline__ float sum8(f32x4 a, f32x4 b) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])); }
+
+// Epilogue of one wave's accumulator tile, shared by the 128^2 and 256^2 kernels: lane (g, c) owns rows
+// m_lane + 16*mi (mi < MI) and columns n_lane + 32*p + 0..7 (p = 0, 1) held in acc[2p][mi], acc[2p+1][mi].
+template <int EPI, int MI>
+__device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* __restrict__ bias, void* __restrict__ out,
+                                              int m_lane, int M, int n_lane, int N, int K, const float* __restrict__ aux,
+                                              int aux_i, void* __restrict__ aux2, long long ldc, bool zero_lane) {
+    if constexpr (epi_is_ln(EPI)) {
+        const float invk = 1.0f / (float)K;
+        float rstd[MI], nmr[MI];
+        float* zero = reinterpret_cast<float*>(aux2);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m_lane + 16 * mi;
+            ln_row_coeff(aux, m < M ? m : M - 1, invk, rstd[mi], nmr[mi]);
+            if (zero && zero_lane && m < M) *reinterpret_cast<float2*>(zero + 2 * (size_t)m) = float2{0.f, 0.f};
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int n = n_lane + 32 * p;
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + n), b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + N + n), c1 = *reinterpret_cast<const f32x4*>(bias + N + n + 4);
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m_lane + 16 * mi;
+                if (m >= M) continue;
+                epilogue_store<epi_base(EPI)>(acc[2 * p][mi] * rstd[mi] + (c0 * nmr[mi] + b0),
+                                              acc[2 * p + 1][mi] * rstd[mi] + (c1 * nmr[mi] + b1), out, m, n, N, nullptr, 0, ldc);
+            }
+        }
+    } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F32) {
+        float* stats = const_cast<float*>(aux);
+        bf16_t* xb = reinterpret_cast<bf16_t*>(aux2);
+        f32x4 b[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            b[p][0] = b[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                b[p][0] = *reinterpret_cast<const f32x4*>(bias + n_lane + 32 * p);
+                b[p][1] = *reinterpret_cast<const f32x4*>(bias + n_lane + 32 * p + 4);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m_lane + 16 * mi;
+            const bool valid = m < M;
+            float s = 0.f, ss = 0.f;
+            if (valid) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int n = n_lane + 32 * p;
+                    float* o = reinterpret_cast<float*>(out) + (size_t)m * ldc + n;
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(o) + (acc[2 * p][mi] + b[p][0]);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(o + 4) + (acc[2 * p + 1][mi] + b[p][1]);
+                    *reinterpret_cast<f32x4*>(o) = v0;
+                    *reinterpret_cast<f32x4*>(o + 4) = v1;
+                    *reinterpret_cast<bf16x8*>(xb + (size_t)m * N + n) =
+                        bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                               (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+                    s += sum8(v0, v1);
+                    ss += sum8(v0 * v0, v1 * v1);
+                }
+            }
+            // the four lanes (g = 0..3) that share row m hold this wave's 64 columns of it
+            s += __shfl_xor(s, 16, 64);
+            ss += __shfl_xor(ss, 16, 64);
+            s += __shfl_xor(s, 32, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            if (valid && zero_lane) {
+                unsafeAtomicAdd(stats + 2 * (size_t)m, s);
+                unsafeAtomicAdd(stats + 2 * (size_t)m + 1, ss);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int n = n_lane + 32 * p;
+            f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+            if (bias) {
+                b0 = *reinterpret_cast<const f32x4*>(bias + n);
+                b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+            }
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int m = m_lane + 16 * mi;
+                if (m >= M) continue;
+                epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
+            }
+        }
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void small_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -102,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
                                                          int M, int N, int K, int n_tiles,
                                                          const float* __restrict__ aux, int aux_i,
                                                          float* __restrict__ part, int k_len, int tiles, int m_pad,
-                                                         long long lda, long long ldc) {
+                                                         long long lda, long long ldc, void* __restrict__ aux2) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = part ? bid_all / tiles : 0;
@@ -221,10 +329,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
 #undef KEDS_SM_G
 
     // ---- epilogue: lane (g,c) owns rows m = m0 + 64*wm + 16*mi + c, columns n0 + 64*wn + 32*p + 8*g + 0..7
+    if (part) {   // split-K slice: raw fp32 accumulators
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int n = n0 + 64 * wn + 32 * p + 8 * g;
-        if (part) {   // split-K slice: raw fp32 accumulators
+        for (int p = 0; p < 2; ++p) {
+            const int n = n0 + 64 * wn + 32 * p + 8 * g;
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m = m0 + 64 * wm + 16 * mi + c;
@@ -232,43 +340,74 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
                 *reinterpret_cast<f32x4*>(o) = acc[2 * p][mi];
                 *reinterpret_cast<f32x4*>(o + 4) = acc[2 * p + 1][mi];
             }
-            continue;
         }
-        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (bias) {
-            b0 = *reinterpret_cast<const f32x4*>(bias + n);
-            b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m = m0 + 64 * wm + 16 * mi + c;
-            if (m >= M) continue;
-            epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
-        }
+        return;
     }
+    // zero_lane: LN epilogues: the one wave column that clears the other stats buffer; RESID_STATS: the lane that adds
+    const bool zl = epi_is_ln(EPI) ? (n0 == 0 && wn == 0 && g == 0) : (g == 0);
+    tile_epilogue<EPI, 4>(acc, bias, out, m0 + 64 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, ldc, zl);
 }
 
 // sum the split-K slices, add bias, apply the epilogue; one thread per 8 consecutive outputs of one row
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
                                                                  const float* __restrict__ bias, void* __restrict__ out,
-                                                                 int M, int N, const float* __restrict__ aux, int aux_i,
-                                                                 long long ldc) {
+                                                                 int M, int N, int K, const float* __restrict__ aux, int aux_i,
+                                                                 long long ldc, void* __restrict__ aux2) {
     const int per_row = N >> 3;
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= M * per_row) return;
     const int m = id / per_row, n = (id - m * per_row) << 3;
     f32x4 v0 = f32x4{0.f, 0.f, 0.f, 0.f}, v1 = v0;
-    if (bias) {
-        v0 = *reinterpret_cast<const f32x4*>(bias + n);
-        v1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-    }
     for (int s = 0; s < splits; ++s) {
         const float* p = part + ((size_t)s * m_pad + m) * N + n;
         v0 += *reinterpret_cast<const f32x4*>(p);
         v1 += *reinterpret_cast<const f32x4*>(p + 4);
     }
-    epilogue_store<EPI>(v0, v1, out, m, n, N, aux, aux_i, ldc);
+    f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (bias) {
+        b0 = *reinterpret_cast<const f32x4*>(bias + n);
+        b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+    }
+    if constexpr (epi_is_ln(EPI)) {
+        float rstd, nmr;
+        ln_row_coeff(aux, m, 1.0f / (float)K, rstd, nmr);
+        float* zero = reinterpret_cast<float*>(aux2);
+        if (zero && n == 0) *reinterpret_cast<float2*>(zero + 2 * (size_t)m) = float2{0.f, 0.f};
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + N + n), c1 = *reinterpret_cast<const f32x4*>(bias + N + n + 4);
+        epilogue_store<epi_base(EPI)>(v0 * rstd + (c0 * nmr + b0), v1 * rstd + (c1 * nmr + b1), out, m, n, N, nullptr, 0, ldc);
+    } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F32) {
+        float* o = reinterpret_cast<float*>(out) + (size_t)m * ldc + n;
+        v0 += *reinterpret_cast<const f32x4*>(o) + b0;
+        v1 += *reinterpret_cast<const f32x4*>(o + 4) + b1;
+        *reinterpret_cast<f32x4*>(o) = v0;
+        *reinterpret_cast<f32x4*>(o + 4) = v1;
+        *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(aux2) + (size_t)m * N + n) =
+            bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                   (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        float* stats = const_cast<float*>(aux);
+        float s = sum8(v0, v1), ss = sum8(v0 * v0, v1 * v1);
+        // lanes that are known to sit in one row (N % 512 == 0: the wave, N % 256 == 0: its halves) add once;
+        // per-thread atomics on one address serialise (measured 56 us for 128 x 1024 outputs)
+        const int seg = (per_row & 63) == 0 ? 64 : (per_row & 31) == 0 ? 32 : 1;   // lanes known to share the row
+        if (seg > 1) {
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                s += __shfl_xor(s, o, 64);
+                ss += __shfl_xor(ss, o, 64);
+            }
+            if (seg == 64) {
+                s += __shfl_xor(s, 32, 64);
+                ss += __shfl_xor(ss, 32, 64);
+            }
+        }
+        if ((threadIdx.x & (seg - 1)) == 0) {
+            unsafeAtomicAdd(stats + 2 * (size_t)m, s);
+            unsafeAtomicAdd(stats + 2 * (size_t)m + 1, ss);
+        }
+    } else {
+        epilogue_store<EPI>(v0 + b0, v1 + b1, out, m, n, N, aux, aux_i, ldc);
+    }
 }
 
 // ==========================================================================================
@@ -448,7 +587,7 @@ size_t g_ws_bytes = 0;
 
 template <int EPI, int NST>
 int launch_small_nst(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-                     int aux_i, int splits, long long lda, long long ldc, hipStream_t st) {
+                     int aux_i, void* aux2, int splits, long long lda, long long ldc, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)gemm_bt_kernel<EPI, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -464,16 +603,16 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
         const int m_pad = m_tiles * BM;
         gemm_bt_kernel<EPI, NST><<<tiles * splits, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
                                                                                M, N, K, n_tiles, aux, aux_i, g_ws,
-                                                                               K / splits, tiles, m_pad, lda, ldc);
+                                                                               K / splits, tiles, m_pad, lda, ldc, aux2);
         int rc = keds_check_launch("gemm_bt_kernel(split-K)");
         if (rc) return rc;
         const int threads = M * (N / 8);
-        gemm_splitk_reduce_kernel<EPI><<<(threads + 255) / 256, 256, 0, st>>>(g_ws, splits, m_pad, bias, out, M, N, aux,
-                                                                              aux_i, ldc);
+        gemm_splitk_reduce_kernel<EPI><<<(threads + 255) / 256, 256, 0, st>>>(g_ws, splits, m_pad, bias, out, M, N, K, aux,
+                                                                              aux_i, ldc, aux2);
         return keds_check_launch("gemm_splitk_reduce_kernel");
     }
     gemm_bt_kernel<EPI, NST><<<tiles, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0, lda, ldc);
+                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0, lda, ldc, aux2);
     return keds_check_launch("gemm_bt_kernel");
 }
 
@@ -481,7 +620,7 @@ int g_no_split = 0;   // test hook
 
 template <int EPI>
 int launch_small(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-                 int aux_i, long long lda, long long ldc, hipStream_t st) {
+                 int aux_i, void* aux2, long long lda, long long ldc, hipStream_t st) {
     const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
     // too few tiles to fill 256 CUs: split K so that ~128+ workgroups stream the weights in parallel
     if (tiles <= 64 && K >= 2048 && !g_no_split && g_ws) {   // at K = 1024 the second launch costs what the split saves
@@ -489,11 +628,11 @@ int launch_small(const void* A, const void* W, const float* bias, void* out, int
         while (splits < 16 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
         const size_t need = (size_t)splits * ((M + BM - 1) / BM * BM) * N * sizeof(float);
         if (splits > 1 && need <= g_ws_bytes)
-            return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, splits, lda, ldc, st);
+            return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, splits, lda, ldc, st);
     }
     // fewer workgroups than 2 per CU: nothing else hides the DMA latency, so use the deep ring
-    if (tiles < 512) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, 1, lda, ldc, st);
-    return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, 1, lda, ldc, st);
+    if (tiles < 512) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
+    return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
 }
 
 namespace pr {
@@ -512,7 +651,8 @@ template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int M, int N, int K, int n_tiles,
-                                                              const float* __restrict__ aux, int aux_i) {
+                                                              const float* __restrict__ aux, int aux_i,
+                                                              void* __restrict__ aux2) {
     using namespace pr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -630,21 +770,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 #undef KEDS_PAIR_G
 
     // ---- epilogue (same ownership as the ring kernel)
-#pragma unroll
-    for (int pp = 0; pp < 2; ++pp) {
-        const int n = n0 + 64 * wn + 32 * pp + 8 * g;
-        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (bias) {
-            b0 = *reinterpret_cast<const f32x4*>(bias + n);
-            b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + 128 * wm + 16 * mi + c;
-            if (m >= M) continue;
-            epilogue_store<EPI>(acc[2 * pp][mi] + b0, acc[2 * pp + 1][mi] + b1, out, m, n, N, aux, aux_i, N);
-        }
-    }
+    const bool zl = epi_is_ln(EPI) ? (n0 == 0 && wn == 0 && g == 0) : (g == 0);
+    tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
 
 int device_cus_gemm() {
@@ -664,7 +791,7 @@ int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
 
 template <int EPI>
 int launch_big(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-               int aux_i, hipStream_t st) {
+               int aux_i, void* aux2, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -696,6 +823,7 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
             return keds_check_launch("gemm_bt_big_kernel<dbg>");
         }
     }
+    if constexpr (EPI <= KEDS_EPI_PATCH_F32)
     if (g_debug_variant == 7) {   // A/B hook: the BK=32 ring kernel
         static bool ring_attr = false;
         if (!ring_attr) {
@@ -708,7 +836,7 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         return keds_check_launch("gemm_bt_big_kernel");
     }
     gemm_bt_pair_kernel<EPI><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
-                                                                            M, N, K, n_tiles, aux, aux_i);
+                                                                            M, N, K, n_tiles, aux, aux_i, aux2);
     return keds_check_launch("gemm_bt_pair_kernel");
 }
 
@@ -716,7 +844,7 @@ int g_force_small = 0;   // test hook: route everything through the 128^2 kernel
 
 template <int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
-                int aux_i, long long lda, long long ldc, hipStream_t st) {
+                int aux_i, void* aux2, long long lda, long long ldc, hipStream_t st) {
     KedsProfScope prof(KEDS_PROF_GEMM, st);
     // Large problems: full 256-row tiles go to the 256^2 kernel, the remainder rows (< 256) to the 128^2 one.
     // (ViT-L/14 at B=128: M = 32896 = 128*256 + 128, so 512..2048 big tiles = whole rounds on 256 CUs.)
@@ -726,13 +854,23 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     const long rounds = (bt + 255) / 256;
     const bool big_ok = !g_force_small && lda == K && ldc == N && N % big::TN == 0 && K % 64 == 0 && K >= 128 && bt >= 512 &&
                         bt * 100 >= rounds * 256 * 85 && (EPI != KEDS_EPI_PATCH_F32 || M % big::TM == 0);
-    if (!big_ok) return launch_small<EPI>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
+    if (!big_ok) return launch_small<EPI>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
     const int m_main = M / big::TM * big::TM;
-    int rc = launch_big<EPI>(A, W, bias, out, m_main, N, K, aux, aux_i, st);
+    int rc = launch_big<EPI>(A, W, bias, out, m_main, N, K, aux, aux_i, aux2, st);
     if (rc || m_main == M || g_skip_tail) return rc;
-    const size_t esz = (EPI == KEDS_EPI_BIAS_RESID_F32 || EPI == KEDS_EPI_BIAS_F32) ? 4 : 2;
+    const size_t esz = (EPI == KEDS_EPI_BIAS_RESID_F32 || EPI == KEDS_EPI_BIAS_F32 || EPI == KEDS_EPI_RESID_STATS_F32) ? 4 : 2;
+    // the remainder launch numbers its rows from 0: move the per-row side buffers along
+    const float* aux_t = aux;
+    void* aux2_t = aux2;
+    if constexpr (epi_is_ln(EPI)) {
+        aux_t = aux + 2 * (size_t)m_main;
+        if (aux2) aux2_t = (float*)aux2 + 2 * (size_t)m_main;
+    } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F32) {
+        aux_t = aux + 2 * (size_t)m_main;
+        aux2_t = (char*)aux2 + (size_t)m_main * N * 2;
+    }
     return launch_small<EPI>((const char*)A + (size_t)m_main * K * 2, W, bias, (char*)out + (size_t)m_main * N * esz,
-                             M - m_main, N, K, aux, aux_i, lda, ldc, st);
+                             M - m_main, N, K, aux_t, aux_i, aux2_t, lda, ldc, st);
 }
 
 }  // namespace
@@ -753,8 +891,8 @@ extern "C" int keds_gemm_force_small(int on) {
     return KEDS_OK;
 }
 
-extern "C" int keds_gemm_bt_ex(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
-                               int M, int N, int K, int epilogue, const float* aux, int aux_i, void* stream) {
+extern "C" int keds_gemm_bt_ex2(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                                int M, int N, int K, int epilogue, const float* aux, int aux_i, void* aux2, void* stream) {
     KEDS_REQUIRE(A && W && out, "keds_gemm_bt: null pointer");
     KEDS_REQUIRE(M > 0 && N > 0 && K > 0, "keds_gemm_bt: empty problem");
     KEDS_REQUIRE(N % BN == 0, "keds_gemm_bt: N=%d must be a multiple of %d", N, BN);
@@ -762,23 +900,36 @@ extern "C" int keds_gemm_bt_ex(const void* A, int64_t lda, const void* W, const 
     KEDS_REQUIRE(lda >= K && ldc >= N && lda % 8 == 0 && ldc % 8 == 0, "keds_gemm_bt: bad row strides");
     KEDS_REQUIRE(epilogue != KEDS_EPI_PATCH_F32 || ldc == N, "keds_gemm_bt: EPI_PATCH needs a dense output");
     hipStream_t st = (hipStream_t)stream;
+#define KEDS_GEMM_CASE(E) case E: return launch_gemm<E>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
     switch (epilogue) {
-        case KEDS_EPI_BIAS_BF16: return launch_gemm<KEDS_EPI_BIAS_BF16>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
-        case KEDS_EPI_BIAS_QGELU_BF16:
-            return launch_gemm<KEDS_EPI_BIAS_QGELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
-        case KEDS_EPI_BIAS_RELU_BF16:
-            return launch_gemm<KEDS_EPI_BIAS_RELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
-        case KEDS_EPI_BIAS_RESID_F32:
-            return launch_gemm<KEDS_EPI_BIAS_RESID_F32>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
-        case KEDS_EPI_BIAS_F32: return launch_gemm<KEDS_EPI_BIAS_F32>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
+        KEDS_GEMM_CASE(KEDS_EPI_BIAS_BF16)
+        KEDS_GEMM_CASE(KEDS_EPI_BIAS_QGELU_BF16)
+        KEDS_GEMM_CASE(KEDS_EPI_BIAS_RELU_BF16)
+        KEDS_GEMM_CASE(KEDS_EPI_BIAS_RESID_F32)
+        KEDS_GEMM_CASE(KEDS_EPI_BIAS_F32)
         case KEDS_EPI_PATCH_F32:
             KEDS_REQUIRE(aux && aux_i > 0, "keds_gemm_bt: EPI_PATCH needs the positional embedding and G");
-            return launch_gemm<KEDS_EPI_PATCH_F32>(A, W, bias, out, M, N, K, aux, aux_i, lda, ldc, st);
+            return launch_gemm<KEDS_EPI_PATCH_F32>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
+        case KEDS_EPI_LN_BIAS_BF16:
+        case KEDS_EPI_LN_QGELU_BF16:
+            KEDS_REQUIRE(bias && aux, "keds_gemm_bt: EPI_LN_* needs bias = [bias' | colsum] and aux = row statistics");
+            if (epilogue == KEDS_EPI_LN_BIAS_BF16)
+                return launch_gemm<KEDS_EPI_LN_BIAS_BF16>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
+            return launch_gemm<KEDS_EPI_LN_QGELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
+        case KEDS_EPI_RESID_STATS_F32:
+            KEDS_REQUIRE(aux && aux2, "keds_gemm_bt: EPI_RESID_STATS needs aux = statistics and aux2 = bf16 copy");
+            return launch_gemm<KEDS_EPI_RESID_STATS_F32>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
         default: keds_set_error("keds_gemm_bt: unknown epilogue %d", epilogue); return KEDS_E_ARG;
     }
+#undef KEDS_GEMM_CASE
+}
+
+extern "C" int keds_gemm_bt_ex(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,
+                               int M, int N, int K, int epilogue, const float* aux, int aux_i, void* stream) {
+    return keds_gemm_bt_ex2(A, lda, W, bias, out, ldc, M, N, K, epilogue, aux, aux_i, nullptr, stream);
 }
 
 extern "C" int keds_gemm_bt(const void* A, const void* W, const float* bias, void* out, int M, int N, int K,
                             int epilogue, const float* aux, int aux_i, void* stream) {
-    return keds_gemm_bt_ex(A, K, W, bias, out, N, M, N, K, epilogue, aux, aux_i, stream);
+    return keds_gemm_bt_ex2(A, K, W, bias, out, N, M, N, K, epilogue, aux, aux_i, nullptr, stream);
 }

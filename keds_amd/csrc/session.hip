@@ -198,6 +198,26 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
         p.fc_w = m;
         if ((rc = L.mat<bf16_t>(b + "mlp.c_proj.weight", width, 4 * width, &m))) return rc;
         p.proj_w = m;
+        // ln_1 folded into in_proj, ln_2 into c_fc (keds_fold_layernorm): fp32 copies of the two weights are temporary
+        Arena tmp;
+        Loader T{L.w, tmp, L.what};
+        const float *wq, *wf;
+        if ((rc = T.mat<float>(b + "attn.in_proj_weight", 3 * width, width, &wq)) ||
+            (rc = T.mat<float>(b + "mlp.c_fc.weight", 4 * width, width, &wf)))
+            return rc;
+        void* qf = L.mem.alloc((size_t)3 * width * width * 2);
+        void* ff = L.mem.alloc((size_t)4 * width * width * 2);
+        float* qb = (float*)L.mem.alloc((size_t)2 * 3 * width * sizeof(float));
+        float* fb = (float*)L.mem.alloc((size_t)2 * 4 * width * sizeof(float));
+        KEDS_REQUIRE(qf && ff && qb && fb, "%s: out of device memory", L.what);
+        if ((rc = keds_fold_layernorm(wq, p.qkv_b, p.ln1_g, p.ln1_b, 3 * width, width, qf, qb, nullptr)) ||
+            (rc = keds_fold_layernorm(wf, p.fc_b, p.ln2_g, p.ln2_b, 4 * width, width, ff, fb, nullptr)))
+            return rc;
+        HIP_TRY(hipDeviceSynchronize(), L.what);
+        p.qkv_wf = qf;
+        p.fc_wf = ff;
+        p.qkv_bc = qb;
+        p.fc_bc = fb;
     }
     return KEDS_OK;
 }

@@ -14,10 +14,13 @@ namespace {
 
 size_t pad_rows(size_t m) { return keds_align_up(m, 128); }
 
-// scratch of one tower: h [Mp,w] bf16 | big [Mp,4w] bf16 (qkv [Mp,3w] + attn [Mp,w], later the MLP hidden)
+// scratch of one tower: h [Mp,w] bf16 | big [Mp,4w] bf16 (qkv [Mp,3w] + attn [Mp,w], later the MLP hidden) |
+// two row-statistics buffers [Mp,2] fp32 (LayerNorm folded into the GEMMs: ln_1 / ln_2 statistics)
 struct TowerWs {
     char* h;
     char* big;
+    float* st1;
+    float* st2;
     size_t bytes;
 };
 
@@ -27,9 +30,12 @@ TowerWs carve_tower(void* ws, int width, int seq, int B) {
     char* p = (char*)ws;
     const size_t hb = keds_align_up(Mp * width * 2, 256);
     const size_t bb = keds_align_up(Mp * (size_t)width * 4 * 2, 256);
+    const size_t sb = keds_align_up(Mp * 2 * sizeof(float), 256);
     t.h = p;
     t.big = p ? p + hb : nullptr;
-    t.bytes = hb + bb;
+    t.st1 = p ? (float*)(p + hb + bb) : nullptr;
+    t.st2 = p ? (float*)(p + hb + bb + sb) : nullptr;
+    t.bytes = hb + bb + 2 * sb;
     return t;
 }
 
@@ -42,11 +48,27 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
     void* att = t.big + Mp * (size_t)w * 3 * 2;  // [Mp, w]
     void* hid = t.big;                         // [Mp, 4w] (aliases qkv|att, both dead by then)
     int rc;
+    // LayerNorm folded into the GEMMs (keds_hip.h, KEDS_EPI_LN_*): t.h holds the bf16 copy of the residual stream,
+    // st1 / st2 the {sum, sum sq} of its rows as seen by ln_1 / ln_2.  Each LN-consuming GEMM also clears the
+    // statistics buffer the next producer accumulates into, so no memset sits between the launches.
+    bool folded = true;
     for (int l = 0; l < p->layers; ++l) {
         const keds_block_params& k = p->blocks[l];
-        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
-        if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
-        if (l == p->layers - 1 && p->last_cls_only) {
+        folded = folded && k.qkv_wf && k.fc_wf && k.qkv_bc && k.fc_bc;
+    }
+    if (folded && (rc = keds_rowstats_cast(x, t.h, t.st1, M, w, st))) return rc;
+    for (int l = 0; l < p->layers; ++l) {
+        const keds_block_params& k = p->blocks[l];
+        const bool last = l == p->layers - 1;
+        if (folded) {
+            if ((rc = keds_gemm_bt_ex2(t.h, w, k.qkv_wf, k.qkv_bc, qkv, 3 * w, M, 3 * w, w, KEDS_EPI_LN_BIAS_BF16, t.st1, 0,
+                                       t.st2, st)))
+                return rc;
+        } else {
+            if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
+            if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
+        }
+        if (last && p->last_cls_only) {
             // After the last block only token 0 of every sample is read (ln_post(x[:,0,:]), model.py:412), so the
             // attention queries, out-proj, ln_2 and the MLP run on those B rows only (row stride S*w in x / attn).
             const long long ld = (long long)S * w;
@@ -62,12 +84,25 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
             break;
         }
         if ((rc = keds_attention(qkv, att, B, S, p->heads, p->causal, st))) return rc;
-        if ((rc = keds_gemm_bt(att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
-        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;
-        if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, hid, M, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st)))
-            return rc;
-        if ((rc = keds_gemm_bt(hid, k.proj_w, k.proj_b, x, M, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
-            return rc;
+        if (folded) {
+            if ((rc = keds_gemm_bt_ex2(att, w, k.out_w, k.out_b, x, w, M, w, w, KEDS_EPI_RESID_STATS_F32, t.st2, 0, t.h, st)))
+                return rc;
+            if ((rc = keds_gemm_bt_ex2(t.h, w, k.fc_wf, k.fc_bc, hid, 4 * w, M, 4 * w, w, KEDS_EPI_LN_QGELU_BF16, t.st2, 0,
+                                       t.st1, st)))
+                return rc;
+            // the last block's output feeds no further ln_1: plain residual update
+            if ((rc = keds_gemm_bt_ex2(hid, 4 * w, k.proj_w, k.proj_b, x, w, M, w, 4 * w,
+                                       last ? KEDS_EPI_BIAS_RESID_F32 : KEDS_EPI_RESID_STATS_F32, last ? nullptr : t.st1, 0,
+                                       last ? nullptr : t.h, st)))
+                return rc;
+        } else {
+            if ((rc = keds_gemm_bt(att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
+            if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;
+            if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, hid, M, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st)))
+                return rc;
+            if ((rc = keds_gemm_bt(hid, k.proj_w, k.proj_b, x, M, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
+                return rc;
+        }
     }
     return KEDS_OK;
 }

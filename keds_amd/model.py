@@ -88,6 +88,18 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
             fc_w=_bf16(blk.mlp.c_fc.weight), proj_w=_bf16(blk.mlp.c_proj.weight),
             qkv_b=_f32(blk.attn.in_proj_bias), out_b=_f32(blk.attn.out_proj.bias),
             fc_b=_f32(blk.mlp.c_fc.bias), proj_b=_f32(blk.mlp.c_proj.bias))
+        # ln_1 folded into in_proj, ln_2 into c_fc (keds_fold_layernorm): the tower then runs without LayerNorm passes
+        lib = load()
+        for name, lin_w, lin_b, ln in (("qkv", blk.attn.in_proj_weight, t["qkv_b"], ("ln1_g", "ln1_b")),
+                                       ("fc", blk.mlp.c_fc.weight, t["fc_b"], ("ln2_g", "ln2_b"))):
+            w32 = _f32(lin_w)
+            n, k = w32.shape
+            wf = torch.empty((n, k), dtype=torch.bfloat16, device=w32.device)
+            bc = torch.empty(2 * n, dtype=torch.float32, device=w32.device)
+            check(lib.keds_fold_layernorm(ptr(w32), ptr(lin_b), ptr(t[ln[0]]), ptr(t[ln[1]]), n, k, ptr(wf), ptr(bc),
+                                          stream()), "keds_fold_layernorm")
+            t[name + "_wf"], t[name + "_bc"] = wf, bc
+        torch.cuda.current_stream().synchronize()          # the fp32 temporaries die here
         for k, v in t.items():
             setattr(blocks[i], k, ptr(v))
         keep.append(t)

@@ -224,3 +224,82 @@ def test_gallery_ranking_and_recall_metric():
     mo = O.get_metrics_cirr(gal2, ref2, [f"{i}.png" for i in ri], names, [f"{i}.png" for i in ti])
     mg = keds_amd.get_metrics_cirr(gal2.cuda(), ref2.cuda(), [f"{i}.png" for i in ri], names, [f"{i}.png" for i in ti])
     assert mo == mg
+
+
+# ---- LayerNorm folded into the GEMMs (KEDS_EPI_LN_* / KEDS_EPI_RESID_STATS_F32) ------------------------------
+def _fold(w, b, gamma, beta):
+    lib = _lib.load()
+    n, k = w.shape
+    wf = torch.empty((n, k), dtype=torch.bfloat16, device="cuda")
+    bc = torch.empty(2 * n, dtype=torch.float32, device="cuda")
+    _lib.check(lib.keds_fold_layernorm(_lib.ptr(w), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), n, k, _lib.ptr(wf),
+                                       _lib.ptr(bc), _lib.stream()), "fold")
+    return wf, bc
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(700, 384, 256, "ln"), (33024 + 128, 3072, 1024, "ln"), (1500, 1024, 256, "gelu"),
+                                       (4224, 4096, 1024, "gelu")])
+def test_gemm_layernorm_epilogues_equal_layernorm_then_linear(M, N, K, epi):
+    """rstd (x W'^T - mean colsum W') + (b + W beta) == Linear(LayerNorm(x)): against torch fp32 on the GPU's own
+    rounded operands, and the second statistics buffer is cleared for exactly the rows of the launch."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, generator=g, device="cuda") * 1.7 + 0.3 * torch.randn(M, 1, generator=g, device="cuda")
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    gamma = 1 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    wf, bc = _fold(w, b, gamma, beta)
+    Mp = (M + 127) // 128 * 128
+    xb = torch.zeros((Mp, K), dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros((Mp, 2), device="cuda")
+    _lib.check(lib.keds_rowstats_cast(_lib.ptr(x), _lib.ptr(xb), _lib.ptr(stats), M, K, _lib.stream()), "rowstats")
+    assert torch.equal(xb[:M], x.to(torch.bfloat16))
+    assert torch.allclose(stats[:M, 0], x.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(stats[:M, 1], (x * x).sum(1), rtol=1e-5)
+    other = torch.full((Mp + 8, 2), 7.0, device="cuda")
+    out = torch.zeros((Mp, N), dtype=torch.bfloat16, device="cuda")
+    code = _lib.EPI_LN_BIAS_BF16 if epi == "ln" else _lib.EPI_LN_QGELU_BF16
+    _lib.ensure_gemm_workspace("cuda")
+    _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(xb), K, _lib.ptr(wf), _lib.ptr(bc), _lib.ptr(out), N, M, N, K, code,
+                                    _lib.ptr(stats), 0, _lib.ptr(other), _lib.stream()), "gemm ln")
+    assert bool((other[:M] == 0).all()) and bool((other[M:] == 7).all())
+    # reference on the rounded operands the kernel saw
+    xr = xb[:M].float()
+    mean, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + 1e-5)
+    want = rstd * (xr @ wf.float().t() - mean * wf.float().sum(1)[None, :]) + (b + w @ beta)[None, :]
+    if epi == "gelu":
+        want = want * torch.sigmoid(1.702 * want)
+    report(f"gemm_ln_{epi}", M=M, N=N, K=K, rel_l2=rel_l2(out[:M], want))
+    assert rel_l2(out[:M], want) <= 4e-3                       # bf16 output rounding
+    # and it IS LayerNorm + Linear (fp32 torch), up to the bf16 operand rounding
+    full = torch.nn.functional.layer_norm(x, (K,), gamma, beta) @ w.t() + b
+    if epi == "gelu":
+        full = full * torch.sigmoid(1.702 * full)
+    assert rel_l2(out[:M], full) <= 1.2e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 256), (33024 + 128, 1024, 1024), (128, 1024, 4096), (2000, 768, 3072)])
+def test_gemm_residual_stats_epilogue(M, N, K):
+    """x += a W^T + b in fp32, plus the bf16 copy and the per-row {sum, sum sq} the next folded LayerNorm needs
+    (256^2 kernel, 128^2 kernel, remainder rows and the split-K reduce all produce them)."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(K + M)
+    Mp = (M + 127) // 128 * 128
+    a = torch.zeros((Mp, K), dtype=torch.bfloat16, device="cuda")
+    a[:M] = (torch.randn(M, K, generator=g, device="cuda")).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    x = torch.zeros((Mp, N), device="cuda")
+    x[:M] = torch.randn(M, N, generator=g, device="cuda")
+    want = x[:M] + a[:M].float() @ w.float().t() + b
+    xb = torch.zeros((Mp, N), dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros((Mp, 2), device="cuda")
+    _lib.ensure_gemm_workspace("cuda")
+    _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x), N, M, N, K,
+                                    _lib.EPI_RESID_STATS_F32, _lib.ptr(stats), 0, _lib.ptr(xb), _lib.stream()), "gemm resid")
+    assert max_abs(x[:M], want) <= 2e-4
+    assert torch.equal(xb[:M], x[:M].to(torch.bfloat16))
+    assert torch.allclose(stats[:M, 0], x[:M].sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(stats[:M, 1], (x[:M] * x[:M]).sum(1), rtol=1e-4)
+    assert bool((stats[M:] == 0).all()) and bool((xb[M:] == 0).all())
