@@ -647,6 +647,13 @@ constexpr int LDS_BYTES = 2 * PBUF_BYTES;       // 128 KiB
 // SLOWER (out-proj main part 59 -> 67 us).  vmcnt retires in order and counts stores on gfx950, so every s_waitcnt that
 // guards a later K-tile also waits for the tile's epilogue store burst to drain (256 CUs x 128 KiB at once, ~8 us);
 // a freshly dispatched workgroup does not inherit that dependency.  Kept per-tile.
+// NOTE (measured, round 1, tools/micro/): what the K-loop is NOT bound by.  (a) DMA latency from beyond L2: with every
+// K-tile re-reading K-tile 0 (L2-hot) the kernel is not faster; LDS-DMA itself streams 59 B/clk/CU from L2.  (b) LDS
+// read bandwidth: dropping a third of the fragment reads changes nothing.  (c) The nominal matrix peak: a register-only
+// MFMA loop sustains 2.06 PFLOP/s on this chip (clock ~2.0 GHz under load), so 1.25-1.3 PF in this loop is ~62 % of the
+// practical peak; the vendor BLAS reaches 1.07 / 1.20 / 1.46 PF on the qkv / fc / proj shapes where this kernel does
+// 1.08 / 1.11 / 1.21.  A 4-wave variant (128 x 128 per wave, 256 accumulators pinned in AGPRs through inline-asm
+// MFMAs) was built and was not faster (1.29 vs 1.32 PF at 8192^3).
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
