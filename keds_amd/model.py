@@ -17,6 +17,7 @@ in the reference itself, App. B).
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -88,10 +89,15 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
             fc_w=_bf16(blk.mlp.c_fc.weight), proj_w=_bf16(blk.mlp.c_proj.weight),
             qkv_b=_f32(blk.attn.in_proj_bias), out_b=_f32(blk.attn.out_proj.bias),
             fc_b=_f32(blk.mlp.c_fc.bias), proj_b=_f32(blk.mlp.c_proj.bias))
-        # ln_1 folded into in_proj, ln_2 into c_fc (keds_fold_layernorm): the tower then runs without LayerNorm passes
+        # ln_1 folded into in_proj, ln_2 into c_fc (keds_fold_layernorm): the tower then runs without LayerNorm passes.
+        # The row statistics are accumulated with fp32 atomics (order varies run to run: last-bit differences in the
+        # embeddings); KEDS_DETERMINISTIC=1 keeps the separate LayerNorm kernels, which are bitwise reproducible.
         lib = load()
-        for name, lin_w, lin_b, ln in (("qkv", blk.attn.in_proj_weight, t["qkv_b"], ("ln1_g", "ln1_b")),
-                                       ("fc", blk.mlp.c_fc.weight, t["fc_b"], ("ln2_g", "ln2_b"))):
+        folds = (("qkv", blk.attn.in_proj_weight, t["qkv_b"], ("ln1_g", "ln1_b")),
+                 ("fc", blk.mlp.c_fc.weight, t["fc_b"], ("ln2_g", "ln2_b")))
+        if os.environ.get("KEDS_DETERMINISTIC", "0") == "1":
+            folds = ()
+        for name, lin_w, lin_b, ln in folds:
             w32 = _f32(lin_w)
             n, k = w32.shape
             wf = torch.empty((n, k), dtype=torch.bfloat16, device=w32.device)

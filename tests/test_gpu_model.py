@@ -268,3 +268,19 @@ def test_imgnet_and_coco_batch_bodies_against_oracle(tiny_model):
                                               database, id_split=265, **kw)
         for key in ("composed", "image", "mixture"):
             _assert_close(f"glue.{name}.{key}", got[key], want[key])
+
+
+def test_deterministic_switch_gives_bitwise_reproducible_embeddings(monkeypatch):
+    """KEDS_DETERMINISTIC=1 keeps the separate LayerNorm kernels (no fp32 atomics): two runs are the same bits, and the
+    result agrees with the default (LayerNorm folded into the GEMMs) path within the usual tolerance."""
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    g = dict(np.load(golden_path("clip_tiny.npz")))
+    img = torch.from_numpy(np.random.RandomState(3).standard_normal((40, 3, 56, 56)).astype(np.float32)).cuda()
+    fast = keds_amd.build_model(dict(sd), fp16=False).cuda().encode_image(img)
+    monkeypatch.setenv("KEDS_DETERMINISTIC", "1")
+    m = keds_amd.build_model(dict(sd), fp16=False).cuda()
+    a, b = m.encode_image(img), m.encode_image(img)
+    assert torch.equal(a, b)
+    assert m._engine().vit.tower.blocks[0].qkv_wf is None
+    _assert_close("deterministic.vs_folded", a, fast, cos_min=0.99995, rel_max=1e-2)
+    _assert_close("deterministic.golden", m.encode_image(torch.from_numpy(g["image"]).cuda()), g["encode_image"])
