@@ -161,6 +161,17 @@ int keds_fold_layernorm(const float* W, const float* bias, const float* gamma, c
  * x fp32 [rows, dim] dense -> xb bf16 [rows, dim], stats fp32 [rows,2] = {sum, sum of squares}. */
 int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim, void* stream);
 
+/* ---- MXFP8 (BASELINE config 5: fp8 encoders).  OCP e4m3 elements, one e8m0 scale per 32 consecutive K (OCP MX),
+ * multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 (block scales applied in hardware, 2x the bf16 MFMA rate).
+ * Scales are stored as [K/128][rows_pad] dwords: byte b of dword (t, r) scales elements 128 t + 32 b .. + 31 of row r. */
+size_t keds_mxfp8_scale_bytes(int rows_pad, int K);
+/* x fp32 or bf16 [rows, K] dense -> q fp8 [rows, K], scales as above.  K % 128 == 0. */
+int keds_quantize_mxfp8(const void* x, int x_is_bf16, int rows, int K, int rows_pad, void* q, void* scales, void* stream);
+/* out bf16 [M,N] = A . W^T + bias with A [M,K], W [N,K] in MXFP8 (m_pad / n_pad: row counts of the scale arrays).
+ * M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256. */
+int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
+                    const float* bias, void* out, int M, int N, int K, void* stream);
+
 /* Optional split-K scratch (fp32, 32 MiB is enough for every shape of the path).  Launches with fewer than ~64 output
  * tiles (remainder rows, M <= 256) then split K over up to 16 workgroups per tile and reduce in a second tiny kernel;
  * without it they run unsplit.  The buffer must stay valid until it is replaced; pass NULL to unregister. */

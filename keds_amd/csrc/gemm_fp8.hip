@@ -1,0 +1,263 @@
+// MXFP8 GEMM for BASELINE config 5 ("fp8 (CDNA4 MFMA) ViT-L/14 encoders"): OCP e4m3 elements with one e8m0 scale per
+// 32 consecutive K (OCP MX), multiplied by v_mfma_scale_f32_16x16x128_f8f6f4, which applies the block scales in
+// hardware and runs at twice the bf16 MFMA rate.
+//
+// Operand / scale lane maps of the instruction, measured with exact data (tools/micro/mx_layout_probe.hip,
+// mx_scale_probe.hip): lane l = (c = l & 15, g = l >> 4) holds, for row (A) / column (B) c, the 16 bytes
+// k = 16g .. 16g+15 in operand bytes 0..15 and k = 64 + 16g .. 64 + 16g + 15 in bytes 16..31, and ITS scale (byte 0 of
+// the scale VGPR) applies to the 32-element block k = 32g .. 32g+31 of that row.  A literal scale operand is mis-read;
+// scales must come from a VGPR.  So a 128-byte LDS row (one K-tile of 128 fp8) is read exactly like the bf16 kernel
+// reads its two K-steps (16-byte chunk g and chunk 4+g), and the whole 256 x 256 tile machinery of gemm.hip carries over
+// with one MFMA step per K-tile: same XOR swizzle, DMA pieces, W-row permutation, supertile mapping.
+//
+// Scales live in HBM as [K/128][rows] dwords (byte b of the dword of (k-tile, row) = block 4*ktile + b), so the 256 rows
+// of a tile are 1 KiB contiguous per K-tile and ride along as one extra LDS-DMA piece per operand.
+#include "keds_common.h"
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TKB = 128;         // K-tile = 128 fp8 = 128 bytes per LDS row
+constexpr int OP_BYTES = 256 * 128;                  // 32 KiB per operand per K-tile
+constexpr int SC_BYTES = 256 * 4;                    // scale dwords of one operand per K-tile
+constexpr int PBUF_BYTES = 2 * OP_BYTES + 2 * SC_BYTES;   // X | W | sX | sW
+constexpr int LDS_BYTES = 2 * PBUF_BYTES;            // 132 KiB
+
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+__device__ __forceinline__ int swz_f8(int row) { return (row >> 1) & 7; }
+// same W-row permutation as gemm.hip: a lane's accumulators of n-tiles (2p, 2p+1) are 8 consecutive output columns
+__device__ __forceinline__ int perm_w8(int R) {
+    const int t = R >> 4, i = R & 15;
+    return 64 * (t >> 2) + 32 * ((t >> 1) & 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
+}
+
+// ---- quantisation: one wave per row, lane handles 8 consecutive elements (4 lanes per 32-block) ---------------------
+template <bool IN_BF16>
+__global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const void* __restrict__ x, int rows, int K, int rows_pad,
+                                                             unsigned char* __restrict__ q, unsigned char* __restrict__ scales) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        float v[8];
+        if constexpr (IN_BF16) {
+            const bf16x8 t = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(x) + (size_t)r * K + k0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+        } else {
+            const float* p = reinterpret_cast<const float*>(x) + (size_t)r * K + k0;
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = a[j];
+                v[4 + j] = b[j];
+            }
+        }
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));       // the 4 lanes of one 32-element block
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        // OCP MX: shared exponent = floor(log2(amax)) - emax(e4m3 = 8); elements saturate at +-448
+        int e = amax > 0.f ? (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8 : -127;
+        e = e < -127 ? -127 : (e > 127 ? 127 : e);
+        const float inv = __uint_as_float((unsigned)(127 - e) << 23);            // 2^-e (e in [-127, 127] -> exponent field 0..254)
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j] * (e == -127 ? 0.f : inv), -448.f), 448.f);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
+        *reinterpret_cast<uint2*>(q + (size_t)r * K + k0) = uint2{lo, hi};
+        if ((lane & 3) == 0) {
+            const int blk = k0 >> 5;                                             // 32-element block index along K
+            scales[((size_t)(blk >> 2) * rows_pad + r) * 4 + (blk & 3)] = (unsigned char)(e + 127);
+        }
+    }
+}
+
+// ---- 256 x 256 x 128 MXFP8 tile kernel: 8 waves (2 along m x 4 along n, 128 x 64 outputs each) -----------------------
+// out bf16 [M,N] = A[M,K] . W[N,K]^T + bias
+__global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char* __restrict__ X, const unsigned char* __restrict__ sX,
+                                                            const unsigned char* __restrict__ W, const unsigned char* __restrict__ sW,
+                                                            const float* __restrict__ bias, bf16_t* __restrict__ out, int M, int N,
+                                                            int K, int n_tiles, int m_pad, int n_pad) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    const int m_tiles = gridDim.x / n_tiles;
+    if ((m_tiles & 7) == 0 && (n_tiles & 3) == 0) {                // 8 x 4 supertile per XCD (gemm.hip)
+        const int grp = bid >> 5, within = bid & 31;
+        const int gcols = n_tiles >> 2;
+        const int gm = grp / gcols, gn = grp - gm * gcols;
+        tm = gm * 8 + (within & 7);
+        tn = gn * 4 + (within >> 3);
+    } else {
+        tm = bid / n_tiles;
+        tn = bid - tm * n_tiles;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 3, wm = wave >> 2;
+    const int g = lane >> 4, c = lane & 15;
+
+    // ---- staging: data pieces as in the bf16 kernel (piece = 8 LDS rows; wave owns pieces wave + 8*i); waves 0 / 1
+    // also bring the 1 KiB of X / W scale dwords of the K-tile
+    const int R0 = 8 * wave + (lane >> 3);
+    const int sch = (lane & 7) ^ swz_f8(R0);
+    const unsigned char* xsrc = X + (size_t)(m0 + R0) * K + sch * 16;
+    const unsigned char* wsrc = W + (size_t)(n0 + perm_w8(R0)) * K + sch * 16;
+    const size_t rstride = (size_t)64 * K;
+    const unsigned char* ssrc = wave == 0 ? sX + ((size_t)m0 + lane * 4) * 4 : sW + ((size_t)n0 + lane * 4) * 4;
+    const size_t sstride = (size_t)(wave == 0 ? m_pad : n_pad) * 4;               // next K-tile's dwords
+    auto issue = [&](int p, int q) {
+        const int i = q & 3;
+        const unsigned char* src = (q < 4 ? xsrc : wsrc) + i * rstride + (size_t)p * TKB;
+        char* dst = smem + (p & 1) * PBUF_BYTES + (q < 4 ? 0 : OP_BYTES) + (wave + 8 * i) * 1024;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    auto issue_scales = [&](int p) {
+        if (wave < 2) {
+            char* dst = smem + (p & 1) * PBUF_BYTES + 2 * OP_BYTES + wave * SC_BYTES;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (size_t)p * sstride),
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+        }
+    };
+    const int f = (c >> 1) & 7;
+    const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
+    const int xrow = (128 * wm + c) * 128;                         // + mi * 2048
+    const int wrow = OP_BYTES + (64 * wn + c) * 128;               // + ni * 2048
+    // scale dwords: X row 128*wm + 16*mi + c; W LDS row R = 64*wn + 16*ni + c holds W row perm_w8(R & 63) + 64*(R >> 6)
+    const int sx_off = 2 * OP_BYTES + (128 * wm + c) * 4;          // + mi * 64
+    int sw_off[4];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) sw_off[ni] = 2 * OP_BYTES + SC_BYTES + (64 * wn + perm_w8(16 * ni + c)) * 4;
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int np = K / TKB;                                        // >= 2
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue(0, q);
+    issue_scales(0);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) issue(1, q);
+    issue_scales(1);
+
+    auto load_frag = [&](const char* buf, int row_off) {
+        i32x8 v;
+        const i32x4 lo = *reinterpret_cast<const i32x4*>(buf + row_off + slot0);
+        const i32x4 hi = *reinterpret_cast<const i32x4*>(buf + row_off + slot1);
+        v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
+        v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
+        return v;
+    };
+
+    for (int p = 0; p < np; ++p) {
+        const char* cb = smem + (p & 1) * PBUF_BYTES;
+        // tile p has landed when at most the pieces of tile p+1 are still in flight (9 per wave for waves 0/1, else 8;
+        // waiting for "<= 8 outstanding" is exact for waves 2..7 and one piece conservative for waves 0/1)
+        if (p + 1 < np) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        i32x8 wf[4];
+        int swv[4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            wf[ni] = load_frag(cb, wrow + ni * 2048);
+            swv[ni] = *reinterpret_cast<const int*>(cb + sw_off[ni]) >> (8 * g);
+        }
+        i32x8 xf = load_frag(cb, xrow);
+        int sxv = *reinterpret_cast<const int*>(cb + sx_off) >> (8 * g);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            i32x8 xn = xf;
+            int sxn = sxv;
+            if (mi < 7) {
+                xn = load_frag(cb, xrow + (mi + 1) * 2048);
+                sxn = *reinterpret_cast<const int*>(cb + sx_off + (mi + 1) * 64) >> (8 * g);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf, acc[ni][mi], 0, 0, 0, swv[ni], 0, sxv);
+            xf = xn;
+            sxv = sxn;
+        }
+        // every wave has read buffer p completely before it is refilled with tile p+2
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (p + 2 < np) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) issue(p + 2, q);
+            issue_scales(p + 2);
+        }
+    }
+
+    // ---- epilogue: lane (g,c) owns rows m0 + 128*wm + 16*mi + c, columns n0 + 64*wn + 32*pp + 8*g + 0..7
+#pragma unroll
+    for (int pp = 0; pp < 2; ++pp) {
+        const int n = n0 + 64 * wn + 32 * pp + 8 * g;
+        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        if (bias) {
+            b0 = *reinterpret_cast<const f32x4*>(bias + n);
+            b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + 128 * wm + 16 * mi + c;
+            if (m >= M) continue;
+            const f32x4 v0 = acc[2 * pp][mi] + b0, v1 = acc[2 * pp + 1][mi] + b1;
+            *reinterpret_cast<bf16x8*>(out + (size_t)m * N + n) =
+                bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                       (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t keds_mxfp8_scale_bytes(int rows_pad, int K) {
+    if (rows_pad <= 0 || K <= 0 || K % 128) return 0;
+    return (size_t)(K / 128) * rows_pad * 4;
+}
+
+extern "C" int keds_quantize_mxfp8(const void* x, int x_is_bf16, int rows, int K, int rows_pad, void* q, void* scales,
+                                   void* stream) {
+    KEDS_REQUIRE(x && q && scales && rows > 0, "keds_quantize_mxfp8: bad argument");
+    KEDS_REQUIRE(K % 128 == 0 && K >= 128 && rows_pad >= rows, "keds_quantize_mxfp8: K %% 128 == 0 and rows_pad >= rows");
+    hipStream_t st = (hipStream_t)stream;
+    if (x_is_bf16)
+        quantize_mxfp8_kernel<true><<<(rows + 3) / 4, 256, 0, st>>>(x, rows, K, rows_pad, (unsigned char*)q, (unsigned char*)scales);
+    else
+        quantize_mxfp8_kernel<false><<<(rows + 3) / 4, 256, 0, st>>>(x, rows, K, rows_pad, (unsigned char*)q, (unsigned char*)scales);
+    return keds_check_launch("quantize_mxfp8_kernel");
+}
+
+extern "C" int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
+                               const float* bias, void* out, int M, int N, int K, void* stream) {
+    KEDS_REQUIRE(Aq && As && Wq && Ws && out, "keds_gemm_mxfp8: null pointer");
+    KEDS_REQUIRE(M > 0 && M % TM == 0 && N > 0 && N % TN == 0, "keds_gemm_mxfp8: M and N must be multiples of 256 (M=%d N=%d)", M, N);
+    KEDS_REQUIRE(K % TKB == 0 && K >= 2 * TKB, "keds_gemm_mxfp8: K=%d must be a multiple of 128, >= 256", K);
+    KEDS_REQUIRE(m_pad >= M && n_pad >= N && m_pad % 4 == 0 && n_pad % 4 == 0, "keds_gemm_mxfp8: bad scale row padding");
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)gemm_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+            hipSuccess) {
+            keds_set_error("keds_gemm_mxfp8: cannot set dynamic LDS size");
+            return KEDS_E_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    KedsProfScope prof(KEDS_PROF_GEMM, st);
+    const int m_tiles = M / TM, n_tiles = N / TN;
+    gemm_mxfp8_kernel<<<m_tiles * n_tiles, 512, LDS_BYTES, st>>>((const unsigned char*)Aq, (const unsigned char*)As,
+                                                                 (const unsigned char*)Wq, (const unsigned char*)Ws, bias,
+                                                                 (bf16_t*)out, M, N, K, n_tiles, m_pad, n_pad);
+    return keds_check_launch("gemm_mxfp8_kernel");
+}
