@@ -165,6 +165,7 @@ int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim
  * multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 (block scales applied in hardware, 2x the bf16 MFMA rate).
  * Scales are stored as [K/128][rows_pad] dwords: byte b of dword (t, r) scales elements 128 t + 32 b .. + 31 of row r. */
 size_t keds_mxfp8_scale_bytes(int rows_pad, int K);
+int keds_mxfp8_debug(int variant);          /* timing-only ablation hook of the MXFP8 GEMM (0 = product path) */
 /* x fp32 or bf16 [rows, K] dense -> q fp8 [rows, K], scales as above.  K % 128 == 0. */
 int keds_quantize_mxfp8(const void* x, int x_is_bf16, int rows, int K, int rows_pad, void* q, void* scales, void* stream);
 /* out bf16 [M,N] = A . W^T + bias with A [M,K], W [N,K] in MXFP8 (m_pad / n_pad: row counts of the scale arrays).

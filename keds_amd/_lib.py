@@ -124,6 +124,7 @@ SIGNATURES = {
     "keds_fold_layernorm": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "keds_rowstats_cast": (i32, [vp, vp, vp, i32, i32, vp]),
     "keds_mxfp8_scale_bytes": (sz, [i32, i32]),
+    "keds_mxfp8_debug": (i32, [i32]),
     "keds_quantize_mxfp8": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "keds_gemm_mxfp8": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
     "keds_gemm_bt_ex": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),

@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const void* __restr
 
 // ---- 256 x 256 x 128 MXFP8 tile kernel: 8 waves (2 along m x 4 along n, 128 x 64 outputs each) -----------------------
 // out bf16 [M,N] = A[M,K] . W[N,K]^T + bias
+template <int DBG>
 __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char* __restrict__ X, const unsigned char* __restrict__ sX,
                                                             const unsigned char* __restrict__ W, const unsigned char* __restrict__ sW,
                                                             const float* __restrict__ bias, bf16_t* __restrict__ out, int M, int N,
@@ -147,9 +148,6 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(0, q);
     issue_scales(0);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) issue(1, q);
-    issue_scales(1);
 
     auto load_frag = [&](const char* buf, int row_off) {
         i32x8 v;
@@ -160,44 +158,86 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
         return v;
     };
 
+    // Ping-pong wave groups: the waves of one SIMD (w and w+4) run the two phases of a K-tile in opposite order inside
+    // each barrier interval,
+    //     group 0:  read fragments of tile p      -> multiply tile p
+    //     group 1:  multiply tile p-1 (registers) -> read fragments of tile p
+    // with a single barrier per K-tile; all fragments of a tile live in registers (96 VGPRs) between the phases and
+    // tile p+1 streams into the other buffer meanwhile.
+    // MEASURED (tools/bench_fp8.py, proj shape 32768 x 1024 x 4096): MFMA only 83 us, DMA + LDS reads only 84 us,
+    // everything 174 us -- the phases ADD even though they now overlap in time on every SIMD, and they added in the
+    // plain "read, then multiply" loop as well (82 + 98 = 178 us).  A register-only MFMA loop already holds only
+    // ~1.6 GHz: the chip is power-limited here, the clock falls when the LDS / DMA traffic runs under the MFMAs, and
+    // wall time follows the ENERGY per K-tile rather than the critical path.  What helps is fewer bytes moved per flop
+    // (fp8 itself: 1.3x over bf16 at K = 4096), not a tighter schedule.
+    const int grp = wave >> 2;
+    i32x8 wf[4], xf[8];
+    int swv[4], sxv[8];
+    auto multiply = [&]() {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                if constexpr (DBG == 2) acc[ni][mi][0] += __int_as_float(wf[ni][0] ^ xf[mi][3] ^ swv[ni] ^ sxv[mi]);
+                else acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0, swv[ni], 0, sxv[mi]);
+            }
+    };
+    unsigned long long t0 = 0, r0 = 0;
+    if constexpr (DBG == 3) {                                      // diagnostic build only
+        t0 = __builtin_amdgcn_s_memtime();
+        r0 = __builtin_amdgcn_s_memrealtime();
+    }
     for (int p = 0; p < np; ++p) {
         const char* cb = smem + (p & 1) * PBUF_BYTES;
-        // tile p has landed when at most the pieces of tile p+1 are still in flight (9 per wave for waves 0/1, else 8;
-        // waiting for "<= 8 outstanding" is exact for waves 2..7 and one piece conservative for waves 0/1)
-        if (p + 1 < np) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        i32x8 wf[4];
-        int swv[4];
+        // tile p has landed (own pieces) and, past the barrier, everybody is done with the other buffer
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (p + 1 < np && DBG != 4) {
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            wf[ni] = load_frag(cb, wrow + ni * 2048);
-            swv[ni] = *reinterpret_cast<const int*>(cb + sw_off[ni]) >> (8 * g);
+            for (int q = 0; q < 8; ++q) issue(p + 1, q);
+            issue_scales(p + 1);
         }
-        i32x8 xf = load_frag(cb, xrow);
-        int sxv = *reinterpret_cast<const int*>(cb + sx_off) >> (8 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 1 && p > 0 && DBG != 1) multiply();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DBG != 1 && DBG != 4) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            i32x8 xn = xf;
-            int sxn = sxv;
-            if (mi < 7) {
-                xn = load_frag(cb, xrow + (mi + 1) * 2048);
-                sxn = *reinterpret_cast<const int*>(cb + sx_off + (mi + 1) * 64) >> (8 * g);
+            for (int ni = 0; ni < 4; ++ni) {
+                wf[ni] = load_frag(cb, wrow + ni * 2048);
+                swv[ni] = *reinterpret_cast<const int*>(cb + sw_off[ni]) >> (8 * g);
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-                acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf, acc[ni][mi], 0, 0, 0, swv[ni], 0, sxv);
-            xf = xn;
-            sxv = sxn;
-        }
-        // every wave has read buffer p completely before it is refilled with tile p+2
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (p + 2 < np) {
+            for (int mi = 0; mi < 8; ++mi) {
+                xf[mi] = load_frag(cb, xrow + mi * 2048);
+                sxv[mi] = *reinterpret_cast<const int*>(cb + sx_off + mi * 64) >> (8 * g);
+            }
+        } else if (p == 0) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q) issue(p + 2, q);
-            issue_scales(p + 2);
+            for (int mi = 0; mi < 8; ++mi) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xf[mi][j] = lane * 0x01010101 + j + mi;
+                sxv[mi] = 127 + (lane & 1);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                wf[ni] = xf[ni] + ni;
+                swv[ni] = 127;
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        if (grp == 0 && DBG != 1) multiply();
+        __builtin_amdgcn_sched_barrier(0);
     }
+    if (grp == 1 && DBG != 1) multiply();
 
+    if constexpr (DBG == 3) {   // (core-clock ticks, 100 MHz ticks) of the K-loop into the first words of this tile's output
+        const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+        if (tid == 0) {
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(out + (size_t)m0 * N + n0);
+            dbg[0] = t1 - t0;
+            dbg[1] = r1 - r0;
+        }
+        return;
+    }
     // ---- epilogue: lane (g,c) owns rows m0 + 128*wm + 16*mi + c, columns n0 + 64*wn + 32*pp + 8*g + 0..7
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
@@ -220,6 +260,12 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
 }
 
 }  // namespace
+
+int g_fp8_debug = 0;   // timing-only ablations of gemm_mxfp8_kernel
+extern "C" int keds_mxfp8_debug(int variant) {
+    g_fp8_debug = variant;
+    return KEDS_OK;
+}
 
 extern "C" size_t keds_mxfp8_scale_bytes(int rows_pad, int K) {
     if (rows_pad <= 0 || K <= 0 || K % 128) return 0;
@@ -246,7 +292,11 @@ extern "C" int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const 
     KEDS_REQUIRE(m_pad >= M && n_pad >= N && m_pad % 4 == 0 && n_pad % 4 == 0, "keds_gemm_mxfp8: bad scale row padding");
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_mxfp8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
             hipSuccess) {
             keds_set_error("keds_gemm_mxfp8: cannot set dynamic LDS size");
             return KEDS_E_LAUNCH;
@@ -256,8 +306,15 @@ extern "C" int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const 
     hipStream_t st = (hipStream_t)stream;
     KedsProfScope prof(KEDS_PROF_GEMM, st);
     const int m_tiles = M / TM, n_tiles = N / TN;
-    gemm_mxfp8_kernel<<<m_tiles * n_tiles, 512, LDS_BYTES, st>>>((const unsigned char*)Aq, (const unsigned char*)As,
-                                                                 (const unsigned char*)Wq, (const unsigned char*)Ws, bias,
-                                                                 (bf16_t*)out, M, N, K, n_tiles, m_pad, n_pad);
+#define KEDS_FP8_LAUNCH(V)                                                                                      \
+    gemm_mxfp8_kernel<V><<<m_tiles * n_tiles, 512, LDS_BYTES, st>>>((const unsigned char*)Aq, (const unsigned char*)As, \
+                                                                    (const unsigned char*)Wq, (const unsigned char*)Ws, bias, \
+                                                                    (bf16_t*)out, M, N, K, n_tiles, m_pad, n_pad)
+    if (g_fp8_debug == 1) KEDS_FP8_LAUNCH(1);
+    else if (g_fp8_debug == 2) KEDS_FP8_LAUNCH(2);
+    else if (g_fp8_debug == 3) KEDS_FP8_LAUNCH(3);
+    else if (g_fp8_debug == 4) KEDS_FP8_LAUNCH(4);
+    else KEDS_FP8_LAUNCH(0);
+#undef KEDS_FP8_LAUNCH
     return keds_check_launch("gemm_mxfp8_kernel");
 }
