@@ -35,6 +35,8 @@ _PER_TOKEN_TAIL = 1024 * 1024 + 2 * 1024 * 4096                     # out-proj +
 GEMM_MAC_PER_IMAGE = (256 * 588 * 1024 + 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL + 1 * _PER_TOKEN_TAIL
                       + 1024 * 768)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_BF16_MEASURED_TFLOPS = 2060.0   # tools/micro/mfma_peak.hip on the gpurun MI355X
+PEAK_HBM_MEASURED_GBPS = 7150.0      # tools/micro/hbm_stream.hip (read-only)
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md
 PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
@@ -220,12 +222,17 @@ def main():
             "roofline": {"kernel": "gemm_bt_kernel (all ViT GEMMs of the step)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
-                         "over the 256x256 GEMM launches)", "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1)},
+                         "over the 256x256 GEMM launches)", "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         # practical ceiling of this chip, measured (profiles/r01_microbench.txt): a register-only
+                         # v_mfma_f32_16x16x32_bf16 loop sustains 2.06 PFLOP/s (clock ~2.0 GHz under MFMA load)
+                         "peak_measured": PEAK_BF16_MEASURED_TFLOPS, "frac_of_measured": ach / PEAK_BF16_MEASURED_TFLOPS},
             "roofline_scan": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_ach,
                               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": scan_ach / PEAK_HBM_GBPS,
                               "traffic": pmc_traffic("scan_topk_kernel<768, 16", B, N, world),
                               "algorithmic_bytes_per_search": (hi - lo) * D * 2.0,
-                              "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1)},
+                              "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1),
+                              # read-only stream over 4 GiB on this box: 7.15 TB/s (profiles/r01_microbench.txt)
+                              "peak_measured": PEAK_HBM_MEASURED_GBPS, "frac_of_measured": scan_ach / PEAK_HBM_MEASURED_GBPS},
             "stage_ms_per_step": {"gemm": gemm_ms / steps, "attention": attn_ms / steps, "layernorm": ln_ms / steps,
                                   "scan": scan_ms / steps, "other": other_ms / steps},
         }

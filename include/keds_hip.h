@@ -178,8 +178,8 @@ int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, c
  * without it they run unsplit.  The buffer must stay valid until it is replaced; pass NULL to unregister. */
 int keds_gemm_set_workspace(void* ptr, size_t bytes);
 
-/* test/bench hook: 1 routes every GEMM through the 128x128 kernel (the 256x256 kernel is used for
- * N % 256 == 0, M >= 1024 otherwise) */
+/* test/bench hook: bit 0 routes every GEMM through the 128x128 kernel, bit 8 skips the remainder-row launch (timing
+ * only), bit 9 disables split-K */
 int keds_gemm_force_small(int on);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (fp32 statistics, eps 1e-5).

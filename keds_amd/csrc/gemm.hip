@@ -17,7 +17,6 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;        // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;       // X tile + W tile
-constexpr int GEMM_LDS = 2 * BUF_BYTES;         // double buffer = 64 KiB
 
 // LDS row r (128 bytes = 8 chunks of 16 B): chunk c is stored at slot c ^ f(r)
 __device__ __forceinline__ int swz_f(int row) { return (row >> 1) & 7; }
@@ -410,177 +409,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     }
 }
 
-// ==========================================================================================
-// Large-problem kernel: 256(m) x 256(n) x 32 tile, 8 waves (2 along m x 4 along n, 128 x 64 each =
-// 8 x 4 MFMA 16x16x32 tiles, 128 accumulator VGPRs), 1 workgroup per CU.
-//   - 4-stage LDS ring (4 x 32 KiB) filled by LDS-DMA; a stage is issued 3 K-steps before it is
-//     read and retired with a COUNTED s_waitcnt vmcnt (2 stages stay in flight), one raw s_barrier
-//     per K-step;
-//   - MFMA operands are register double-buffered: while the 32 MFMAs of K-step t run, the 12
-//     ds_read_b128 of step t+1 are issued between them, so LDS latency hides under the matrix pipe
-//     of the two waves sharing a SIMD;
-//   - LDS rows are 64 B (4 chunks); chunk c of row r is stored at slot c ^ ((-(r>>2))&3), which
-//     makes every ds_read_b128 lane group hit 16 distinct 16-byte slots (conflict free);
-//   - same operand roles and W-row permutation as the 128^2 kernel, so the epilogue is shared.
-// Only full 256-row tiles are given to this kernel; remainder rows go to the 128^2 kernel.
-// ==========================================================================================
-namespace big {
-constexpr int TM = 256, TN = 256, TK = 32, NST = 4;
-constexpr int OP_BYTES = 256 * TK * 2;          // 16 KiB per operand per stage
-constexpr int STAGE_BYTES = 2 * OP_BYTES;       // X | W
-constexpr int LDS_BYTES = NST * STAGE_BYTES;    // 128 KiB
-constexpr int LOADS_PER_STAGE = 4;              // global_load_lds per thread per stage
-
-__device__ __forceinline__ int swz4(int row) { return (0 - (row >> 2)) & 3; }
-
-template <int N, bool BARRIER = true>
-__device__ __forceinline__ void wait_vm_lgkm_barrier() {
-    if constexpr (BARRIER) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
-}
-}  // namespace big
-
-// DBG (timing-only ablations, results are wrong unless 0): 1 = no s_barrier, 2 = no LDS-DMA in the loop,
-// 3 = no fragment reads in the loop, 4 = no MFMA
-template <int EPI, int DBG = 0>
-__global__ __launch_bounds__(512, 2) void gemm_bt_big_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                             const float* __restrict__ bias, void* __restrict__ out,
-                                                             int M, int N, int K, int n_tiles,
-                                                             const float* __restrict__ aux, int aux_i) {
-    using namespace big;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / n_tiles, tn = bid - tm * n_tiles;
-    const int m0 = tm * TM, n0 = tn * TN;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 3, wm = wave >> 2;
-    const int g = lane >> 4, c = lane & 15;
-
-    // ---- staging: per stage each wave moves X pieces {w, w+8} and W pieces {w, w+8}; a piece is
-    //      16 LDS rows x 64 B = 1 KiB; lane -> (row = piece*16 + lane>>2, slot = lane&3)
-    const char* xsrc[2];
-    const char* wsrc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int R = 16 * (wave + 8 * i) + (lane >> 2);
-        const int ch = (lane & 3) ^ swz4(R);
-        xsrc[i] = reinterpret_cast<const char*>(X + (size_t)(m0 + R) * K) + ch * 16;
-        // LDS row R of the W tile holds W row n0 + 64*(R>>6) + perm_w(R & 63)
-        wsrc[i] = reinterpret_cast<const char*>(W + (size_t)(n0 + (R & ~63) + perm_w(R & 63)) * K) + ch * 16;
-    }
-    if constexpr (DBG >= 5) {   // timing-only: same bytes per stage fetched as FULL 128-byte lines (8 rows x 128 B / piece)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int R8 = 8 * (wave + 8 * i) + (lane >> 3);
-            xsrc[i] = reinterpret_cast<const char*>(X + (size_t)(m0 + R8) * K) + (lane & 7) * 16;
-            wsrc[i] = reinterpret_cast<const char*>(W + (size_t)(n0 + R8) * K) + (lane & 7) * 16;
-        }
-    }
-    auto issue = [&](int kt) {
-        char* sb = smem + (kt & (NST - 1)) * STAGE_BYTES;
-        const size_t koff = DBG >= 5 ? (size_t)(kt & 1) * 128 * K * 2 + (size_t)(kt >> 1) * 128 : (size_t)kt * TK * 2;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sb + (wave + 8 * i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(sb + OP_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
-        }
-    };
-    // ---- fragment read offsets inside a stage (row & 15 = c for every tile: same swizzle slot)
-    const int slot = (g ^ swz4(c)) << 4;
-    const int xoff = (128 * wm + c) * 64 + slot;                 // + mi * 1024
-    const int woff = OP_BYTES + (64 * wn + c) * 64 + slot;       // + ni * 1024
-
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = K / TK;                                       // even and >= 4 (K % 64 == 0, K >= 128)
-    // prologue: fill the whole ring (stages 0..3), retire stage 0 (3 stages stay in flight)
-#pragma unroll
-    for (int s = 0; s < NST; ++s) issue(s);
-    wait_vm_lgkm_barrier<3 * LOADS_PER_STAGE>();
-    bf16x8 xa[8], wa[4], xb[8], wb[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) wa[ni] = *reinterpret_cast<const bf16x8*>(smem + woff + ni * 1024);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(smem + xoff + mi * 1024);
-
-    // One K-step: the 32 MFMAs of step kt run from (xc, wc) while the 12 fragment reads of step kt+1
-    // are issued between them into (xn, wn_).  Before that, VMWAIT retires stage kt+1 (VMWAIT loads stay
-    // in flight), lgkmcnt(0) retires this wave's reads of stage kt, and the barrier makes both true for
-    // every wave -- so stage kt+1 may be read and the slot of stage kt may be refilled (ISSUE).
-#define KEDS_SGB_4M_1R __builtin_amdgcn_sched_group_barrier(0x008, 4, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-#define KEDS_GEMM_STEP(kt, xc, wc, xn, wn_, VMWAIT, ISSUE, PREFETCH)                                          \
-    {                                                                                                          \
-        const char* nb = smem + (((kt) + 1) & (NST - 1)) * STAGE_BYTES;                                        \
-        __builtin_amdgcn_sched_barrier(0);   /* MFMAs are register-only: fence them at the step boundary */    \
-        if constexpr (PREFETCH) wait_vm_lgkm_barrier<(DBG == 2 ? 0 : VMWAIT), DBG != 1>();                     \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr (ISSUE && DBG != 2) issue((kt) + NST);                                                    \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-        _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) {                                                     \
-            if constexpr (DBG != 4 && DBG != 5) {                                                              \
-                _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                               \
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0); \
-            }                                                                                                  \
-            if constexpr (PREFETCH && DBG != 3) {                                                              \
-                if (mi == 0) {                                                                                 \
-                    _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                           \
-                        wn_[ni] = *reinterpret_cast<const bf16x8*>(nb + woff + ni * 1024);                     \
-                    xn[0] = *reinterpret_cast<const bf16x8*>(nb + xoff);                                       \
-                }                                                                                              \
-                if (mi < 7) xn[mi + 1] = *reinterpret_cast<const bf16x8*>(nb + xoff + (mi + 1) * 1024);        \
-            }                                                                                                  \
-        }                                                                                                      \
-        if constexpr (PREFETCH && DBG == 0) { /* pin the interleave: 4 MFMA, then the reads that follow */     \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                 \
-            KEDS_SGB_4M_1R KEDS_SGB_4M_1R KEDS_SGB_4M_1R KEDS_SGB_4M_1R KEDS_SGB_4M_1R KEDS_SGB_4M_1R          \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
-        }                                                                                                      \
-    }
-
-    int kt = 0;
-    for (; kt + 5 < nk; kt += 2) {                               // steady state: kt + 4 < nk for both steps
-        KEDS_GEMM_STEP(kt, xa, wa, xb, wb, 2 * LOADS_PER_STAGE, true, true)
-        KEDS_GEMM_STEP(kt + 1, xb, wb, xa, wa, 2 * LOADS_PER_STAGE, true, true)
-    }
-    // tail: steps nk-4 .. nk-1 (nothing left to issue; the ring drains 8 -> 4 -> 0)
-    KEDS_GEMM_STEP(kt, xa, wa, xb, wb, 2 * LOADS_PER_STAGE, false, true)
-    KEDS_GEMM_STEP(kt + 1, xb, wb, xa, wa, LOADS_PER_STAGE, false, true)
-    KEDS_GEMM_STEP(kt + 2, xa, wa, xb, wb, 0, false, true)
-    KEDS_GEMM_STEP(kt + 3, xb, wb, xa, wa, 0, false, false)
-#undef KEDS_GEMM_STEP
-#undef KEDS_SGB_4M_1R
-
-    if constexpr (DBG == 4 || DBG == 5) {   // keep the fragments alive
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) asm volatile("" ::"v"(xa[mi]), "v"(xb[mi]));
-#pragma unroll
-        for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(wa[ni]), "v"(wb[ni]));
-    }
-    // ---- epilogue: lane (g,c) owns rows m = m0 + 128*wm + 16*mi + c, columns n0 + 64*wn + 32*p + 8*g + 0..7
-#pragma unroll
-    for (int p = 0; p < 2; ++p) {
-        const int n = n0 + 64 * wn + 32 * p + 8 * g;
-        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
-        if (bias) {
-            b0 = *reinterpret_cast<const f32x4*>(bias + n);
-            b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-        }
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + 128 * wm + 16 * mi + c;
-            if (m >= M) continue;
-            epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, N);
-        }
-    }
-}
+// (A 256 x 256 x 32 kernel with a 4-stage LDS ring and counted vmcnt lived here in round 1.  Its 64-byte LDS rows make
+// every DMA lane group fetch half cache lines, the texture-address path saturates, and the 256 x 256 x 64 kernel below
+// replaced it: +16 % DMA rate from full-line fetches.  profiles/r01_gemm_pmc_ring_kernel.txt keeps its counters.)
 
 float* g_ws = nullptr;      // caller-registered split-K workspace (keds_gemm_set_workspace)
 size_t g_ws_bytes = 0;
@@ -776,7 +607,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 #undef KEDS_PAIR_STEP
 #undef KEDS_PAIR_G
 
-    // ---- epilogue (same ownership as the ring kernel)
+    // ---- epilogue (same ownership pattern as the 128^2 kernel)
     const bool zl = epi_is_ln(EPI) ? (n0 == 0 && wn == 0 && g == 0) : (g == 0);
     tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
@@ -793,7 +624,6 @@ int device_cus_gemm() {
     return cus;
 }
 
-int g_debug_variant = 0;  // timing-only ablations of the big kernel (EPI_BIAS_BF16 only)
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
 
 template <int EPI>
@@ -808,40 +638,7 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         }
         attr_set = true;
     }
-    const int m_tiles = M / big::TM, n_tiles = N / big::TN;       // M is a multiple of 256 here
-    if constexpr (EPI == KEDS_EPI_BIAS_BF16) {
-        if (g_debug_variant && g_debug_variant != 7) {
-#define KEDS_DBG_LAUNCH(V)                                                                                          \
-    {                                                                                                              \
-        (void)hipFuncSetAttribute((const void*)gemm_bt_big_kernel<EPI, V>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
-                                  big::LDS_BYTES);                                                                 \
-        gemm_bt_big_kernel<EPI, V><<<m_tiles * n_tiles, 512, big::LDS_BYTES, st>>>(                                \
-            (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles, aux, aux_i);                          \
-    }
-            switch (g_debug_variant) {
-                case 1: KEDS_DBG_LAUNCH(1) break;
-                case 2: KEDS_DBG_LAUNCH(2) break;
-                case 3: KEDS_DBG_LAUNCH(3) break;
-                case 4: KEDS_DBG_LAUNCH(4) break;
-                case 5: KEDS_DBG_LAUNCH(5) break;
-                default: KEDS_DBG_LAUNCH(6) break;
-            }
-#undef KEDS_DBG_LAUNCH
-            return keds_check_launch("gemm_bt_big_kernel<dbg>");
-        }
-    }
-    if constexpr (EPI <= KEDS_EPI_PATCH_F32)
-    if (g_debug_variant == 7) {   // A/B hook: the BK=32 ring kernel
-        static bool ring_attr = false;
-        if (!ring_attr) {
-            (void)hipFuncSetAttribute((const void*)gemm_bt_big_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      big::LDS_BYTES);
-            ring_attr = true;
-        }
-        gemm_bt_big_kernel<EPI><<<m_tiles * n_tiles, 512, big::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias,
-                                                                                out, M, N, K, n_tiles, aux, aux_i);
-        return keds_check_launch("gemm_bt_big_kernel");
-    }
+    const int m_tiles = M / pr::TM, n_tiles = N / pr::TN;         // M is a multiple of 256 here
     gemm_bt_pair_kernel<EPI><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
                                                                             M, N, K, n_tiles, aux, aux_i, aux2);
     return keds_check_launch("gemm_bt_pair_kernel");
@@ -857,12 +654,12 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     // (ViT-L/14 at B=128: M = 32896 = 128*256 + 128, so 512..2048 big tiles = whole rounds on 256 CUs.)
     // the 256^2 kernel runs one workgroup per CU: use it when its full tiles fill at least two rounds of 256 CUs
     // with >= 85% of the last round busy; otherwise the 128^2 kernel's finer tiles quantise better
-    const long bt = (long)(M / big::TM) * (N / big::TN);
+    const long bt = (long)(M / pr::TM) * (N / pr::TN);
     const long rounds = (bt + 255) / 256;
-    const bool big_ok = !g_force_small && lda == K && ldc == N && N % big::TN == 0 && K % 64 == 0 && K >= 128 && bt >= 512 &&
-                        bt * 100 >= rounds * 256 * 85 && (EPI != KEDS_EPI_PATCH_F32 || M % big::TM == 0);
+    const bool big_ok = !g_force_small && lda == K && ldc == N && N % pr::TN == 0 && K % 64 == 0 && K >= 128 && bt >= 512 &&
+                        bt * 100 >= rounds * 256 * 85 && (EPI != KEDS_EPI_PATCH_F32 || M % pr::TM == 0);
     if (!big_ok) return launch_small<EPI>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
-    const int m_main = M / big::TM * big::TM;
+    const int m_main = M / pr::TM * pr::TM;
     int rc = launch_big<EPI>(A, W, bias, out, m_main, N, K, aux, aux_i, aux2, st);
     if (rc || m_main == M || g_skip_tail) return rc;
     const size_t esz = (EPI == KEDS_EPI_BIAS_RESID_F32 || EPI == KEDS_EPI_BIAS_F32 || EPI == KEDS_EPI_RESID_STATS_F32) ? 4 : 2;
@@ -893,7 +690,6 @@ extern "C" int keds_gemm_set_workspace(void* ptr, size_t bytes) {
 extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
-    g_debug_variant = (on >> 4) & 15;   // bits 4-7: timing-only ablation of the 256^2 kernel (0 = product path)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
     return KEDS_OK;
 }
