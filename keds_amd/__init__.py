@@ -15,4 +15,7 @@ from .retrieval import (build_database, compose_query_features, get_cirr_testout
                         get_metrics_coco, get_metrics_fashion, get_metrics_imgnet, get_retrieved_features,
                         load_checkpoint, make_stream_modules)
 
+from . import clip   # noqa: F401  (load / _transform / tokenize of the reference's model/clip.py)
+from .clip import load, tokenize   # noqa: F401
+
 __version__ = "0.1.0"

@@ -286,6 +286,32 @@ def mint_eval_glue():
                          if not k.startswith(("gallery", "ref", "coco_image", "coco_ref", "imgnet_q", "imgnet_t", "text", "tok3"))})
 
 
+def mint_tokenizer():
+    """(string -> ids) pairs from the reference's own tokenizer (src/third_party/open_clip/simple_tokenizer.py + clip.py
+    tokenize), with an identity stand-in for the missing `ftfy` (a no-op on these clean strings)."""
+    import importlib.util, json, types
+    sys.modules.setdefault("ftfy", types.SimpleNamespace(fix_text=lambda t: t))
+    base = os.path.join(os.path.dirname(REF), "src", "third_party", "open_clip") if not REF.endswith("src") else os.path.join(REF, "third_party", "open_clip")
+    spec = importlib.util.spec_from_file_location("ref_simple_tokenizer", os.path.join(base, "simple_tokenizer.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    tk = mod.SimpleTokenizer()
+    texts = ["*", "a photo of * , in the style of sketch", "A photo of a cat.", "remove the dog and add two red   balloons!",
+             "it's the zebra's 3rd birthday -- isn't it?", "caf\u00e9 na\u00efve r\u00e9sum\u00e9 \u00fcber", "price: $1,234.50 (50% off) &amp; more",
+             "the quick brown fox jumps over the lazy dog " * 12, "\u65e5\u672c\u8a9e\u306e\u30c6\u30b9\u30c8 emoji \U0001F600 ok", ""]
+    sot, eot = tk.encoder["<|startoftext|>"], tk.encoder["<|endoftext|>"]
+    rows = []
+    for t in texts:
+        ids = [sot] + tk.encode(t) + [eot]
+        if len(ids) > 77:
+            ids = ids[:77]
+            ids[-1] = eot
+        rows.append(ids + [0] * (77 - len(ids)))
+    json.dump({"texts": texts, "tokens": rows, "decoded": [tk.decode(r[1:r.index(eot)]) for r in rows]},
+              open(os.path.join(OUT, "tokenizer.json"), "w"), ensure_ascii=True, indent=0)
+    print("tokenizer:", len(texts), "strings; '*' ->", rows[0][:3])
+
+
 def mint_keys():
     """state_dict key -> shape lists of the reference modules (the checkpoint contract)."""
     import json
@@ -308,9 +334,11 @@ VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=
             context_length=77, vocab_size=49408, transformer_width=768, transformer_layers=12)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["tiny", "knowledge", "cirr", "search", "metrics", "glue", "keys", "vitl"]
+    which = sys.argv[1:] or ["tiny", "knowledge", "cirr", "search", "metrics", "glue", "tokenizer", "keys", "vitl"]
     if "glue" in which:
         mint_eval_glue()
+    if "tokenizer" in which:
+        mint_tokenizer()
     if "keys" in which:
         mint_keys()
     model = None
