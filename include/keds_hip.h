@@ -172,6 +172,22 @@ int keds_quantize_mxfp8(const void* x, int x_is_bf16, int rows, int K, int rows_
  * M % 256 == 0, N % 256 == 0, K % 128 == 0, K >= 256. */
 int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
                     const float* bias, void* out, int M, int N, int K, void* stream);
+/* the same with the fused epilogues of the fp8 tower (cf. KEDS_EPI_LN_* / KEDS_EPI_RESID_STATS_F32 above):
+ *   LN_BIAS_BF16   out bf16 = rstd (acc - mean csum) + bias';  bias = [bias' | csum], aux = row statistics [M,2],
+ *                  aux2 (nullable) = statistics buffer cleared for these rows
+ *   LN_QGELU_MX    the same, then QuickGELU, emitted as MXFP8 to qout [M,N] / qscale ([N/128][q_pad] dwords)
+ *   RESID_STATS_MX out fp32 += acc + bias; MXFP8 copy of the new rows to qout / qscale; aux += {sum, sum sq} per row */
+#define KEDS_FP8_EPI_BIAS_BF16 0
+#define KEDS_FP8_EPI_LN_BIAS_BF16 1
+#define KEDS_FP8_EPI_LN_QGELU_MX 2
+#define KEDS_FP8_EPI_RESID_STATS_MX 3
+int keds_gemm_mxfp8_ex(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
+                       const float* bias, void* out, int M, int N, int K, int epilogue, float* aux, float* aux2,
+                       void* qout, void* qscale, int q_pad, void* stream);
+/* Weight preparation for the fp8 tower: W fp32 [N,K] (times diag(gamma) when a LayerNorm is folded in) -> MXFP8 wq / wscale,
+ * bias_csum fp32 [2N] = [bias + W beta | row sums of the dequantised weight].  gamma = beta = NULL: plain quantisation. */
+int keds_fold_layernorm_mxfp8(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                              int n_pad, void* wq, void* wscale, float* bias_csum, void* stream);
 
 /* Optional split-K scratch (fp32, 32 MiB is enough for every shape of the path).  Launches with fewer than ~64 output
  * tiles (remainder rows, M <= 256) then split K over up to 16 workgroups per tile and reduce in a second tiny kernel;

@@ -21,6 +21,7 @@ ABI_VERSION = 2
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32 = 6, 7, 8
+FP8_EPI_BIAS_BF16, FP8_EPI_LN_BIAS_BF16, FP8_EPI_LN_QGELU_MX, FP8_EPI_RESID_STATS_MX = range(4)
 PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
 SCAN_MAX_K = 16
 
@@ -127,6 +128,8 @@ SIGNATURES = {
     "keds_mxfp8_debug": (i32, [i32]),
     "keds_quantize_mxfp8": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "keds_gemm_mxfp8": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, vp]),
+    "keds_gemm_mxfp8_ex": (i32, [vp, vp, i32, vp, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "keds_fold_layernorm_mxfp8": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp]),
     "keds_gemm_bt_ex": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "keds_attention_debug": (i32, [i32]),

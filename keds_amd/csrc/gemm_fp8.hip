@@ -32,6 +32,29 @@ __device__ __forceinline__ int perm_w8(int R) {
     return 64 * (t >> 2) + 32 * ((t >> 1) & 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
 }
 
+// OCP MX shared exponent of a 32-element block from its amax: floor(log2(amax)) - 8 (emax of e4m3), clamped to e8m0
+__device__ __forceinline__ int mx_block_exp(float amax) {
+    int e = amax > 0.f ? (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8 : -127;
+    return e < -127 ? -127 : (e > 127 ? 127 : e);
+}
+// eight values scaled by 2^-e, saturated at +-448, rounded to nearest even e4m3: two dwords of four bytes
+__device__ __forceinline__ uint2 mx_pack8(const float (&v)[8], int e) {
+    const float inv = e == -127 ? 0.f : __uint_as_float((unsigned)(127 - e) << 23);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = fminf(fmaxf(v[j] * inv, -448.f), 448.f);
+    unsigned lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(s[0], s[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(s[2], s[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(s[4], s[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(s[6], s[7], hi, true);
+    return uint2{lo, hi};
+}
+// scale byte of block `blk` (32 columns) of row r in the [K/128][rows_pad] dword layout
+__device__ __forceinline__ size_t mx_scale_index(int blk, int r, int rows_pad) {
+    return ((size_t)(blk >> 2) * rows_pad + r) * 4 + (blk & 3);
+}
+
 // ---- quantisation: one wave per row, lane handles 8 consecutive elements (4 lanes per 32-block) ---------------------
 template <bool IN_BF16>
 __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const void* __restrict__ x, int rows, int K, int rows_pad,
@@ -59,32 +82,70 @@ __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const void* __restr
         for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
         amax = fmaxf(amax, __shfl_xor(amax, 1, 64));       // the 4 lanes of one 32-element block
         amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
-        // OCP MX: shared exponent = floor(log2(amax)) - emax(e4m3 = 8); elements saturate at +-448
-        int e = amax > 0.f ? (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8 : -127;
-        e = e < -127 ? -127 : (e > 127 ? 127 : e);
-        const float inv = __uint_as_float((unsigned)(127 - e) << 23);            // 2^-e (e in [-127, 127] -> exponent field 0..254)
-        unsigned lo = 0, hi = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fminf(fmaxf(v[j] * (e == -127 ? 0.f : inv), -448.f), 448.f);
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0], v[1], lo, false);
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2], v[3], lo, true);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4], v[5], hi, false);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6], v[7], hi, true);
-        *reinterpret_cast<uint2*>(q + (size_t)r * K + k0) = uint2{lo, hi};
+        const int e = mx_block_exp(amax);
+        *reinterpret_cast<uint2*>(q + (size_t)r * K + k0) = mx_pack8(v, e);
         if ((lane & 3) == 0) {
-            const int blk = k0 >> 5;                                             // 32-element block index along K
-            scales[((size_t)(blk >> 2) * rows_pad + r) * 4 + (blk & 3)] = (unsigned char)(e + 127);
+            scales[mx_scale_index(k0 >> 5, r, rows_pad)] = (unsigned char)(e + 127);
         }
+    }
+}
+
+// One wave per output row n of an nn.Linear weight W [N,K]: (optionally) fold the LayerNorm that feeds it, quantise to
+// MXFP8 and emit what the LN epilogue needs: bias' = bias + W.beta (fp32) and csum = row sum of the DEQUANTISED W.diag(gamma)
+// (what the MFMA multiplies the row mean with).  gamma == nullptr: plain quantisation, bias copied, csum still written.
+__global__ __launch_bounds__(256) void fold_quantize_mxfp8_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  int N, int K, int n_pad, unsigned char* __restrict__ wq,
+                                                                  unsigned char* __restrict__ wscale, float* __restrict__ bias_csum) {
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (n >= N) return;
+    float cs = 0.f, bb = 0.f;
+    for (int k0 = lane * 8; k0 < K; k0 += 512) {
+        float v[8];
+        float amax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float w = W[(size_t)n * K + k0 + j];
+            v[j] = gamma ? w * gamma[k0 + j] : w;
+            if (beta) bb += w * beta[k0 + j];
+            amax = fmaxf(amax, fabsf(v[j]));
+        }
+        amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+        amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+        const int e = mx_block_exp(amax);
+        const uint2 q = mx_pack8(v, e);
+        *reinterpret_cast<uint2*>(wq + (size_t)n * K + k0) = q;
+        if ((lane & 3) == 0) wscale[mx_scale_index(k0 >> 5, n, n_pad)] = (unsigned char)(e + 127);
+        const float sc = e == -127 ? 0.f : __uint_as_float((unsigned)(e + 127) << 23);
+        const float d = ((__builtin_amdgcn_cvt_f32_fp8(q.x, 0) + __builtin_amdgcn_cvt_f32_fp8(q.x, 1)) +
+                         (__builtin_amdgcn_cvt_f32_fp8(q.x, 2) + __builtin_amdgcn_cvt_f32_fp8(q.x, 3))) +
+                        ((__builtin_amdgcn_cvt_f32_fp8(q.y, 0) + __builtin_amdgcn_cvt_f32_fp8(q.y, 1)) +
+                         (__builtin_amdgcn_cvt_f32_fp8(q.y, 2) + __builtin_amdgcn_cvt_f32_fp8(q.y, 3)));
+        cs += d * sc;
+    }
+    cs = wave_sum(cs);
+    bb = wave_sum(bb);
+    if (lane == 0) {
+        bias_csum[n] = (bias ? bias[n] : 0.f) + bb;
+        bias_csum[N + n] = cs;
     }
 }
 
 // ---- 256 x 256 x 128 MXFP8 tile kernel: 8 waves (2 along m x 4 along n, 128 x 64 outputs each) -----------------------
 // out bf16 [M,N] = A[M,K] . W[N,K]^T + bias
-template <int DBG>
+// EPI: 0 = out bf16 = acc + bias
+//      1 = LayerNorm folded in (gemm.hip, KEDS_EPI_LN_BIAS_BF16): bias = [bias' | csum], aux = row statistics, aux2 = statistics
+//          buffer to clear; out bf16
+//      2 = the same + QuickGELU, emitted as MXFP8: qout / qscale (rows padded to q_pad) instead of `out`
+//      3 = out fp32 += acc + bias (residual stream), its MXFP8 copy to qout / qscale and row {sum, sum sq} atomically to aux
+template <int EPI, int DBG>
 __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char* __restrict__ X, const unsigned char* __restrict__ sX,
                                                             const unsigned char* __restrict__ W, const unsigned char* __restrict__ sW,
-                                                            const float* __restrict__ bias, bf16_t* __restrict__ out, int M, int N,
-                                                            int K, int n_tiles, int m_pad, int n_pad) {
+                                                            const float* __restrict__ bias, void* __restrict__ out, int M, int N,
+                                                            int K, int n_tiles, int m_pad, int n_pad, float* __restrict__ aux,
+                                                            float* __restrict__ aux2, unsigned char* __restrict__ qout,
+                                                            unsigned char* __restrict__ qscale, int q_pad) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
@@ -232,29 +293,100 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
     if constexpr (DBG == 3) {   // (core-clock ticks, 100 MHz ticks) of the K-loop into the first words of this tile's output
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
         if (tid == 0) {
-            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(out + (size_t)m0 * N + n0);
+            unsigned long long* dbg = reinterpret_cast<unsigned long long*>(reinterpret_cast<bf16_t*>(out) + (size_t)m0 * N + n0);
             dbg[0] = t1 - t0;
             dbg[1] = r1 - r0;
         }
         return;
     }
-    // ---- epilogue: lane (g,c) owns rows m0 + 128*wm + 16*mi + c, columns n0 + 64*wn + 32*pp + 8*g + 0..7
+    // ---- epilogue: lane (g,c) owns rows m0 + 128*wm + 16*mi + c, columns n0 + 64*wn + 32*pp + 8*g + 0..7.  The four lanes
+    // g = 0..3 of a row hold exactly one 32-column MX block per pp, so block amax / row sums are two xor-shuffles.
+    const float invk = 1.0f / (float)K;
+    float rstd[8], nmr[8];
+    if constexpr (EPI == 1 || EPI == 2) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + 128 * wm + 16 * mi + c;
+            const float sm = aux[2 * (size_t)m], ss = aux[2 * (size_t)m + 1];
+            const float mean = sm * invk;
+            rstd[mi] = rsqrtf(fmaxf(ss * invk - mean * mean, 0.f) + 1e-5f);
+            nmr[mi] = -mean * rstd[mi];
+            if (aux2 && n0 == 0 && wn == 0 && g == 0) *reinterpret_cast<float2*>(aux2 + 2 * (size_t)m) = float2{0.f, 0.f};
+        }
+    }
+    float rs[8], rss[8];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) rs[mi] = rss[mi] = 0.f;
 #pragma unroll
     for (int pp = 0; pp < 2; ++pp) {
         const int n = n0 + 64 * wn + 32 * pp + 8 * g;
-        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0, c0 = b0, c1 = b0;
         if (bias) {
             b0 = *reinterpret_cast<const f32x4*>(bias + n);
             b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
         }
+        if constexpr (EPI == 1 || EPI == 2) {
+            c0 = *reinterpret_cast<const f32x4*>(bias + N + n);
+            c1 = *reinterpret_cast<const f32x4*>(bias + N + n + 4);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            const int m = m0 + 128 * wm + 16 * mi + c;           // M is a multiple of 256: every row is valid
+            f32x4 v0, v1;
+            if constexpr (EPI == 1 || EPI == 2) {
+                v0 = acc[2 * pp][mi] * rstd[mi] + (c0 * nmr[mi] + b0);
+                v1 = acc[2 * pp + 1][mi] * rstd[mi] + (c1 * nmr[mi] + b1);
+            } else {
+                v0 = acc[2 * pp][mi] + b0;
+                v1 = acc[2 * pp + 1][mi] + b1;
+            }
+            if constexpr (EPI == 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                     // x * sigmoid(1.702 x)  (src/model/model.py:300-302)
+                    v0[j] = v0[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v0[j]));
+                    v1[j] = v1[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v1[j]));
+                }
+            }
+            if constexpr (EPI == 3) {
+                float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
+                v0 += *reinterpret_cast<const f32x4*>(o);
+                v1 += *reinterpret_cast<const f32x4*>(o + 4);
+                *reinterpret_cast<f32x4*>(o) = v0;
+                *reinterpret_cast<f32x4*>(o + 4) = v1;
+                rs[mi] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+                rss[mi] += ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) +
+                           ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
+            }
+            if constexpr (EPI == 0 || EPI == 1) {
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * N + n) =
+                    bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                           (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+            } else {                                              // MXFP8 copy: one 32-column block per (row, pp)
+                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                float amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+                amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                const int e = mx_block_exp(amax);
+                *reinterpret_cast<uint2*>(qout + (size_t)m * N + n) = mx_pack8(v, e);
+                if (g == 0) qscale[mx_scale_index((n0 + 64 * wn + 32 * pp) >> 5, m, q_pad)] = (unsigned char)(e + 127);
+            }
+        }
+    }
+    if constexpr (EPI == 3) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + 128 * wm + 16 * mi + c;
-            if (m >= M) continue;
-            const f32x4 v0 = acc[2 * pp][mi] + b0, v1 = acc[2 * pp + 1][mi] + b1;
-            *reinterpret_cast<bf16x8*>(out + (size_t)m * N + n) =
-                bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
-                       (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+            float a = rs[mi], b2 = rss[mi];
+            a += __shfl_xor(a, 16, 64);
+            b2 += __shfl_xor(b2, 16, 64);
+            a += __shfl_xor(a, 32, 64);
+            b2 += __shfl_xor(b2, 32, 64);
+            if (g == 0) {
+                unsafeAtomicAdd(aux + 2 * (size_t)m, a);
+                unsafeAtomicAdd(aux + 2 * (size_t)m + 1, b2);
+            }
         }
     }
 }
@@ -284,37 +416,71 @@ extern "C" int keds_quantize_mxfp8(const void* x, int x_is_bf16, int rows, int K
     return keds_check_launch("quantize_mxfp8_kernel");
 }
 
-extern "C" int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
-                               const float* bias, void* out, int M, int N, int K, void* stream) {
-    KEDS_REQUIRE(Aq && As && Wq && Ws && out, "keds_gemm_mxfp8: null pointer");
-    KEDS_REQUIRE(M > 0 && M % TM == 0 && N > 0 && N % TN == 0, "keds_gemm_mxfp8: M and N must be multiples of 256 (M=%d N=%d)", M, N);
-    KEDS_REQUIRE(K % TKB == 0 && K >= 2 * TKB, "keds_gemm_mxfp8: K=%d must be a multiple of 128, >= 256", K);
-    KEDS_REQUIRE(m_pad >= M && n_pad >= N && m_pad % 4 == 0 && n_pad % 4 == 0, "keds_gemm_mxfp8: bad scale row padding");
+namespace {
+template <int EPI, int DBG>
+int launch_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad, const float* bias,
+                 void* out, int M, int N, int K, float* aux, float* aux2, void* qout, void* qscale, int q_pad, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
-            hipSuccess) {
+        if (hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess) {
             keds_set_error("keds_gemm_mxfp8: cannot set dynamic LDS size");
             return KEDS_E_LAUNCH;
         }
         attr_set = true;
     }
+    const int m_tiles = M / TM, n_tiles = N / TN;
+    gemm_mxfp8_kernel<EPI, DBG><<<m_tiles * n_tiles, 512, LDS_BYTES, st>>>(
+        (const unsigned char*)Aq, (const unsigned char*)As, (const unsigned char*)Wq, (const unsigned char*)Ws, bias, out, M, N, K,
+        n_tiles, m_pad, n_pad, aux, aux2, (unsigned char*)qout, (unsigned char*)qscale, q_pad);
+    return keds_check_launch("gemm_mxfp8_kernel");
+}
+}  // namespace
+
+extern "C" int keds_gemm_mxfp8_ex(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
+                                  const float* bias, void* out, int M, int N, int K, int epilogue, float* aux, float* aux2,
+                                  void* qout, void* qscale, int q_pad, void* stream) {
+    KEDS_REQUIRE(Aq && As && Wq && Ws, "keds_gemm_mxfp8: null pointer");
+    KEDS_REQUIRE(M > 0 && M % TM == 0 && N > 0 && N % TN == 0, "keds_gemm_mxfp8: M and N must be multiples of 256 (M=%d N=%d)", M, N);
+    KEDS_REQUIRE(K % TKB == 0 && K >= 2 * TKB, "keds_gemm_mxfp8: K=%d must be a multiple of 128, >= 256", K);
+    KEDS_REQUIRE(m_pad >= M && n_pad >= N && m_pad % 4 == 0 && n_pad % 4 == 0, "keds_gemm_mxfp8: bad scale row padding");
     hipStream_t st = (hipStream_t)stream;
     KedsProfScope prof(KEDS_PROF_GEMM, st);
-    const int m_tiles = M / TM, n_tiles = N / TN;
-#define KEDS_FP8_LAUNCH(V)                                                                                      \
-    gemm_mxfp8_kernel<V><<<m_tiles * n_tiles, 512, LDS_BYTES, st>>>((const unsigned char*)Aq, (const unsigned char*)As, \
-                                                                    (const unsigned char*)Wq, (const unsigned char*)Ws, bias, \
-                                                                    (bf16_t*)out, M, N, K, n_tiles, m_pad, n_pad)
-    if (g_fp8_debug == 1) KEDS_FP8_LAUNCH(1);
-    else if (g_fp8_debug == 2) KEDS_FP8_LAUNCH(2);
-    else if (g_fp8_debug == 3) KEDS_FP8_LAUNCH(3);
-    else if (g_fp8_debug == 4) KEDS_FP8_LAUNCH(4);
-    else KEDS_FP8_LAUNCH(0);
-#undef KEDS_FP8_LAUNCH
-    return keds_check_launch("gemm_mxfp8_kernel");
+#define KEDS_FP8_GO(E, D) return launch_mxfp8<E, D>(Aq, As, m_pad, Wq, Ws, n_pad, bias, out, M, N, K, aux, aux2, qout, qscale, q_pad, st)
+    switch (epilogue) {
+        case KEDS_FP8_EPI_BIAS_BF16:
+            KEDS_REQUIRE(out != nullptr, "keds_gemm_mxfp8: null output");
+            if (g_fp8_debug == 1) KEDS_FP8_GO(0, 1);
+            if (g_fp8_debug == 2) KEDS_FP8_GO(0, 2);
+            if (g_fp8_debug == 3) KEDS_FP8_GO(0, 3);
+            if (g_fp8_debug == 4) KEDS_FP8_GO(0, 4);
+            KEDS_FP8_GO(0, 0);
+        case KEDS_FP8_EPI_LN_BIAS_BF16:
+            KEDS_REQUIRE(out && bias && aux, "keds_gemm_mxfp8: LN epilogue needs out, bias = [bias' | csum] and row statistics");
+            KEDS_FP8_GO(1, 0);
+        case KEDS_FP8_EPI_LN_QGELU_MX:
+            KEDS_REQUIRE(bias && aux && qout && qscale && q_pad >= M, "keds_gemm_mxfp8: LN+QuickGELU MX epilogue arguments");
+            KEDS_FP8_GO(2, 0);
+        case KEDS_FP8_EPI_RESID_STATS_MX:
+            KEDS_REQUIRE(out && aux && qout && qscale && q_pad >= M, "keds_gemm_mxfp8: residual MX epilogue arguments");
+            KEDS_FP8_GO(3, 0);
+        default: keds_set_error("keds_gemm_mxfp8: unknown epilogue %d", epilogue); return KEDS_E_ARG;
+    }
+#undef KEDS_FP8_GO
+}
+
+extern "C" int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
+                               const float* bias, void* out, int M, int N, int K, void* stream) {
+    return keds_gemm_mxfp8_ex(Aq, As, m_pad, Wq, Ws, n_pad, bias, out, M, N, K, KEDS_FP8_EPI_BIAS_BF16, nullptr, nullptr, nullptr,
+                              nullptr, 0, stream);
+}
+
+extern "C" int keds_fold_layernorm_mxfp8(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                                         int n_pad, void* wq, void* wscale, float* bias_csum, void* stream) {
+    KEDS_REQUIRE(W && wq && wscale && bias_csum && N > 0, "keds_fold_layernorm_mxfp8: bad argument");
+    KEDS_REQUIRE((gamma == nullptr) == (beta == nullptr), "keds_fold_layernorm_mxfp8: gamma and beta come together");
+    KEDS_REQUIRE(K % 128 == 0 && K >= 128 && n_pad >= N, "keds_fold_layernorm_mxfp8: K %% 128 == 0 and n_pad >= N");
+    fold_quantize_mxfp8_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(W, bias, gamma, beta, N, K, n_pad, (unsigned char*)wq,
+                                                                            (unsigned char*)wscale, bias_csum);
+    return keds_check_launch("fold_quantize_mxfp8_kernel");
 }

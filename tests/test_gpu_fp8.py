@@ -84,3 +84,99 @@ def test_mxfp8_gemm_argument_errors():
     assert lib.keds_gemm_mxfp8(1, 1, 256, 1, 1, 256, None, 1, 200, 256, 256, None) == -1 and "256" in _lib.last_error()
     assert lib.keds_gemm_mxfp8(1, 1, 256, 1, 1, 256, None, 1, 256, 256, 128, None) == -1
     assert lib.keds_mxfp8_scale_bytes(256, 1024) == 8 * 256 * 4 and lib.keds_mxfp8_scale_bytes(256, 100) == 0
+
+
+# ---- fused epilogues of the fp8 tower ---------------------------------------------------------------------------------
+def _fold_fp8(w, b, gamma, beta):
+    lib = _lib.load()
+    n, k = w.shape
+    n_pad = (n + 255) // 256 * 256
+    wq = torch.zeros((n, k), dtype=torch.uint8, device="cuda")
+    ws = torch.full((k // 128, n_pad, 4), 127, dtype=torch.uint8, device="cuda")
+    bc = torch.zeros(2 * n, device="cuda")
+    _lib.check(lib.keds_fold_layernorm_mxfp8(_lib.ptr(w), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), n, k, n_pad, _lib.ptr(wq),
+                                             _lib.ptr(ws), _lib.ptr(bc), _lib.stream()), "fold fp8")
+    return wq, ws, bc
+
+
+def test_fold_layernorm_mxfp8_weight_preparation():
+    g = torch.Generator(device="cuda").manual_seed(5)
+    N, K = 768, 1024
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    gamma = 1 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    wq, ws, bc = _fold_fp8(w, b, gamma, beta)
+    qt, st = _torch_mx(w * gamma)
+    assert torch.equal(wq, qt) and torch.equal(ws[:, :N, :].permute(1, 0, 2).reshape(N, K // 32), st)
+    deq = _dequantize(wq, ws)
+    assert torch.allclose(bc[N:], deq.sum(1), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(bc[:N], b + w @ beta, rtol=1e-5, atol=1e-5)
+    wq2, ws2, bc2 = _fold_fp8(w, b, None, None)                   # plain quantisation
+    qt2, _ = _torch_mx(w)
+    assert torch.equal(wq2, qt2) and torch.allclose(bc2[:N], b)
+
+
+@pytest.mark.parametrize("M,N,K,gelu", [(512, 768, 1024, False), (1024, 1024, 256, True), (2048, 4096, 1024, True)])
+def test_mxfp8_layernorm_epilogues(M, N, K, gelu):
+    """LayerNorm folded into the fp8 GEMM: equals Linear(LayerNorm(x)) at fp8 tolerance and, exactly (up to the output
+    rounding), the formula on the dequantised operands; the QuickGELU variant emits a valid MXFP8 tensor."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N)
+    x = torch.randn(M, K, generator=g, device="cuda") * 1.5 + 0.2 * torch.randn(M, 1, generator=g, device="cuda")
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    gamma = 1 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    wq, ws, bc = _fold_fp8(w, b, gamma, beta)
+    xq, xs = _quantize(x)
+    stats = torch.stack([x.sum(1), (x * x).sum(1)], dim=1).contiguous()
+    other = torch.full((M + 8, 2), 7.0, device="cuda")
+    mean, rstd = x.mean(1, keepdim=True), torch.rsqrt(x.var(1, unbiased=False, keepdim=True) + 1e-5)
+    want = rstd * (_dequantize(xq, xs) @ _dequantize(wq, ws).t() - mean * bc[N:][None, :]) + bc[:N][None, :]
+    full = torch.nn.functional.layer_norm(x, (K,), gamma, beta) @ w.t() + b
+    if gelu:
+        want, full = want * torch.sigmoid(1.702 * want), full * torch.sigmoid(1.702 * full)
+        q = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+        qs = torch.full((N // 128, M, 4), 127, dtype=torch.uint8, device="cuda")
+        _lib.check(lib.keds_gemm_mxfp8_ex(_lib.ptr(xq), _lib.ptr(xs), xs.shape[1], _lib.ptr(wq), _lib.ptr(ws), ws.shape[1],
+                                          _lib.ptr(bc), None, M, N, K, _lib.FP8_EPI_LN_QGELU_MX, _lib.ptr(stats), _lib.ptr(other),
+                                          _lib.ptr(q), _lib.ptr(qs), M, _lib.stream()), "gemm fp8 ln gelu")
+        got = _dequantize(q, qs)
+        qt, st = _torch_mx(got)                                    # idempotent: re-quantising the decoded tensor reproduces it
+        assert torch.equal(qt, q)
+        tol_exact = 5e-2                                           # the output itself is e4m3 now
+    else:
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.keds_gemm_mxfp8_ex(_lib.ptr(xq), _lib.ptr(xs), xs.shape[1], _lib.ptr(wq), _lib.ptr(ws), ws.shape[1],
+                                          _lib.ptr(bc), _lib.ptr(out), M, N, K, _lib.FP8_EPI_LN_BIAS_BF16, _lib.ptr(stats),
+                                          _lib.ptr(other), None, None, 0, _lib.stream()), "gemm fp8 ln")
+        got = out.float()
+        tol_exact = 4e-3
+    assert bool((other[:M] == 0).all()) and bool((other[M:] == 7).all())
+    report("mxfp8_ln_epilogue", M=M, N=N, K=K, gelu=gelu, rel_l2_formula=rel_l2(got, want), rel_l2_fp32=rel_l2(got, full))
+    assert rel_l2(got, want) <= tol_exact
+    assert rel_l2(got, full) <= 9e-2
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1024, 1024, 4096)])
+def test_mxfp8_residual_stats_epilogue(M, N, K):
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randn(M, K, generator=g, device="cuda")
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    x = torch.randn(M, N, generator=g, device="cuda")
+    aq, as_ = _quantize(a)
+    wq, ws = _quantize(w)
+    want = x + _dequantize(aq, as_) @ _dequantize(wq, ws).t() + b
+    stats = torch.zeros((M, 2), device="cuda")
+    q = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    qs = torch.full((N // 128, M, 4), 127, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.keds_gemm_mxfp8_ex(_lib.ptr(aq), _lib.ptr(as_), as_.shape[1], _lib.ptr(wq), _lib.ptr(ws), ws.shape[1], _lib.ptr(b),
+                                      _lib.ptr(x), M, N, K, _lib.FP8_EPI_RESID_STATS_MX, _lib.ptr(stats), None, _lib.ptr(q),
+                                      _lib.ptr(qs), M, _lib.stream()), "gemm fp8 resid")
+    assert float((x - want).abs().max()) <= 5e-4
+    qt, st = _torch_mx(x)                                          # the MXFP8 copy is the quantisation of the NEW rows
+    assert torch.equal(q, qt) and torch.equal(qs.permute(1, 0, 2).reshape(M, N // 32), st)
+    assert torch.allclose(stats[:, 0], x.sum(1), rtol=1e-4, atol=2e-3) and torch.allclose(stats[:, 1], (x * x).sum(1), rtol=1e-4)
