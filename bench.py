@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--db-rows", type=int, default=500000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8 = BASELINE config 5 (MXFP8 GEMM operands in the image tower); the headline metric is bf16")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent pairs around every kernel class (default: only the "
                     "dominant GEMM class and the scan; the full breakdown costs ~1-2 %% of the step)")
     args = ap.parse_args()
@@ -142,6 +144,8 @@ def main():
 
     B, N, D, k = args.batch, args.db_rows, 768, args.k
     model = random_clip(dev)
+    if args.precision == "fp8":
+        model.set_precision("fp8")
     # synthetic database: seeded unit-norm rows; this rank keeps rows [lo, hi)
     lo, hi = shard_bounds(N, world, rank)
     gen = torch.Generator(device=dev).manual_seed(2002)
@@ -214,7 +218,7 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": "bf16" if args.precision == "bf16" else "fp8 (MXFP8 e4m3 operands, fp32 accumulate; config 5)", "data": "synthetic",
             "config": {"workload": "ViT-L/14 encode_image (224x224 synthetic, random-init weights) + exact top-10 "
                                    "over a synthetic unit-norm 0.5M x 768 database",
                        "batch_per_gpu": B, "global_batch": B * world, "db_rows": N, "dim": D, "k": k,

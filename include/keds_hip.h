@@ -30,7 +30,7 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 2
+#define KEDS_ABI_VERSION 3
 
 int keds_abi_version(void);
 const char* keds_last_error(void);
@@ -256,12 +256,21 @@ typedef struct {
      * parameters are still needed (CLS-only last block). */
     const void *qkv_wf, *fc_wf;                     /* bf16 [3d,d], [4d,d] */
     const float *qkv_bc, *fc_bc;                    /* fp32 [2*3d], [2*4d]: folded bias | column sums */
+    /* optional (all or none; needs the folded set above): MXFP8 copies for keds_tower_params.fp8
+     * (keds_fold_layernorm_mxfp8: in_proj / c_fc with their LayerNorm folded in, out_proj / c_proj plain);
+     * scales in the [K/128][N] dword layout */
+    const void *qkv_q8, *out_q8, *fc_q8, *proj_q8;
+    const void *qkv_s8, *out_s8, *fc_s8, *proj_s8;
+    const float *qkv_bc8, *fc_bc8;                  /* fp32 [2*3d], [2*4d] for the MXFP8 weights */
 } keds_block_params;
 
 typedef struct {
     int width, layers, heads, seq;                  /* seq = tokens per sample (257 / 77) */
     int causal;
     const keds_block_params* blocks;                /* HOST array [layers] of device pointers */
+    int fp8;                                        /* 1: BASELINE config 5 -- the four GEMMs of every block run on MXFP8
+                                                       operands (full 256-row tiles; remainder rows stay bf16); needs the
+                                                       *_q8 block fields and width % 256 == 0 */
     int last_cls_only;                              /* 1: after the LAST block only token 0 of every sample is
                                                        defined (ViT read-out): its attention queries, out-proj, ln_2
                                                        and MLP run on B rows instead of B*seq */

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 
 # ---- constants mirrored from keds_hip.h ------------------------------------------------------
-ABI_VERSION = 2
+ABI_VERSION = 3
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32 = 6, 7, 8
@@ -30,12 +30,14 @@ vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
 class BlockParams(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "out_w", "fc_w", "proj_w",
-                                  "qkv_b", "out_b", "fc_b", "proj_b", "qkv_wf", "fc_wf", "qkv_bc", "fc_bc")]
+                                  "qkv_b", "out_b", "fc_b", "proj_b", "qkv_wf", "fc_wf", "qkv_bc", "fc_bc",
+                                  "qkv_q8", "out_q8", "fc_q8", "proj_q8", "qkv_s8", "out_s8", "fc_s8", "proj_s8",
+                                  "qkv_bc8", "fc_bc8")]
 
 
 class TowerParams(C.Structure):
     _fields_ = [("width", i32), ("layers", i32), ("heads", i32), ("seq", i32), ("causal", i32),
-                ("blocks", C.POINTER(BlockParams)), ("last_cls_only", i32)]
+                ("blocks", C.POINTER(BlockParams)), ("fp8", i32), ("last_cls_only", i32)]
 
 
 class VitParams(C.Structure):

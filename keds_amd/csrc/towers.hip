@@ -21,6 +21,8 @@ struct TowerWs {
     char* big;
     float* st1;
     float* st2;
+    // MXFP8 operands of the full 256-row tiles (fp8 towers): residual copy, attention output, MLP hidden (+ scale dwords)
+    unsigned char *xq, *xs, *aq, *as, *hq, *hs;
     size_t bytes;
 };
 
@@ -35,8 +37,82 @@ TowerWs carve_tower(void* ws, int width, int seq, int B) {
     t.big = p ? p + hb : nullptr;
     t.st1 = p ? (float*)(p + hb + bb) : nullptr;
     t.st2 = p ? (float*)(p + hb + bb + sb) : nullptr;
-    t.bytes = hb + bb + 2 * sb;
+    const size_t Mm = (size_t)B * seq / 256 * 256;
+    const size_t q1 = keds_align_up(Mm * width, 256), s1 = keds_align_up(Mm * (size_t)(width / 32), 256);   // 1 scale byte / 32
+    size_t off = hb + bb + 2 * sb;
+    auto take = [&](size_t n) {
+        unsigned char* r = p ? (unsigned char*)(p + off) : nullptr;
+        off += n;
+        return r;
+    };
+    t.xq = take(q1);
+    t.xs = take(s1);
+    t.aq = take(q1);
+    t.as = take(s1);
+    t.hq = take(4 * q1);
+    t.hs = take(4 * s1);
+    t.bytes = off;
     return t;
+}
+
+// BASELINE config 5: the four GEMMs of every block on MXFP8 operands (gemm_fp8.hip).  The residual stream stays fp32;
+// its MXFP8 copy (xq, xs), the attention output (aq) and the MLP hidden (hq) are e4m3 + one e8m0 scale per 32 columns,
+// produced by the GEMM epilogues themselves (the attention output by one quantisation pass).  Rows beyond the last full
+// 256-row tile (128 of 32,896 at B = 128) keep the bf16 path: every producer below has a bf16 twin for those rows.
+int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs& t, int Mm, hipStream_t st) {
+    const int w = p->width, S = p->seq;
+    const int M = B * S, Mt = M - Mm;
+    const size_t Mp = pad_rows((size_t)M);
+    bf16_t* h = (bf16_t*)t.h;
+    bf16_t* qkv = (bf16_t*)t.big;
+    bf16_t* att = qkv + Mp * (size_t)w * 3;
+    bf16_t* hid = qkv;
+    float* st1t = t.st1 + 2 * (size_t)Mm;
+    float* st2t = t.st2 + 2 * (size_t)Mm;
+    int rc;
+    if ((rc = keds_rowstats_cast(x, h, t.st1, M, w, st))) return rc;
+    if ((rc = keds_quantize_mxfp8(x, 0, Mm, w, Mm, t.xq, t.xs, st))) return rc;
+    for (int l = 0; l < p->layers; ++l) {
+        const keds_block_params& k = p->blocks[l];
+        const bool last = l == p->layers - 1;
+        if ((rc = keds_gemm_mxfp8_ex(t.xq, t.xs, Mm, k.qkv_q8, k.qkv_s8, 3 * w, k.qkv_bc8, qkv, Mm, 3 * w, w,
+                                     KEDS_FP8_EPI_LN_BIAS_BF16, t.st1, t.st2, nullptr, nullptr, 0, st)))
+            return rc;
+        if (Mt && (rc = keds_gemm_bt_ex2(h + (size_t)Mm * w, w, k.qkv_wf, k.qkv_bc, qkv + (size_t)Mm * 3 * w, 3 * w, Mt, 3 * w, w,
+                                         KEDS_EPI_LN_BIAS_BF16, st1t, 0, st2t, st)))
+            return rc;
+        if (last && p->last_cls_only) {           // CLS rows only (see tower_forward): a handful of rows, bf16 kernels
+            const long long ld = (long long)S * w;
+            if ((rc = keds_attention_ex(qkv, att, B, S, p->heads, p->causal, 1, st))) return rc;
+            if ((rc = keds_gemm_bt_ex(att, ld, k.out_w, k.out_b, x, ld, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
+                return rc;
+            if ((rc = keds_layernorm_impl(x, w, nullptr, S, k.ln2_g, k.ln2_b, h, 0, B, w, st))) return rc;
+            if ((rc = keds_gemm_bt(h, k.fc_w, k.fc_b, hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
+            return keds_gemm_bt_ex(hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st);
+        }
+        if ((rc = keds_attention(qkv, att, B, S, p->heads, p->causal, st))) return rc;
+        if ((rc = keds_quantize_mxfp8(att, 1, Mm, w, Mm, t.aq, t.as, st))) return rc;
+        if ((rc = keds_gemm_mxfp8_ex(t.aq, t.as, Mm, k.out_q8, k.out_s8, w, k.out_b, x, Mm, w, w, KEDS_FP8_EPI_RESID_STATS_MX,
+                                     t.st2, nullptr, t.xq, t.xs, Mm, st)))
+            return rc;
+        if (Mt && (rc = keds_gemm_bt_ex2(att + (size_t)Mm * w, w, k.out_w, k.out_b, x + (size_t)Mm * w, w, Mt, w, w,
+                                         KEDS_EPI_RESID_STATS_F32, st2t, 0, h + (size_t)Mm * w, st)))
+            return rc;
+        if ((rc = keds_gemm_mxfp8_ex(t.xq, t.xs, Mm, k.fc_q8, k.fc_s8, 4 * w, k.fc_bc8, nullptr, Mm, 4 * w, w,
+                                     KEDS_FP8_EPI_LN_QGELU_MX, t.st2, t.st1, t.hq, t.hs, Mm, st)))
+            return rc;
+        if (Mt && (rc = keds_gemm_bt_ex2(h + (size_t)Mm * w, w, k.fc_wf, k.fc_bc, hid + (size_t)Mm * 4 * w, 4 * w, Mt, 4 * w, w,
+                                         KEDS_EPI_LN_QGELU_BF16, st2t, 0, st1t, st)))
+            return rc;
+        if ((rc = keds_gemm_mxfp8_ex(t.hq, t.hs, Mm, k.proj_q8, k.proj_s8, w, k.proj_b, x, Mm, w, 4 * w,
+                                     KEDS_FP8_EPI_RESID_STATS_MX, t.st1, nullptr, t.xq, t.xs, Mm, st)))
+            return rc;
+        if (Mt && (rc = keds_gemm_bt_ex2(hid + (size_t)Mm * 4 * w, 4 * w, k.proj_w, k.proj_b, x + (size_t)Mm * w, w, Mt, w, 4 * w,
+                                         last ? KEDS_EPI_BIAS_RESID_F32 : KEDS_EPI_RESID_STATS_F32, last ? nullptr : st1t, 0,
+                                         last ? nullptr : (void*)(h + (size_t)Mm * w), st)))
+            return rc;
+    }
+    return KEDS_OK;
 }
 
 int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st) {
@@ -51,11 +127,20 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
     // LayerNorm folded into the GEMMs (keds_hip.h, KEDS_EPI_LN_*): t.h holds the bf16 copy of the residual stream,
     // st1 / st2 the {sum, sum sq} of its rows as seen by ln_1 / ln_2.  Each LN-consuming GEMM also clears the
     // statistics buffer the next producer accumulates into, so no memset sits between the launches.
-    bool folded = true;
+    bool folded = true, have8 = true;
     for (int l = 0; l < p->layers; ++l) {
         const keds_block_params& k = p->blocks[l];
         folded = folded && k.qkv_wf && k.fc_wf && k.qkv_bc && k.fc_bc;
+        have8 = have8 && k.qkv_q8 && k.out_q8 && k.fc_q8 && k.proj_q8 && k.qkv_s8 && k.out_s8 && k.fc_s8 && k.proj_s8 &&
+                k.qkv_bc8 && k.fc_bc8;
     }
+    const int Mm = M / 256 * 256;                  // rows in full 256-row tiles: MXFP8 GEMMs; the rest stays on the bf16 kernels
+    const bool fp8 = p->fp8 && folded && have8 && Mm > 0 && w % 256 == 0;
+    if (p->fp8 && !fp8) {
+        keds_set_error("keds_tower_forward: fp8 needs the folded and MXFP8 weights, width %% 256 == 0 and >= 256 rows");
+        return KEDS_E_ARG;
+    }
+    if (fp8) return tower_forward_fp8(p, x, B, t, Mm, st);
     if (folded && (rc = keds_rowstats_cast(x, t.h, t.st1, M, w, st))) return rc;
     for (int l = 0; l < p->layers; ++l) {
         const keds_block_params& k = p->blocks[l];

@@ -80,7 +80,8 @@ class VisualTransformer(nn.Module):
         self.proj = nn.Parameter(scale * torch.randn(width, output_dim))
 
 
-def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: bool = False) -> _lib.TowerParams:
+def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: bool = False,
+                fp8: bool = False) -> _lib.TowerParams:
     blocks = (_lib.BlockParams * tr.layers)()
     for i, blk in enumerate(tr.resblocks):
         t = dict(
@@ -105,12 +106,30 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
             check(lib.keds_fold_layernorm(ptr(w32), ptr(lin_b), ptr(t[ln[0]]), ptr(t[ln[1]]), n, k, ptr(wf), ptr(bc),
                                           stream()), "keds_fold_layernorm")
             t[name + "_wf"], t[name + "_bc"] = wf, bc
+        if fp8 and folds:
+            # BASELINE config 5: MXFP8 copies of the four weights (in_proj / c_fc with their LayerNorm folded in)
+            for name, lin_w, lin_b, ln in (("qkv", blk.attn.in_proj_weight, t["qkv_b"], ("ln1_g", "ln1_b")),
+                                           ("out", blk.attn.out_proj.weight, t["out_b"], None),
+                                           ("fc", blk.mlp.c_fc.weight, t["fc_b"], ("ln2_g", "ln2_b")),
+                                           ("proj", blk.mlp.c_proj.weight, t["proj_b"], None)):
+                w32 = _f32(lin_w)
+                n, k = w32.shape
+                q8 = torch.empty((n, k), dtype=torch.uint8, device=w32.device)
+                s8 = torch.empty((k // 128, n, 4), dtype=torch.uint8, device=w32.device)
+                bc8 = torch.empty(2 * n, dtype=torch.float32, device=w32.device)
+                check(lib.keds_fold_layernorm_mxfp8(ptr(w32), ptr(lin_b), ptr(t[ln[0]]) if ln else None,
+                                                    ptr(t[ln[1]]) if ln else None, n, k, n, ptr(q8), ptr(s8), ptr(bc8),
+                                                    stream()), "keds_fold_layernorm_mxfp8")
+                t[name + "_q8"], t[name + "_s8"] = q8, s8
+                if ln:
+                    t[name + "_bc8"] = bc8
         torch.cuda.current_stream().synchronize()          # the fp32 temporaries die here
         for k, v in t.items():
             setattr(blocks[i], k, ptr(v))
         keep.append(t)
     keep.append(blocks)
-    return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks, 1 if cls_only else 0)
+    return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks, 1 if fp8 else 0,
+                            1 if cls_only else 0)
 
 
 class _Packed:
@@ -130,7 +149,8 @@ class _Packed:
                  ln_pre_g=_f32(v.ln_pre.weight), ln_pre_b=_f32(v.ln_pre.bias), ln_post_g=_f32(v.ln_post.weight),
                  ln_post_b=_f32(v.ln_post.bias), proj_t=_bf16(v.proj.detach().t()))
         self.keep.append(t)
-        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep, cls_only=True),
+        fp8 = getattr(clip, "precision", "bf16") == "fp8"
+        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep, cls_only=True, fp8=fp8),
                                   v.input_resolution, P,
                                   self.kpad, v.output_dim, *[ptr(t[k]) for k in (
                                       "conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
@@ -172,6 +192,7 @@ class CLIP(nn.Module):
         self.initialize_parameters()
         self._packed: Optional[_Packed] = None
         self._ws = _lib.Workspace()
+        self.precision = os.environ.get("KEDS_PRECISION", "bf16")
 
     # ---- init (same distributions as model.py:511-541) ------------------------------------------
     def initialize_parameters(self):
@@ -205,6 +226,17 @@ class CLIP(nn.Module):
     def repack(self):
         """Re-read the parameters (call after mutating weights in place)."""
         self._packed = None
+
+    def set_precision(self, precision: str = "bf16"):
+        """"bf16" (default: bf16 GEMM operands) or "fp8" (BASELINE config 5: the image tower's GEMMs on MXFP8 operands --
+        OCP e4m3 with an e8m0 scale per 32 elements; needs vision width % 256 == 0; the text tower stays bf16)."""
+        if precision not in ("bf16", "fp8"):
+            raise ValueError("precision must be 'bf16' or 'fp8'")
+        if precision == "fp8" and (self.visual.transformer.width % 256 != 0 or os.environ.get("KEDS_DETERMINISTIC", "0") == "1"):
+            raise ValueError("fp8 needs a vision width that is a multiple of 256 and the folded LayerNorm path")
+        self.precision = precision
+        self._packed = None
+        return self
 
     def _engine(self) -> _Packed:
         _lib.require_gpu()

@@ -180,3 +180,33 @@ def test_mxfp8_residual_stats_epilogue(M, N, K):
     qt, st = _torch_mx(x)                                          # the MXFP8 copy is the quantisation of the NEW rows
     assert torch.equal(q, qt) and torch.equal(qs.permute(1, 0, 2).reshape(M, N // 32), st)
     assert torch.allclose(stats[:, 0], x.sum(1), rtol=1e-4, atol=2e-3) and torch.allclose(stats[:, 1], (x * x).sum(1), rtol=1e-4)
+
+
+def test_vitl14_fp8_encoder_against_reference_golden():
+    """BASELINE config 5: ViT-L/14 with MXFP8 GEMM operands vs the reference's fp32 outputs.  Stated tolerance for the fp8
+    path: cosine >= 0.995 per row, rel-L2 <= 0.1 (two e4m3 operands per GEMM, 48 GEMMs deep; bf16 path: 0.9999 / 1.5e-2).
+    B = 2 gives 514 rows = two full 256-row MXFP8 tiles + 2 remainder rows on the bf16 kernels; B = 5 adds a ragged case."""
+    import keds_amd
+    from oracle import keds_oracle as O
+    from tests.conftest import golden_path
+    from tests.gpu_util import min_cosine
+    from tests.test_gpu_model import VITL
+    g = dict(np.load(golden_path("clip_vitl14.npz")))
+    sd = O.synth_clip_state_dict(**VITL, seed=7)
+    m = keds_amd.build_model(sd, fp16=False).cuda().set_precision("fp8")
+    img = torch.from_numpy(g["image"]).cuda()
+    out = m.encode_image(img)
+    c, r = min_cosine(out, g["encode_image"]), rel_l2(out, g["encode_image"])
+    report("vitl14_fp8.encode_image", min_cosine=c, rel_l2=r)
+    assert torch.isfinite(out).all() and c >= 0.995 and r <= 0.1
+    ref = m.set_precision("bf16").encode_image(img)
+    assert min_cosine(ref, g["encode_image"]) >= 0.9999            # switching back restores the bf16 path
+    rs = np.random.RandomState(3)
+    img5 = torch.from_numpy(rs.standard_normal((5, 3, 224, 224)).astype(np.float32)).cuda()
+    a = m.set_precision("fp8").encode_image(img5)
+    b = m.set_precision("bf16").encode_image(img5)
+    c5 = min_cosine(a, b)
+    report("vitl14_fp8.vs_bf16_B5", min_cosine=c5, rel_l2=rel_l2(a, b))
+    assert c5 >= 0.995
+    with pytest.raises(ValueError):
+        m.set_precision("int4")
