@@ -170,14 +170,17 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
     // also bring the 1 KiB of X / W scale dwords of the K-tile
     const int R0 = 8 * wave + (lane >> 3);
     const int sch = (lane & 7) ^ swz_f8(R0);
-    const unsigned char* xsrc = X + (size_t)(m0 + R0) * K + sch * 16;
-    const unsigned char* wsrc = W + (size_t)(n0 + perm_w8(R0)) * K + sch * 16;
-    const size_t rstride = (size_t)64 * K;
-    const unsigned char* ssrc = wave == 0 ? sX + ((size_t)m0 + lane * 4) * 4 : sW + ((size_t)n0 + lane * 4) * 4;
+    // uniform tile bases (SGPRs) + 32-bit lane offsets: 64-bit per-lane pointers cost 6 VGPRs this kernel does not have
+    const unsigned char* xt = X + (size_t)m0 * K;
+    const unsigned char* wt = W + (size_t)n0 * K;
+    const unsigned xoff = (unsigned)R0 * (unsigned)K + sch * 16;
+    const unsigned woff = (unsigned)perm_w8(R0) * (unsigned)K + sch * 16;
+    const unsigned rstride = 64u * (unsigned)K;
+    const unsigned char* st_base = wave == 0 ? sX + (size_t)m0 * 4 : sW + (size_t)n0 * 4;
     const size_t sstride = (size_t)(wave == 0 ? m_pad : n_pad) * 4;               // next K-tile's dwords
     auto issue = [&](int p, int q) {
         const int i = q & 3;
-        const unsigned char* src = (q < 4 ? xsrc : wsrc) + i * rstride + (size_t)p * TKB;
+        const unsigned char* src = (q < 4 ? xt + (xoff + i * rstride + (unsigned)p * TKB) : wt + (woff + i * rstride + (unsigned)p * TKB));
         char* dst = smem + (p & 1) * PBUF_BYTES + (q < 4 ? 0 : OP_BYTES) + (wave + 8 * i) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -185,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
     auto issue_scales = [&](int p) {
         if (wave < 2) {
             char* dst = smem + (p & 1) * PBUF_BYTES + 2 * OP_BYTES + wave * SC_BYTES;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ssrc + (size_t)p * sstride),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(st_base + (size_t)p * sstride + lane * 16),
                                              (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
         }
     };
@@ -195,9 +198,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
     const int wrow = OP_BYTES + (64 * wn + c) * 128;               // + ni * 2048
     // scale dwords: X row 128*wm + 16*mi + c; W LDS row R = 64*wn + 16*ni + c holds W row perm_w8(R & 63) + 64*(R >> 6)
     const int sx_off = 2 * OP_BYTES + (128 * wm + c) * 4;          // + mi * 64
-    int sw_off[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) sw_off[ni] = 2 * OP_BYTES + SC_BYTES + (64 * wn + perm_w8(16 * ni + c)) * 4;
+    // perm_w8(16*ni + c) = [8*(c>>2) + (c&3)] + [32*((ni>>1)&1) + 4*(ni&1)]: one lane-dependent base + a constant per ni
+    const int sw_base = 2 * OP_BYTES + SC_BYTES + (64 * wn + 8 * (c >> 2) + (c & 3)) * 4;
 
     f32x4 acc[4][8];
 #pragma unroll
@@ -233,15 +235,27 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
     // (fp8 itself: 1.3x over bf16 at K = 4096), not a tighter schedule.
     const int grp = wave >> 2;
     i32x8 wf[4], xf[8];
-    int swv[4], sxv[8];
+    int swp = 0, sxp[2] = {0, 0};          // e8m0 scales packed four to a register, picked by the MFMA's op_sel byte
     auto multiply = [&]() {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < 8; ++mi) {
+#define KEDS_FP8_MFMA(NI, OB)                                                                                         \
+    acc[NI][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[NI], xf[mi], acc[NI][mi], 0, 0, NI, swp, OB, sxp[mi >> 2]);
+#define KEDS_FP8_ROW(OB) KEDS_FP8_MFMA(0, OB) KEDS_FP8_MFMA(1, OB) KEDS_FP8_MFMA(2, OB) KEDS_FP8_MFMA(3, OB)
+            if constexpr (DBG == 2) {
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                if constexpr (DBG == 2) acc[ni][mi][0] += __int_as_float(wf[ni][0] ^ xf[mi][3] ^ swv[ni] ^ sxv[mi]);
-                else acc[ni][mi] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0, swv[ni], 0, sxv[mi]);
+                for (int ni = 0; ni < 4; ++ni) acc[ni][mi][0] += __int_as_float(wf[ni][0] ^ xf[mi][3] ^ swp ^ sxp[mi >> 2]);
+            } else {
+                switch (mi & 3) {                      // op_sel is an immediate: the unrolled mi makes this a constant
+                    case 0: KEDS_FP8_ROW(0) break;
+                    case 1: KEDS_FP8_ROW(1) break;
+                    case 2: KEDS_FP8_ROW(2) break;
+                    default: KEDS_FP8_ROW(3) break;
+                }
             }
+#undef KEDS_FP8_ROW
+#undef KEDS_FP8_MFMA
+        }
     };
     unsigned long long t0 = 0, r0 = 0;
     if constexpr (DBG == 3) {                                      // diagnostic build only
@@ -261,28 +275,28 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
         if (grp == 1 && p > 0 && DBG != 1) multiply();
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (DBG != 1 && DBG != 4) {
+            swp = 0;
+            sxp[0] = sxp[1] = 0;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
                 wf[ni] = load_frag(cb, wrow + ni * 2048);
-                swv[ni] = *reinterpret_cast<const int*>(cb + sw_off[ni]) >> (8 * g);
+                swp |= ((*reinterpret_cast<const unsigned*>(cb + sw_base + (32 * ((ni >> 1) & 1) + 4 * (ni & 1)) * 4) >> (8 * g)) & 0xFFu) << (8 * ni);
             }
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
                 xf[mi] = load_frag(cb, xrow + mi * 2048);
-                sxv[mi] = *reinterpret_cast<const int*>(cb + sx_off + mi * 64) >> (8 * g);
+                sxp[mi >> 2] |= ((*reinterpret_cast<const unsigned*>(cb + sx_off + mi * 64) >> (8 * g)) & 0xFFu) << (8 * (mi & 3));
             }
         } else if (p == 0) {
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) xf[mi][j] = lane * 0x01010101 + j + mi;
-                sxv[mi] = 127 + (lane & 1);
             }
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-                wf[ni] = xf[ni] + ni;
-                swv[ni] = 127;
-            }
+            for (int ni = 0; ni < 4; ++ni) wf[ni] = xf[ni] + ni;
+            swp = 0x7F7F7F7F;
+            sxp[0] = sxp[1] = 0x7F7F7F7F + (lane & 1);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (grp == 0 && DBG != 1) multiply();
