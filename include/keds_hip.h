@@ -214,6 +214,10 @@ int keds_attention_debug(int variant);
 int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream);
 /* same, computing and storing only the first q_limit query rows of every sample (keys/values: all S rows) */
 int keds_attention_ex(const void* qkv, void* out, int B, int S, int heads, int causal, int q_limit, void* stream);
+/* fp8 towers: rows < q8_rows of the output are written as MXFP8 (q8 [q8_rows, d] e4m3, s8 scale dwords [d/128][q8_rows])
+ * INSTEAD of bf16; the remaining rows go to `out` as usual */
+int keds_attention_mx(const void* qkv, void* out, int B, int S, int heads, int causal, int q_limit, void* q8, void* s8,
+                      int q8_rows, void* stream);
 
 /* patch im2col for conv1 (model.py:381,394-396): image fp32 [B,3,R,R] -> bf16 [B*G, Kpad],
  * column c*P*P + ky*P + kx, zero padded to Kpad (a multiple of 64). */

@@ -136,6 +136,7 @@ SIGNATURES = {
     "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "keds_attention_debug": (i32, [i32]),
     "keds_attention_ex": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "keds_attention_mx": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     "keds_attention": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_im2col": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_embed_tokens": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),

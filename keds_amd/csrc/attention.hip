@@ -41,6 +41,10 @@ struct AttnCtx {
     const char* k_lds;
     const char* vt_lds;
     int S, q_limit, ld, d, g, c;
+    // fp8 towers: rows < q8_rows of the [B*S, d] output go out as MXFP8 (e4m3 + e8m0 per 32 columns) INSTEAD of bf16
+    unsigned char* q8;    // element (row, col) at q8[row*d + col]; nullptr = bf16 everywhere
+    unsigned char* s8;    // scale dwords [d/128][q8_rows]
+    int q8_rows, row0, col0;   // first global row of this sample, first column of this head
 };
 
 // NQ consecutive 16-query tiles starting at tile qt0, for one wave.
@@ -157,11 +161,32 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         if (qidx[t] < cx.q_limit) {
-            bf16_t* op = cx.out + (size_t)qidx[t] * cx.d + 4 * g;
+            const int row = cx.row0 + qidx[t];
+            if (cx.q8 && row < cx.q8_rows) {
+                // lane (g, c): head columns 16*dt + 4g + r; a 32-column MX block = dt in {2b, 2b+1} over the four g lanes
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                const f32x4 v = o[t][dt] * inv[t];
-                *reinterpret_cast<bf16x4*>(op + dt * 16) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                for (int b2 = 0; b2 < 2; ++b2) {
+                    const f32x4 v0 = o[t][2 * b2] * inv[t], v1 = o[t][2 * b2 + 1] * inv[t];
+                    const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    float amax = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+                    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                    const int e = mx_block_exp(amax);
+                    const uint2 pk = mx_pack8(v, e);
+                    unsigned char* qp = cx.q8 + (size_t)row * cx.d + cx.col0 + 32 * b2 + 4 * g;
+                    *reinterpret_cast<unsigned*>(qp) = pk.x;
+                    *reinterpret_cast<unsigned*>(qp + 16) = pk.y;
+                    if (g == 0) cx.s8[mx_scale_index((cx.col0 >> 5) + b2, row, cx.q8_rows)] = (unsigned char)(e + 127);
+                }
+            } else {
+                bf16_t* op = cx.out + (size_t)qidx[t] * cx.d + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    const f32x4 v = o[t][dt] * inv[t];
+                    *reinterpret_cast<bf16x4*>(op + dt * 16) = bf16x4{(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+                }
             }
         }
     }
@@ -172,7 +197,8 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
 // need no mask (non-causal only) -- evaluating the mask for all 72 score registers cost half the loop's instructions.
 template <int NKT, bool CAUSAL, int NFULL, int DBG = 0, bool NQ2 = (NKT == 18 && !CAUSAL)>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
-                                                        int heads, int q_limit) {
+                                                        int heads, int q_limit, unsigned char* __restrict__ q8,
+                                                        unsigned char* __restrict__ s8, int q8_rows) {
     using C = AttnCfg<NKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -233,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     // ---- queries: NQ = 2 tiles (32 queries) per step share every K / V^T fragment read from LDS (the loop is
     // LDS-bandwidth bound: 72 ds_read_b128 per 16-query tile); an odd last tile runs alone on a rotating wave.
     const int nqt = DBG == 5 ? 0 : (q_limit + 15) >> 4;      // only the first q_limit query rows are computed and stored
-    AttnCtx cx{base, out + (size_t)b * S * d + h * DH, k_lds, vt_lds, S, q_limit, ld, d, g, c};
+    AttnCtx cx{base, out + (size_t)b * S * d + h * DH, k_lds, vt_lds, S, q_limit, ld, d, g, c, q8, s8, q8_rows, b * S, h * DH};
     if constexpr (NQ2) {
         const int npair = nqt >> 1;
         for (int qp = wave; qp < npair; qp += 4) attn_tiles<NKT, CAUSAL, NFULL, DBG, 2>(cx, 2 * qp);
@@ -246,7 +272,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
 int g_attn_debug = 0;   // timing-only ablations (ViT kernel)
 
 template <int NKT, bool CAUSAL, int NFULL>
-int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit, hipStream_t st) {
+int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit, void* q8, void* s8, int q8_rows,
+                hipStream_t st) {
     using C = AttnCfg<NKT>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -264,7 +291,7 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit
     {                                                                                                            \
         (void)hipFuncSetAttribute((const void*)attention_kernel<NKT, CAUSAL, NFULL, V>,                          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);                           \
-        attention_kernel<NKT, CAUSAL, NFULL, V><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit); \
+        attention_kernel<NKT, CAUSAL, NFULL, V><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit, (unsigned char*)q8, (unsigned char*)s8, q8_rows); \
     }
             switch (g_attn_debug) {
                 case 1: KEDS_ATTN_DBG(1) break;
@@ -277,7 +304,8 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit
             return keds_check_launch("attention_kernel<dbg>");
         }
     }
-    attention_kernel<NKT, CAUSAL, NFULL><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit);
+    attention_kernel<NKT, CAUSAL, NFULL><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit,
+                                                                         (unsigned char*)q8, (unsigned char*)s8, q8_rows);
     return keds_check_launch("attention_kernel");
 }
 
@@ -290,19 +318,26 @@ extern "C" int keds_attention_debug(int variant) {
 
 extern "C" int keds_attention_ex(const void* qkv, void* out, int B, int S, int heads, int causal, int q_limit,
                                  void* stream) {
+    return keds_attention_mx(qkv, out, B, S, heads, causal, q_limit, nullptr, nullptr, 0, stream);
+}
+
+extern "C" int keds_attention_mx(const void* qkv, void* out, int B, int S, int heads, int causal, int q_limit, void* q8,
+                                 void* s8, int q8_rows, void* stream) {
     KEDS_REQUIRE(qkv && out && B > 0 && heads > 0, "keds_attention: bad argument");
+    KEDS_REQUIRE((q8 == nullptr) == (s8 == nullptr) && (q8 == nullptr || (q8_rows > 0 && (heads * 64) % 128 == 0)),
+                 "keds_attention_mx: q8, s8 and q8_rows come together; width must be a multiple of 128");
     KEDS_REQUIRE(S >= 1 && S <= 288, "keds_attention: S=%d unsupported (1..288)", S);
     if (q_limit <= 0 || q_limit > S) q_limit = S;
     hipStream_t st = (hipStream_t)stream;
     if (causal) {
-        if (S <= 32) return launch_attn<2, true, 0>(qkv, out, B, S, heads, q_limit, st);
-        if (S <= 96) return launch_attn<6, true, 0>(qkv, out, B, S, heads, q_limit, st);
-        return launch_attn<18, true, 0>(qkv, out, B, S, heads, q_limit, st);
+        if (S <= 32) return launch_attn<2, true, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
+        if (S <= 96) return launch_attn<6, true, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
+        return launch_attn<18, true, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
     }
-    if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, q_limit, st);
-    if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, q_limit, st);
-    if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, q_limit, st);   // ViT-L/14: 257 tokens
-    return launch_attn<18, false, 0>(qkv, out, B, S, heads, q_limit, st);
+    if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
+    if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
+    if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);   // ViT-L/14: 257 tokens
+    return launch_attn<18, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
 }
 
 extern "C" int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream) {

@@ -63,3 +63,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
     return base + (bid >> 3);
 }
+
+// ---- OCP MX (e4m3 elements, one e8m0 scale per 32) helpers shared by gemm_fp8.hip and attention.hip --------------
+// OCP MX shared exponent of a 32-element block from its amax: floor(log2(amax)) - 8 (emax of e4m3), clamped to e8m0
+__device__ __forceinline__ int mx_block_exp(float amax) {
+    int e = amax > 0.f ? (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127 - 8 : -127;
+    return e < -127 ? -127 : (e > 127 ? 127 : e);
+}
+// eight values scaled by 2^-e, saturated at +-448, rounded to nearest even e4m3: two dwords of four bytes
+__device__ __forceinline__ uint2 mx_pack8(const float (&v)[8], int e) {
+    const float inv = e == -127 ? 0.f : __uint_as_float((unsigned)(127 - e) << 23);
+    float s[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = fminf(fmaxf(v[j] * inv, -448.f), 448.f);
+    unsigned lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(s[0], s[1], lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(s[2], s[3], lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(s[4], s[5], hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(s[6], s[7], hi, true);
+    return uint2{lo, hi};
+}
+// scale byte of block `blk` (32 columns) of row r in the [K/128][rows_pad] dword layout
+__device__ __forceinline__ size_t mx_scale_index(int blk, int r, int rows_pad) {
+    return ((size_t)(blk >> 2) * rows_pad + r) * 4 + (blk & 3);
+}

@@ -90,8 +90,8 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
             if ((rc = keds_gemm_bt(h, k.fc_w, k.fc_b, hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
             return keds_gemm_bt_ex(hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st);
         }
-        if ((rc = keds_attention(qkv, att, B, S, p->heads, p->causal, st))) return rc;
-        if ((rc = keds_quantize_mxfp8(att, 1, Mm, w, Mm, t.aq, t.as, st))) return rc;
+        // attention writes its output as MXFP8 for the full-tile rows and as bf16 for the remainder rows
+        if ((rc = keds_attention_mx(qkv, att, B, S, p->heads, p->causal, S, t.aq, t.as, Mm, st))) return rc;
         if ((rc = keds_gemm_mxfp8_ex(t.aq, t.as, Mm, k.out_q8, k.out_s8, w, k.out_b, x, Mm, w, w, KEDS_FP8_EPI_RESID_STATS_MX,
                                      t.st2, nullptr, t.xq, t.xs, Mm, st)))
             return rc;

@@ -210,3 +210,27 @@ def test_vitl14_fp8_encoder_against_reference_golden():
     assert c5 >= 0.995
     with pytest.raises(ValueError):
         m.set_precision("int4")
+
+
+def test_attention_mxfp8_output_equals_quantised_bf16_path():
+    """keds_attention_mx: rows below q8_rows leave the attention kernel as MXFP8, the rest as bf16.  Quantising the fp32
+    result before (here) or after (reference: bf16 output, then the quantiser) the bf16 rounding differs by one bf16 ulp
+    of the input at most, so the decoded tensors agree to fp8 resolution and the bf16 rows are bit-identical."""
+    from keds_amd import ops
+    lib = _lib.load()
+    B, S, H = 3, 257, 16
+    d = H * 64
+    g = torch.Generator(device="cuda").manual_seed(9)
+    qkv = (torch.randn(B * S, 3 * d, generator=g, device="cuda") * 1.2).to(torch.bfloat16)
+    ref = ops.attention(qkv, B, S, H, False)                                    # bf16 everywhere
+    rows8 = 512
+    out = torch.zeros((B * S, d), dtype=torch.bfloat16, device="cuda")
+    q8 = torch.zeros((rows8, d), dtype=torch.uint8, device="cuda")
+    s8 = torch.full((d // 128, rows8, 4), 127, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.keds_attention_mx(_lib.ptr(qkv), _lib.ptr(out), B, S, H, 0, S, _lib.ptr(q8), _lib.ptr(s8), rows8,
+                                     _lib.stream()), "attention_mx")
+    assert torch.equal(out[rows8:], ref[rows8:]) and bool((out[:rows8] == 0).all())
+    got = _dequantize(q8, s8)
+    assert rel_l2(got, ref[:rows8].float()) <= 4e-2
+    qt, st = _torch_mx(got)                                                      # a valid MX tensor: re-quantising reproduces it
+    assert torch.equal(qt, q8)
