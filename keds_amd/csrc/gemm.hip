@@ -484,7 +484,8 @@ constexpr int LDS_BYTES = 2 * PBUF_BYTES;       // 128 KiB
 // MFMA loop sustains 2.06 PFLOP/s on this chip (clock ~2.0 GHz under load), so 1.25-1.3 PF in this loop is ~62 % of the
 // practical peak; the vendor BLAS reaches 1.07 / 1.20 / 1.46 PF on the qkv / fc / proj shapes where this kernel does
 // 1.08 / 1.11 / 1.21.  A 4-wave variant (128 x 128 per wave, 256 accumulators pinned in AGPRs through inline-asm
-// MFMAs) was built and was not faster (1.29 vs 1.32 PF at 8192^3).
+// MFMAs) was built and was not faster (1.29 vs 1.32 PF at 8192^3); with the MFMA builtin the register allocator moves
+// ~30 accumulators between AGPRs and VGPRs every K-tile (2 v_accvgpr ops per MFMA): correct, 1.21 vs 1.32 PF.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
