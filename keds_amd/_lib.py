@@ -73,7 +73,7 @@ class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", vp), ("dtype", i32), ("ndim", i32), ("shape", i64 * 4)]
 
 
-DT_F32, DT_BF16, DT_F16 = 0, 1, 2
+DT_F32, DT_BF16, DT_F16, DT_FP8 = 0, 1, 2, 3
 COMM_ID_BYTES = 128
 pp = C.POINTER(vp)      # handle out-parameter
 

@@ -178,7 +178,8 @@ struct Loader {
 };
 
 // resblocks of one tower (model.py:305-326): keys <prefix>transformer.resblocks.<i>.*
-int load_blocks(const Loader& L, const std::string& prefix, int width, int layers, std::vector<keds_block_params>& blocks) {
+int load_blocks(const Loader& L, const std::string& prefix, int width, int layers, std::vector<keds_block_params>& blocks,
+                bool fp8) {
     blocks.assign(layers, keds_block_params{});
     for (int i = 0; i < layers; ++i) {
         const std::string b = prefix + "transformer.resblocks." + std::to_string(i) + ".";
@@ -222,6 +223,29 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
         p.fc_wf = ff;
         p.qkv_bc = qb;
         p.fc_bc = fb;
+        if (fp8) {   // MXFP8 copies of the four weights (keds_fold_layernorm_mxfp8; KEDS_FP8 compute, BASELINE config 5)
+            const float *wo, *wp;
+            if ((rc = T.mat<float>(b + "attn.out_proj.weight", width, width, &wo)) ||
+                (rc = T.mat<float>(b + "mlp.c_proj.weight", width, 4 * width, &wp)))
+                return rc;
+            struct Item { const float* w; const float* bias; const float* g; const float* be; int n, k; const void** q; const void** s; const float** bc; };
+            const float* scratch_bc = nullptr;
+            Item items[4] = {{wq, p.qkv_b, p.ln1_g, p.ln1_b, 3 * width, width, &p.qkv_q8, &p.qkv_s8, &p.qkv_bc8},
+                             {wo, p.out_b, nullptr, nullptr, width, width, &p.out_q8, &p.out_s8, &scratch_bc},
+                             {wf, p.fc_b, p.ln2_g, p.ln2_b, 4 * width, width, &p.fc_q8, &p.fc_s8, &p.fc_bc8},
+                             {wp, p.proj_b, nullptr, nullptr, width, 4 * width, &p.proj_q8, &p.proj_s8, &scratch_bc}};
+            for (const Item& it : items) {
+                void* q = L.mem.alloc((size_t)it.n * it.k);
+                void* sc = L.mem.alloc(keds_mxfp8_scale_bytes(it.n, it.k));
+                float* bc = (float*)L.mem.alloc((size_t)2 * it.n * sizeof(float));
+                KEDS_REQUIRE(q && sc && bc, "%s: out of device memory", L.what);
+                if ((rc = keds_fold_layernorm_mxfp8(it.w, it.bias, it.g, it.be, it.n, it.k, it.n, q, sc, bc, nullptr))) return rc;
+                *it.q = q;
+                *it.s = sc;
+                *it.bc = bc;
+            }
+            HIP_TRY(hipDeviceSynchronize(), L.what);
+        }
     }
     return KEDS_OK;
 }
@@ -352,7 +376,7 @@ extern "C" int keds_ctx_destroy(keds_ctx* ctx) {
 extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_vit** out) {
     const char* what = "keds_vit_create";
     KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
-    KEDS_REQUIRE(compute == KEDS_BF16, "%s: compute dtype must be KEDS_BF16 (bf16 operands, fp32 accumulate)", what);
+    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8, "%s: compute dtype must be KEDS_BF16 or KEDS_FP8", what);
     int rc = use_device(ctx, what);
     if (rc) return rc;
     Weights W(weights, n);
@@ -378,7 +402,12 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
                        layers);
         return fail(KEDS_E_ARG);
     }
-    if ((rc = load_blocks(L, "visual.", width, layers, v->blocks))) return fail(rc);
+    const bool fp8 = compute == KEDS_FP8;
+    if (fp8 && width % 256 != 0) {
+        keds_set_error("%s: KEDS_FP8 needs a width that is a multiple of 256", what);
+        return fail(KEDS_E_ARG);
+    }
+    if ((rc = load_blocks(L, "visual.", width, layers, v->blocks, fp8))) return fail(rc);
     keds_vit_params& p = v->p;
     memset(&p, 0, sizeof(p));
     p.tower.width = width;
@@ -388,6 +417,7 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
     p.tower.causal = 0;
     p.tower.blocks = v->blocks.data();
     p.tower.last_cls_only = 1;
+    p.tower.fp8 = fp8 ? 1 : 0;
     p.resolution = grid * patch;
     p.patch = patch;
     const int kreal = 3 * patch * patch;
@@ -451,7 +481,7 @@ extern "C" int keds_vit_forward(keds_vit* vit, const void* image, int img_dtype,
 extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_text** out) {
     const char* what = "keds_text_create";
     KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
-    KEDS_REQUIRE(compute == KEDS_BF16, "%s: compute dtype must be KEDS_BF16", what);
+    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8, "%s: compute dtype must be KEDS_BF16 or KEDS_FP8", what);
     int rc = use_device(ctx, what);
     if (rc) return rc;
     Weights W(weights, n);
@@ -475,7 +505,8 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
         keds_set_error("%s: inconsistent text tower shapes (width %d, context %d, layers %d)", what, width, context, layers);
         return fail(KEDS_E_ARG);
     }
-    if ((rc = load_blocks(L, "", width, layers, t->blocks))) return fail(rc);
+    const bool fp8 = compute == KEDS_FP8 && width % 256 == 0;
+    if ((rc = load_blocks(L, "", width, layers, t->blocks, fp8))) return fail(rc);
     keds_text_params& p = t->p;
     memset(&p, 0, sizeof(p));
     p.tower.width = width;
@@ -485,6 +516,7 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
     p.tower.causal = 1;
     p.tower.blocks = t->blocks.data();
     p.tower.last_cls_only = 0;
+    p.tower.fp8 = fp8 ? 1 : 0;
     p.vocab = vocab;
     p.embed_dim = embed;
     const bf16_t* proj_t;

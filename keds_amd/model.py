@@ -159,7 +159,8 @@ class _Packed:
                   ln_final_g=_f32(clip.ln_final.weight), ln_final_b=_f32(clip.ln_final.bias),
                   proj_t=_bf16(clip.text_projection.detach().t()))
         self.keep.append(tt)
-        self.text = _lib.TextParams(_pack_tower(clip.transformer, clip.context_length, True, self.keep),
+        self.text = _lib.TextParams(_pack_tower(clip.transformer, clip.context_length, True, self.keep,
+                                                fp8=fp8 and clip.transformer.width % 256 == 0),
                                     clip.vocab_size, clip.embed_dim,
                                     *[ptr(tt[k]) for k in ("token_emb", "pos_emb", "ln_final_g", "ln_final_b", "proj_t")])
         self.device = conv.device
@@ -229,7 +230,8 @@ class CLIP(nn.Module):
 
     def set_precision(self, precision: str = "bf16"):
         """"bf16" (default: bf16 GEMM operands) or "fp8" (BASELINE config 5: the image tower's GEMMs on MXFP8 operands --
-        OCP e4m3 with an e8m0 scale per 32 elements; needs vision width % 256 == 0; the text tower stays bf16)."""
+        OCP e4m3 with an e8m0 scale per 32 elements; needs vision width % 256 == 0; the text tower follows when its width is
+        a multiple of 256 too, e.g. 768)."""
         if precision not in ("bf16", "fp8"):
             raise ValueError("precision must be 'bf16' or 'fp8'")
         if precision == "fp8" and (self.visual.transformer.width % 256 != 0 or os.environ.get("KEDS_DETERMINISTIC", "0") == "1"):

@@ -92,10 +92,10 @@ class Vit(_Handle):
     """CLIP.encode_image (src/model/model.py:569-575) from the `visual.*` keys of a CLIP state_dict."""
     _destroy = "keds_vit_destroy"
 
-    def __init__(self, ctx: Context, state_dict):
+    def __init__(self, ctx: Context, state_dict, compute: int = _lib.DT_BF16):
         super().__init__(ctx)
         arr, keep = _tensor_list({k: v for k, v in state_dict.items() if k.startswith("visual.")})
-        check(load().keds_vit_create(ctx.h, arr, len(arr), _lib.DT_BF16, C.byref(self.h)), "keds_vit_create")
+        check(load().keds_vit_create(ctx.h, arr, len(arr), compute, C.byref(self.h)), "keds_vit_create")
         info = [C.c_int() for _ in range(5)]
         check(load().keds_vit_info(self.h, *[C.byref(i) for i in info]), "keds_vit_info")
         self.width, self.layers, self.resolution, self.patch, self.embed_dim = [i.value for i in info]
@@ -112,10 +112,10 @@ class Text(_Handle):
     """CLIP.encode_text / encode_text_img_retrieval (src/model/model.py:577-590, 808-851)."""
     _destroy = "keds_text_destroy"
 
-    def __init__(self, ctx: Context, state_dict):
+    def __init__(self, ctx: Context, state_dict, compute: int = _lib.DT_BF16):
         super().__init__(ctx)
         arr, keep = _tensor_list({k: v for k, v in state_dict.items() if not k.startswith("visual.")})
-        check(load().keds_text_create(ctx.h, arr, len(arr), _lib.DT_BF16, C.byref(self.h)), "keds_text_create")
+        check(load().keds_text_create(ctx.h, arr, len(arr), compute, C.byref(self.h)), "keds_text_create")
         info = [C.c_int() for _ in range(5)]
         check(load().keds_text_info(self.h, *[C.byref(i) for i in info]), "keds_text_info")
         self.width, self.layers, self.context, self.vocab, self.embed_dim = [i.value for i in info]

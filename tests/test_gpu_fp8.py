@@ -234,3 +234,41 @@ def test_attention_mxfp8_output_equals_quantised_bf16_path():
     assert rel_l2(got, ref[:rows8].float()) <= 4e-2
     qt, st = _torch_mx(got)                                                      # a valid MX tensor: re-quantising reproduces it
     assert torch.equal(qt, q8)
+
+
+def test_text_tower_and_session_handles_in_fp8():
+    """The text tower (width 768 = 3 x 256) follows set_precision('fp8'); the handle ABI takes KEDS_FP8 as compute type
+    and runs the same kernels as the torch-hosted path."""
+    import keds_amd
+    from keds_amd import session
+    from oracle import keds_oracle as O
+    from tests.conftest import golden_path
+    from tests.gpu_util import min_cosine
+    from tests.test_gpu_model import VITL
+    g = dict(np.load(golden_path("clip_vitl14.npz")))
+    sd = O.synth_clip_state_dict(**VITL, seed=7)
+    m = keds_amd.build_model(sd, fp16=False).cuda().set_precision("fp8")
+    text = torch.from_numpy(g["text"]).cuda()
+    rs = np.random.RandomState(11)
+    many = torch.from_numpy(np.tile(g["text"], (5, 1))).cuda()                  # 10 rows x 77 = 770 rows: three full tiles + 2 rows
+    t8 = m.encode_text(many)
+    c = min_cosine(t8[:2], g["encode_text"])
+    report("vitl14_fp8.encode_text", min_cosine=c, rel_l2=rel_l2(t8[:2], g["encode_text"]))
+    assert c >= 0.99            # the 12-block text tower is more sensitive to e4m3 operands than the image tower (measured 0.9935)
+    tok3 = torch.from_numpy(np.tile(g["tok3"], (5, 1, 1))).cuda()
+    e8 = m.encode_text_img_retrieval(many, tok3, split_ind=265, repeat=False)
+    assert min_cosine(e8[:2], g["eti3"]) >= 0.99
+    ctx = session.Context(0)
+    try:
+        vit = session.Vit(ctx, {k: v.numpy() for k, v in sd.items()}, compute=_lib.DT_FP8)
+        img = torch.from_numpy(g["image"]).cuda()
+        # same kernels.  The LayerNorm row statistics are fp32 atomics; a last-bit difference there flips e4m3 roundings
+        # downstream, so two fp8 runs of ONE model agree to cosine ~0.99975 (measured), not bitwise
+        assert min_cosine(vit.forward(img), m.encode_image(img)) >= 0.9995
+        txt = session.Text(ctx, {k: v.numpy() for k, v in sd.items()}, compute=_lib.DT_FP8)
+        eot = (many == 49407).int().argmax(dim=1)
+        assert min_cosine(txt.forward(many, eot), t8) >= 0.999
+        vit.close()
+        txt.close()
+    finally:
+        ctx.close()
