@@ -131,11 +131,12 @@ int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery
  *     LN(x) W^T + b = rstd (x W'^T - mean colsum(W')) + (b + W beta),   W' = bf16(W diag(gamma))
  * so the 2 x layers LayerNorm passes over the residual stream disappear (keds_fold_layernorm builds W', colsum, b'). */
 #define KEDS_EPI_LN_BIAS_BF16 6     /* out bf16 = rstd[m] (acc - mean[m] csum[n]) + bias'[n];  bias = [bias'(N) | csum(N)],
-                                       aux = row stats fp32 [M,2] of A's rows (LayerNorm width = K),
-                                       aux2 (nullable) = fp32 [M,2] buffer that is ZEROED for this launch's rows */
+                                       aux = row statistics [M,2] of A's rows (LayerNorm width = K): {sum, sum of squares} as
+                                       64-bit fixed point (value * 2^28; integer atomics: order independent, deterministic),
+                                       aux2 (nullable) = statistics buffer that is ZEROED for this launch's rows */
 #define KEDS_EPI_LN_QGELU_BF16 7    /* same, then QuickGELU */
 #define KEDS_EPI_RESID_STATS_F32 8  /* out f32 += acc + bias (in place); aux2 = bf16 copy [M,N] of the new rows;
-                                       aux = fp32 [M,2] += {sum, sum sq} of the new rows (atomic; zeroed by the caller) */
+                                       aux = statistics [M,2] (64-bit fixed point) += {sum, sum sq} of the new rows (zeroed before) */
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W bf16 row-major (W is the nn.Linear
  * weight as stored).  N % 128 == 0, K % 64 == 0; rows of A / out up to the next multiple of
@@ -158,7 +159,7 @@ int keds_fold_layernorm(const float* W, const float* bias, const float* gamma, c
                         void* w_folded, float* bias_csum, void* stream);
 
 /* Row statistics + bf16 copy of a residual stream (what KEDS_EPI_RESID_STATS_F32 emits, for the first block):
- * x fp32 [rows, dim] dense -> xb bf16 [rows, dim], stats fp32 [rows,2] = {sum, sum of squares}. */
+ * x fp32 [rows, dim] dense -> xb bf16 [rows, dim], stats [rows,2] = {sum, sum of squares} as 64-bit fixed point (* 2^28). */
 int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim, void* stream);
 
 /* ---- MXFP8 (BASELINE config 5: fp8 encoders).  OCP e4m3 elements, one e8m0 scale per 32 consecutive K (OCP MX),

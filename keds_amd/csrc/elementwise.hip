@@ -97,7 +97,11 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
     }
     s = wave_sum(s);
     q = wave_sum(q);
-    if (lane == 0) *reinterpret_cast<float2*>(stats + 2 * (size_t)r) = float2{s, q};
+    if (lane == 0) {
+        keds_stat_t* row = reinterpret_cast<keds_stat_t*>(stats) + 2 * (size_t)r;
+        row[0] = keds_stat_fixed(s);
+        row[1] = keds_stat_fixed(q);
+    }
 }
 
 // one wave per output row n of W [N,K]: w_folded = bf16(W * gamma), csum = sum of the ROUNDED products (what the MFMA

@@ -83,8 +83,9 @@ constexpr int epi_base(int e) {
 constexpr float LN_EPS = 1e-5f;
 
 // LayerNorm statistics of row m from {sum, sum of squares}: returns (rstd, -mean * rstd)
-__device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats, int m, float invk, float& rstd, float& nmr) {
-    const float s = stats[2 * (size_t)m], ss = stats[2 * (size_t)m + 1];
+__device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats_, int m, float invk, float& rstd, float& nmr) {
+    const keds_stat_t* stats = reinterpret_cast<const keds_stat_t*>(stats_);
+    const float s = keds_stat_value(stats[2 * (size_t)m]), ss = keds_stat_value(stats[2 * (size_t)m + 1]);
     const float mean = s * invk;
     const float var = fmaxf(ss * invk - mean * mean, 0.f);
     rstd = rsqrtf(var + LN_EPS);
@@ -102,12 +103,12 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
     if constexpr (epi_is_ln(EPI)) {
         const float invk = 1.0f / (float)K;
         float rstd[MI], nmr[MI];
-        float* zero = reinterpret_cast<float*>(aux2);
+        keds_stat_t* zero = reinterpret_cast<keds_stat_t*>(aux2);
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m_lane + 16 * mi;
             ln_row_coeff(aux, m < M ? m : M - 1, invk, rstd[mi], nmr[mi]);
-            if (zero && zero_lane && m < M) *reinterpret_cast<float2*>(zero + 2 * (size_t)m) = float2{0.f, 0.f};
+            if (zero && zero_lane && m < M) keds_stat_zero(zero + 2 * (size_t)m);
         }
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -123,7 +124,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
             }
         }
     } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F32) {
-        float* stats = const_cast<float*>(aux);
+        keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
         bf16_t* xb = reinterpret_cast<bf16_t*>(aux2);
         f32x4 b[2][2];
 #pragma unroll
@@ -160,10 +161,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
             ss += __shfl_xor(ss, 16, 64);
             s += __shfl_xor(s, 32, 64);
             ss += __shfl_xor(ss, 32, 64);
-            if (valid && zero_lane) {
-                unsafeAtomicAdd(stats + 2 * (size_t)m, s);
-                unsafeAtomicAdd(stats + 2 * (size_t)m + 1, ss);
-            }
+            if (valid && zero_lane) keds_stat_add(stats + 2 * (size_t)m, s, ss);
         }
     } else {
 #pragma unroll
@@ -371,8 +369,8 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     if constexpr (epi_is_ln(EPI)) {
         float rstd, nmr;
         ln_row_coeff(aux, m, 1.0f / (float)K, rstd, nmr);
-        float* zero = reinterpret_cast<float*>(aux2);
-        if (zero && n == 0) *reinterpret_cast<float2*>(zero + 2 * (size_t)m) = float2{0.f, 0.f};
+        keds_stat_t* zero = reinterpret_cast<keds_stat_t*>(aux2);
+        if (zero && n == 0) keds_stat_zero(zero + 2 * (size_t)m);
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + N + n), c1 = *reinterpret_cast<const f32x4*>(bias + N + n + 4);
         epilogue_store<epi_base(EPI)>(v0 * rstd + (c0 * nmr + b0), v1 * rstd + (c1 * nmr + b1), out, m, n, N, nullptr, 0, ldc);
     } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F32) {
@@ -384,7 +382,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(aux2) + (size_t)m * N + n) =
             bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
                    (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
-        float* stats = const_cast<float*>(aux);
+        keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
         float s = sum8(v0, v1), ss = sum8(v0 * v0, v1 * v1);
         // lanes that are known to sit in one row (N % 512 == 0: the wave, N % 256 == 0: its halves) add once;
         // per-thread atomics on one address serialise (measured 56 us for 128 x 1024 outputs)
@@ -400,10 +398,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
                 ss += __shfl_xor(ss, 32, 64);
             }
         }
-        if ((threadIdx.x & (seg - 1)) == 0) {
-            unsafeAtomicAdd(stats + 2 * (size_t)m, s);
-            unsafeAtomicAdd(stats + 2 * (size_t)m + 1, ss);
-        }
+        if ((threadIdx.x & (seg - 1)) == 0) keds_stat_add(stats + 2 * (size_t)m, s, ss);
     } else {
         epilogue_store<EPI>(v0 + b0, v1 + b1, out, m, n, N, aux, aux_i, ldc);
     }
@@ -668,10 +663,10 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     const float* aux_t = aux;
     void* aux2_t = aux2;
     if constexpr (epi_is_ln(EPI)) {
-        aux_t = aux + 2 * (size_t)m_main;
-        if (aux2) aux2_t = (float*)aux2 + 2 * (size_t)m_main;
+        aux_t = (const float*)((const keds_stat_t*)aux + 2 * (size_t)m_main);
+        if (aux2) aux2_t = (keds_stat_t*)aux2 + 2 * (size_t)m_main;
     } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F32) {
-        aux_t = aux + 2 * (size_t)m_main;
+        aux_t = (const float*)((const keds_stat_t*)aux + 2 * (size_t)m_main);
         aux2_t = (char*)aux2 + (size_t)m_main * N * 2;
     }
     return launch_small<EPI>((const char*)A + (size_t)m_main * K * 2, W, bias, (char*)out + (size_t)m_main * N * esz,

@@ -298,11 +298,12 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + 128 * wm + 16 * mi + c;
-            const float sm = aux[2 * (size_t)m], ss = aux[2 * (size_t)m + 1];
+            const keds_stat_t* strow = reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)m;
+            const float sm = keds_stat_value(strow[0]), ss = keds_stat_value(strow[1]);
             const float mean = sm * invk;
             rstd[mi] = rsqrtf(fmaxf(ss * invk - mean * mean, 0.f) + 1e-5f);
             nmr[mi] = -mean * rstd[mi];
-            if (aux2 && n0 == 0 && wn == 0 && g == 0) *reinterpret_cast<float2*>(aux2 + 2 * (size_t)m) = float2{0.f, 0.f};
+            if (aux2 && n0 == 0 && wn == 0 && g == 0) keds_stat_zero(reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)m);
         }
     }
     float rs[8], rss[8];
@@ -374,10 +375,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
             b2 += __shfl_xor(b2, 16, 64);
             a += __shfl_xor(a, 32, 64);
             b2 += __shfl_xor(b2, 32, 64);
-            if (g == 0) {
-                unsafeAtomicAdd(aux + 2 * (size_t)m, a);
-                unsafeAtomicAdd(aux + 2 * (size_t)m + 1, b2);
-            }
+            if (g == 0) keds_stat_add(reinterpret_cast<keds_stat_t*>(aux) + 2 * (size_t)m, a, b2);
         }
     }
 }

@@ -64,6 +64,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// ---- LayerNorm row statistics {sum, sum of squares} accumulated across workgroups ---------------------------------
+// Stored as 64-bit FIXED POINT (value * 2^28) and added with integer atomics: integer addition is associative, so the
+// result does not depend on the order in which tiles arrive and every run produces the same bits (fp32 atomics did
+// not: last-bit differences, amplified by e4m3 rounding in the fp8 towers).  One row = two long long (16 bytes).
+typedef long long keds_stat_t;
+#define KEDS_STAT_SCALE 268435456.0f            /* 2^28: exact for |partial| >= 2^-5, 2^-28 absolute below; sums < 3.4e10 */
+__device__ __forceinline__ keds_stat_t keds_stat_fixed(float v) { return (keds_stat_t)__float2ll_rn(v * KEDS_STAT_SCALE); }
+__device__ __forceinline__ float keds_stat_value(keds_stat_t a) { return (float)((double)a * (1.0 / 268435456.0)); }
+__device__ __forceinline__ void keds_stat_add(keds_stat_t* row, float s, float ss) {
+    atomicAdd(reinterpret_cast<unsigned long long*>(row), (unsigned long long)keds_stat_fixed(s));
+    atomicAdd(reinterpret_cast<unsigned long long*>(row + 1), (unsigned long long)keds_stat_fixed(ss));
+}
+__device__ __forceinline__ void keds_stat_zero(keds_stat_t* row) {
+    row[0] = 0;
+    row[1] = 0;
+}
+
 // ---- OCP MX (e4m3 elements, one e8m0 scale per 32) helpers shared by gemm_fp8.hip and attention.hip --------------
 // OCP MX shared exponent of a 32-element block from its amax: floor(log2(amax)) - 8 (emax of e4m3), clamped to e8m0
 __device__ __forceinline__ int mx_block_exp(float amax) {

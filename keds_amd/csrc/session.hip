@@ -201,7 +201,7 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
         if ((rc = L.mat<bf16_t>(b + "mlp.c_proj.weight", width, 4 * width, &m))) return rc;
         p.proj_w = m;
         // ln_1 folded into in_proj, ln_2 into c_fc (keds_fold_layernorm): fp32 copies of the two weights are temporary.
-        // KEDS_DETERMINISTIC=1 keeps the separate LayerNorm kernels (no fp32 atomics: bitwise reproducible runs).
+        // KEDS_DETERMINISTIC=1 keeps the separate LayerNorm kernels (A/B reference; the folded path is reproducible too).
         const char* det = getenv("KEDS_DETERMINISTIC");
         if (det && det[0] == '1') continue;
         Arena tmp;

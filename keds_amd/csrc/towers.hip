@@ -15,7 +15,7 @@ namespace {
 size_t pad_rows(size_t m) { return keds_align_up(m, 128); }
 
 // scratch of one tower: h [Mp,w] bf16 | big [Mp,4w] bf16 (qkv [Mp,3w] + attn [Mp,w], later the MLP hidden) |
-// two row-statistics buffers [Mp,2] fp32 (LayerNorm folded into the GEMMs: ln_1 / ln_2 statistics)
+// two row-statistics buffers [Mp,2] of 64-bit fixed point (LayerNorm folded into the GEMMs: ln_1 / ln_2 statistics)
 struct TowerWs {
     char* h;
     char* big;
@@ -32,7 +32,7 @@ TowerWs carve_tower(void* ws, int width, int seq, int B) {
     char* p = (char*)ws;
     const size_t hb = keds_align_up(Mp * width * 2, 256);
     const size_t bb = keds_align_up(Mp * (size_t)width * 4 * 2, 256);
-    const size_t sb = keds_align_up(Mp * 2 * sizeof(float), 256);
+    const size_t sb = keds_align_up(Mp * 2 * sizeof(keds_stat_t), 256);
     t.h = p;
     t.big = p ? p + hb : nullptr;
     t.st1 = p ? (float*)(p + hb + bb) : nullptr;
@@ -67,8 +67,8 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
     bf16_t* qkv = (bf16_t*)t.big;
     bf16_t* att = qkv + Mp * (size_t)w * 3;
     bf16_t* hid = qkv;
-    float* st1t = t.st1 + 2 * (size_t)Mm;
-    float* st2t = t.st2 + 2 * (size_t)Mm;
+    float* st1t = (float*)((keds_stat_t*)t.st1 + 2 * (size_t)Mm);      // statistics rows are two 64-bit words
+    float* st2t = (float*)((keds_stat_t*)t.st2 + 2 * (size_t)Mm);
     int rc;
     if ((rc = keds_rowstats_cast(x, h, t.st1, M, w, st))) return rc;
     if ((rc = keds_quantize_mxfp8(x, 0, Mm, w, Mm, t.xq, t.xs, st))) return rc;

@@ -91,8 +91,8 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
             qkv_b=_f32(blk.attn.in_proj_bias), out_b=_f32(blk.attn.out_proj.bias),
             fc_b=_f32(blk.mlp.c_fc.bias), proj_b=_f32(blk.mlp.c_proj.bias))
         # ln_1 folded into in_proj, ln_2 into c_fc (keds_fold_layernorm): the tower then runs without LayerNorm passes.
-        # The row statistics are accumulated with fp32 atomics (order varies run to run: last-bit differences in the
-        # embeddings); KEDS_DETERMINISTIC=1 keeps the separate LayerNorm kernels, which are bitwise reproducible.
+        # The row statistics cross workgroups as 64-bit fixed-point integer atomics (order independent: reproducible bits);
+        # KEDS_DETERMINISTIC=1 keeps the separate LayerNorm kernels as an A/B reference.
         lib = load()
         folds = (("qkv", blk.attn.in_proj_weight, t["qkv_b"], ("ln1_g", "ln1_b")),
                  ("fc", blk.mlp.c_fc.weight, t["fc_b"], ("ln2_g", "ln2_b")))

@@ -252,11 +252,12 @@ def test_gemm_layernorm_epilogues_equal_layernorm_then_linear(M, N, K, epi):
     wf, bc = _fold(w, b, gamma, beta)
     Mp = (M + 127) // 128 * 128
     xb = torch.zeros((Mp, K), dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros((Mp, 2), device="cuda")
+    stats = torch.zeros((Mp, 2), dtype=torch.int64, device="cuda")      # {sum, sum sq} as 64-bit fixed point (* 2^28)
     _lib.check(lib.keds_rowstats_cast(_lib.ptr(x), _lib.ptr(xb), _lib.ptr(stats), M, K, _lib.stream()), "rowstats")
     assert torch.equal(xb[:M], x.to(torch.bfloat16))
-    assert torch.allclose(stats[:M, 0], x.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(stats[:M, 1], (x * x).sum(1), rtol=1e-5)
-    other = torch.full((Mp + 8, 2), 7.0, device="cuda")
+    sf = stats.double() / 2.0 ** 28
+    assert torch.allclose(sf[:M, 0].float(), x.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(sf[:M, 1].float(), (x * x).sum(1), rtol=1e-5)
+    other = torch.full((Mp + 8, 2), 7, dtype=torch.int64, device="cuda")
     out = torch.zeros((Mp, N), dtype=torch.bfloat16, device="cuda")
     code = _lib.EPI_LN_BIAS_BF16 if epi == "ln" else _lib.EPI_LN_QGELU_BF16
     _lib.ensure_gemm_workspace("cuda")
@@ -293,13 +294,21 @@ def test_gemm_residual_stats_epilogue(M, N, K):
     x = torch.zeros((Mp, N), device="cuda")
     x[:M] = torch.randn(M, N, generator=g, device="cuda")
     want = x[:M] + a[:M].float() @ w.float().t() + b
+    x0 = x.clone()
     xb = torch.zeros((Mp, N), dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros((Mp, 2), device="cuda")
+    stats = torch.zeros((Mp, 2), dtype=torch.int64, device="cuda")
     _lib.ensure_gemm_workspace("cuda")
     _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x), N, M, N, K,
                                     _lib.EPI_RESID_STATS_F32, _lib.ptr(stats), 0, _lib.ptr(xb), _lib.stream()), "gemm resid")
     assert max_abs(x[:M], want) <= 2e-4
     assert torch.equal(xb[:M], x[:M].to(torch.bfloat16))
-    assert torch.allclose(stats[:M, 0], x[:M].sum(1), rtol=1e-4, atol=2e-3)
-    assert torch.allclose(stats[:M, 1], (x[:M] * x[:M]).sum(1), rtol=1e-4)
+    sf = (stats.double() / 2.0 ** 28).float()
+    assert torch.allclose(sf[:M, 0], x[:M].sum(1), rtol=1e-4, atol=2e-3)
+    assert torch.allclose(sf[:M, 1], (x[:M] * x[:M]).sum(1), rtol=1e-4)
     assert bool((stats[M:] == 0).all()) and bool((xb[M:] == 0).all())
+    # integer accumulation: a second run from the same inputs reproduces the statistics bit for bit
+    x2 = x0.clone()
+    stats2 = torch.zeros((Mp, 2), dtype=torch.int64, device="cuda")
+    _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x2), N, M, N, K,
+                                    _lib.EPI_RESID_STATS_F32, _lib.ptr(stats2), 0, _lib.ptr(xb), _lib.stream()), "gemm resid 2")
+    assert torch.equal(stats2, stats) and torch.equal(x2, x)
