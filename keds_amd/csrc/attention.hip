@@ -103,8 +103,7 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
                 }
                 mx = fmaxf(mx, v);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = rows_max(mx);
         const float nmx = -mx * sl2;
         // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two elements per VALU issue); v_exp_f32 stays per element
         const f32x2 vs = f32x2{sl2, sl2}, vn = f32x2{nmx, nmx};
@@ -125,8 +124,7 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
             }
         }
         float sum = vsum[0] + vsum[1];
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = rows_sum(sum);
         inv[t] = 1.0f / sum;
     }
     // ---- O^T = V^T . P^T
@@ -171,8 +169,7 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
                     float amax = 0.f;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
-                    amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-                    amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                    amax = rows_max(amax);
                     const int e = mx_block_exp(amax);
                     const uint2 pk = mx_pack8(v, e);
                     unsigned char* qp = cx.q8 + (size_t)row * cx.d + cx.col0 + 32 * b2 + 4 * g;

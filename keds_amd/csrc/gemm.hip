@@ -157,10 +157,8 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
                 }
             }
             // the four lanes (g = 0..3) that share row m hold this wave's 64 columns of it
-            s += __shfl_xor(s, 16, 64);
-            ss += __shfl_xor(ss, 16, 64);
-            s += __shfl_xor(s, 32, 64);
-            ss += __shfl_xor(ss, 32, 64);
+            s = rows_sum(s);
+            ss = rows_sum(ss);
             if (valid && zero_lane) keds_stat_add(stats + 2 * (size_t)m, s, ss);
         }
     } else {

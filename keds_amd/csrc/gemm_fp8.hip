@@ -358,8 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
                 float amax = 0.f;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
-                amax = fmaxf(amax, __shfl_xor(amax, 16, 64));
-                amax = fmaxf(amax, __shfl_xor(amax, 32, 64));
+                amax = rows_max(amax);
                 const int e = mx_block_exp(amax);
                 *reinterpret_cast<uint2*>(qout + (size_t)m * N + n) = mx_pack8(v, e);
                 if (g == 0) qscale[mx_scale_index((n0 + 64 * wn + 32 * pp) >> 5, m, q_pad)] = (unsigned char)(e + 127);
@@ -371,10 +370,8 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + 128 * wm + 16 * mi + c;
             float a = rs[mi], b2 = rss[mi];
-            a += __shfl_xor(a, 16, 64);
-            b2 += __shfl_xor(b2, 16, 64);
-            a += __shfl_xor(a, 32, 64);
-            b2 += __shfl_xor(b2, 32, 64);
+            a = rows_sum(a);
+            b2 = rows_sum(b2);
             if (g == 0) keds_stat_add(reinterpret_cast<keds_stat_t*>(aux) + 2 * (size_t)m, a, b2);
         }
     }

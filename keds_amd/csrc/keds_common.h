@@ -55,6 +55,22 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Reductions over the lane bits 4 and 5 (the four 16-lane rows of a wave: the lanes that share an MFMA output column /
+// row) with gfx950's v_permlane16_swap / v_permlane32_swap: VALU instructions instead of the ds_bpermute round trips that
+// __shfl_xor(x, 16 / 32) compiles to.  With both operands = x, swap16 gives {row0,row0,row2,row2} and {row1,row1,row3,row3}.
+__device__ __forceinline__ float rows_max(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
 // XCD-aware bijective remap of a 1-D block id: blocks that the dispatcher deals to one XCD
 // (b, b+8, b+16, ...) get a contiguous run of logical ids, so neighbouring tiles share an L2.
 // Speed only; any placement is correct.
