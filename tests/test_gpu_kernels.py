@@ -312,3 +312,42 @@ def test_gemm_residual_stats_epilogue(M, N, K):
     _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x2), N, M, N, K,
                                     _lib.EPI_RESID_STATS_F32, _lib.ptr(stats2), 0, _lib.ptr(xb), _lib.stream()), "gemm resid 2")
     assert torch.equal(stats2, stats) and torch.equal(x2, x)
+
+
+def test_gemm_random_shapes_all_epilogues():
+    """Seeded sweep over shapes that straddle every dispatch boundary (128^2 / 256^2 kernels, remainder rows, split-K,
+    ring depth) for every epilogue, against torch fp32 on the rounded operands."""
+    lib = _lib.load()
+    rs = np.random.RandomState(123)
+    _lib.ensure_gemm_workspace("cuda")
+    cases = 0
+    for _ in range(28):
+        M = int(rs.choice([1, 7, 128, 129, 255, 256, 257, 1000, 4100, 33000, 66000]))
+        N = int(rs.choice([128, 256, 384, 768, 1024, 2304]))
+        K = int(rs.choice([64, 128, 320, 768, 1024, 2048, 4096]))
+        if M * N * K > 3.5e11:
+            continue
+        epi = int(rs.choice([_lib.EPI_BIAS_BF16, _lib.EPI_BIAS_QGELU_BF16, _lib.EPI_BIAS_RELU_BF16, _lib.EPI_BIAS_RESID_F32,
+                             _lib.EPI_BIAS_F32]))
+        g = torch.Generator(device="cuda").manual_seed(M * 7 + N + K)
+        Mp = (M + 127) // 128 * 128
+        a = torch.zeros((Mp, K), dtype=torch.bfloat16, device="cuda")
+        a[:M] = torch.randn(M, K, generator=g, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+        b = torch.randn(N, generator=g, device="cuda") * 0.3
+        f32 = epi in (_lib.EPI_BIAS_RESID_F32, _lib.EPI_BIAS_F32)
+        out = torch.randn((Mp, N), generator=g, device="cuda") if f32 else torch.zeros((Mp, N), dtype=torch.bfloat16, device="cuda")
+        ref = a[:M].float() @ w.float().t() + b
+        if epi == _lib.EPI_BIAS_QGELU_BF16:
+            ref = ref * torch.sigmoid(1.702 * ref)
+        elif epi == _lib.EPI_BIAS_RELU_BF16:
+            ref = torch.relu(ref)
+        elif epi == _lib.EPI_BIAS_RESID_F32:
+            ref = ref + out[:M]
+        guard = out[M:].clone()
+        ops.gemm_bt(a, w, b, epi, out=out, m=M)
+        err = rel_l2(out[:M], ref)
+        assert err <= (2e-6 if f32 else 4e-3), (M, N, K, epi, err)
+        assert torch.equal(out[M:], guard), "rows past M were written"
+        cases += 1
+    assert cases >= 20

@@ -227,3 +227,30 @@ def test_two_million_keys_sharded_like_config5():
     Do, Io = O.flat_l2_search(torch.cat(parts), qq, 10)
     report("search_2M", n=n, index_mismatches=int((Iq.cpu() != Io).sum()), d_maxabs=max_abs(Dq, Do))
     assert torch.equal(Iq.cpu(), Io) and max_abs(Dq, Do) <= D_ATOL
+
+
+def test_search_random_sizes_against_oracle():
+    """Seeded sweep over database sizes (ragged stage tails, below / above the two-phase threshold), dimensions, query
+    counts (partial and multiple query blocks) and k."""
+    rs = np.random.RandomState(77)
+    for case in range(10):
+        dim = int(rs.choice([128, 256, 512, 768, 1024]))
+        n = int(rs.choice([1, 31, 33, 1000, 4097, 32767, 32769, 70001]))
+        nq = int(rs.choice([1, 2, 127, 128, 129, 300]))
+        k = int(rs.randint(1, 17))
+        db = O.synth_database(n, dim, seed=500 + case, clustered=bool(case % 2), n_centroids=16)
+        q = O.synth_database(nq, dim, seed=900 + case)
+        idx = keds_amd.FlatIndex(dim)
+        idx.add(db)
+        kk = min(k, n)
+        D, I, _ = idx.search_device(q.cuda(), k)
+        Do, Io = O.flat_l2_search(db, q, kk)
+        I, D = I.cpu(), D.cpu()
+        if not torch.equal(I[:, :kk], Io):               # only exact-tie / fp32-vs-fp64 near-tie swaps are tolerated
+            bad = torch.nonzero((I[:, :kk] != Io).any(dim=1)).flatten()
+            assert len(bad) <= max(1, nq // 100), (n, dim, nq, k)
+            for r in bad.tolist():
+                exact = ((q[r].double()[None, :] - db[I[r, :kk]].double()) ** 2).sum(1)
+                assert float((exact - Do[r].double()).abs().max()) <= 1e-6
+        assert max_abs(D[:, :kk], Do) <= D_ATOL
+        assert bool((I[:, kk:] == -1).all())
