@@ -169,6 +169,48 @@ def exchange_and_merge(D: torch.Tensor, I: torch.Tensor, metric: int = _lib.METR
     return merge_partials(Dp, Ip, metric)
 
 
+def exchange_merge_gather(D_p: torch.Tensor, I_p: torch.Tensor, rows_p: torch.Tensor, B: int,
+                          metric: int = _lib.METRIC_L2, group=None):
+    """Sharded search WITH the winners' rows (the knowledge path needs the 16 neighbour rows, which live on the shard
+    that found them; SURVEY 8e option B).  Every rank searched its shard for all B*world queries and holds
+    D_p / I_p [B*world, k] and rows_p [B*world, k, dim] (rows of its own shard).  Block r of each (the B queries of
+    rank r) is sent to rank r only (all-to-all: B*k*dim*4 bytes per peer, 6.3 MB at B=128, k=16), then the owner merges
+    its `world` partial lists keyed on (distance, id) and picks each winner's row from the part that supplied it.
+    Returns (D [B,k], I [B,k], rows [B,k,dim]) for this rank's own queries.  Works on CPU tensors (gloo tests)."""
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    k, dim = D_p.shape[1], rows_p.shape[2]
+
+    def a2a(t):
+        t = t.contiguous()
+        out = torch.empty_like(t)
+        if t.is_cuda:
+            dist.all_to_all_single(out, t, group=group)          # equal splits: block r <-> rank r
+        else:                                                     # gloo has no all_to_all_single on every build: use all_gather
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t, group=group)
+            rank = dist.get_rank(group)
+            n = t.shape[0] // world
+            out = torch.cat([p[rank * n:(rank + 1) * n] for p in parts])
+        return out
+
+    Dq = a2a(D_p).reshape(world, B, k)                            # part w = what shard w found for MY queries
+    Iq = a2a(I_p).reshape(world, B, k)
+    Rq = a2a(rows_p).reshape(world, B, k, dim)
+    if Dq.is_cuda:
+        D, I = ops.topk_merge_parts(Dq, Iq, metric)
+    else:
+        D, I = merge_partials(Dq, Iq, metric)
+    # provenance: ids are unique across shards, so the slot that holds id I[b,j] is the one that supplied it
+    flat_i = Iq.permute(1, 0, 2).reshape(B, world * k)            # [B, world*k]
+    hit = flat_i[:, None, :] == I[:, :, None]                     # [B, k, world*k]
+    src = hit.to(torch.int8).argmax(dim=2)                        # first match (padding ids -1 never win a real slot)
+    flat_r = Rq.permute(1, 0, 2, 3).reshape(B, world * k, dim)
+    rows = torch.gather(flat_r, 1, src[:, :, None].expand(B, k, dim))
+    rows = torch.where((I >= 0)[:, :, None], rows, torch.zeros_like(rows))
+    return D, I, rows
+
+
 class ShardedFlatIndex:
     """Row-sharded index: rank r owns rows shard_bounds(n, world, r).
 
@@ -201,3 +243,15 @@ class ShardedFlatIndex:
         if self.world == 1:
             return D, I
         return exchange_and_merge(D, I, self.local.metric, self.group)
+
+    def search_gather(self, q_local: torch.Tensor, k: int, normalize: bool = False):
+        """Data-parallel form: every rank passes ITS OWN B queries (same B everywhere) and gets (D, I, rows) for them:
+        all-gather of the queries, local scan + gather on the shard, all-to-all of the partials with their rows, merge
+        and row selection on the owner (`exchange_merge_gather`)."""
+        if self.world == 1:
+            return self.local.search_gather(q_local, k, normalize=normalize)
+        B = q_local.shape[0]
+        allq = [torch.empty_like(q_local) for _ in range(self.world)]
+        self.dist.all_gather(allq, q_local.contiguous(), group=self.group)
+        D_p, I_p, rows_p = self.local.search_gather(torch.cat(allq), k, normalize=normalize)
+        return exchange_merge_gather(D_p, I_p, rows_p, B, self.local.metric, self.group)

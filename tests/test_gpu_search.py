@@ -254,3 +254,32 @@ def test_search_random_sizes_against_oracle():
                 assert float((exact - Do[r].double()).abs().max()) <= 1e-6
         assert max_abs(D[:, :kk], Do) <= D_ATOL
         assert bool((I[:, kk:] == -1).all())
+
+
+def test_exchange_merge_gather_over_rccl_single_rank():
+    """The sharded search-with-rows exchange (all-to-all of partial lists and their rows, merge, row selection) on
+    device tensors over a 1-rank RCCL group; the 2-rank logic runs under gloo in tests/test_host_cpu.py."""
+    import os
+    import torch.distributed as dist
+    from keds_amd.index import exchange_merge_gather
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        n, dim = 9000, 256
+        db = O.synth_database(n, dim, seed=21)
+        q = O.synth_database(12, dim, seed=22).cuda()
+        idx = keds_amd.FlatIndex(dim)
+        idx.add(db)
+        Dp, Ip, Rp = idx.search_gather(q, 16)
+        D, I, R = exchange_merge_gather(Dp, Ip, Rp, 12, _lib.METRIC_L2)
+        assert torch.equal(D, Dp) and torch.equal(I, Ip) and torch.equal(R, Rp)
+        sh = keds_amd.ShardedFlatIndex(dim)
+        sh.add_global(db)
+        D2, I2, R2 = sh.search_gather(q, 16)
+        assert torch.equal(I2, Ip) and torch.equal(R2, Rp)
+    finally:
+        if created:
+            dist.destroy_process_group()

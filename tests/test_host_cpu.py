@@ -193,7 +193,17 @@ def _gloo_worker(rank, world, port, out):
         from keds_amd.index import exchange_and_merge
         D, I = exchange_and_merge(d, i + lo, _lib.METRIC_L2, group=None)
         Dg, Ig = O.flat_l2_search(db, q, 10)
-        out[rank] = bool(torch.equal(I, Ig) and torch.allclose(D, Dg))
+        ok = bool(torch.equal(I, Ig) and torch.allclose(D, Dg))
+        # data-parallel form with the winners' rows: each rank owns 4 of 8 queries; its shard answers all 8 and ships the
+        # rows it found with its partial lists (knowledge-path neighbours)
+        from keds_amd.index import exchange_merge_gather
+        qall = O.synth_database(8, 64, seed=11)
+        dp, ip = O.flat_l2_search(db[lo:hi], qall, 16)
+        rows_p = db[lo:hi][ip.reshape(-1)].reshape(8, 16, 64)
+        D2, I2, R2 = exchange_merge_gather(dp, ip + lo, rows_p, 4, _lib.METRIC_L2, group=None)
+        Dg2, Ig2 = O.flat_l2_search(db, qall[rank * 4:(rank + 1) * 4], 16)
+        ok = ok and bool(torch.equal(I2, Ig2) and torch.allclose(D2, Dg2) and torch.equal(R2, db[Ig2.reshape(-1)].reshape(4, 16, 64)))
+        out[rank] = ok
     finally:
         dist.destroy_process_group()
 
