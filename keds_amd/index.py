@@ -73,6 +73,40 @@ class FlatIndex:
         self.rows = None
         self.packed = None
 
+    # ---- on-disk form (the database is built once and reloaded by every eval run) ----------------
+    MAGIC = "keds-flat-index-v1"
+
+    def save(self, path: str) -> None:
+        """One torch file: the fp32 rows (what the reference keeps in cc_*_databases.pt, eval_retrieval.py:281-282) plus
+        the packed bf16 scan image, so loading needs no re-pack.  The image layout is tied to the kernel: the file
+        carries the ABI version and is re-packed on load if it does not match."""
+        if self.rows is None:
+            raise RuntimeError("save of an empty index")
+        torch.save({"magic": self.MAGIC, "abi": _lib.ABI_VERSION, "d": self.d, "metric": self.metric, "row0": self.row0,
+                    "rows": self.rows.cpu(), "packed": self.packed.cpu()}, path)
+
+    @classmethod
+    def load(cls, path: str, device=None) -> "FlatIndex":
+        """Load an index written by `save`, or a plain float32 [N, d] tensor file such as the reference's
+        cc_image_databases.pt / cc_text_databases.pt (then the scan image is built here)."""
+        blob = torch.load(path, map_location="cpu")
+        if isinstance(blob, torch.Tensor):
+            idx = cls(blob.shape[1], "l2", device=device)
+            idx.add(blob.float())
+            return idx
+        if not isinstance(blob, dict) or blob.get("magic") != cls.MAGIC:
+            raise RuntimeError(f"{path} is neither a saved FlatIndex nor a [N, d] tensor")
+        idx = cls(int(blob["d"]), "l2" if int(blob["metric"]) == _lib.METRIC_L2 else "ip", device=device,
+                  row0=int(blob["row0"]))
+        dev = idx._dev()
+        expect = load().keds_index_packed_bytes(blob["rows"].shape[0], idx.d)
+        if int(blob["abi"]) == _lib.ABI_VERSION and blob["packed"].numel() == expect:
+            idx.rows = blob["rows"].to(dev, dtype=torch.float32).contiguous()
+            idx.packed = blob["packed"].to(dev).contiguous()
+        else:
+            idx.add(blob["rows"])
+        return idx
+
     # ---- search ---------------------------------------------------------------------------------
     def search_device(self, q: torch.Tensor, k: int, normalize: bool = False,
                       gather: bool = False) -> Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor]]:

@@ -32,6 +32,29 @@ def build_database(image_bases: torch.Tensor, text_bases: torch.Tensor, basename
     return [ii.rows, ti.rows, list(basenames) if basenames is not None else None, ii, ti]
 
 
+@torch.no_grad()
+def extract_feature_database(model: CLIP, image_batches, text_batches, out_dir: Optional[str] = None, device=None):
+    """Build the bi-modal database on the device (the reference ships only the result,
+    README.md:8 / eval_retrieval.py:253-286): encode every image batch and every caption batch, L2-normalise, and return
+    (image_bases, text_bases) as float32 [N, D] device tensors -- what `build_database` takes.  With `out_dir` the two
+    matrices are also written as `cc_image_databases.pt` / `cc_text_databases.pt` (plain float32 tensors: the reference's
+    own on-disk format) and the ready-to-search indices as `cc_image_index.pt` / `cc_text_index.pt` (FlatIndex.save)."""
+    imgs = [model.encode_image(b.to(device) if device is not None else b, normalize=True).float() for b in image_batches]
+    txts = [model.encode_text(b.to(device) if device is not None else b, normalize=True).float() for b in text_batches]
+    image_bases, text_bases = torch.cat(imgs), torch.cat(txts)
+    if image_bases.shape != text_bases.shape:
+        raise RuntimeError(f"image / text databases differ in shape: {tuple(image_bases.shape)} vs {tuple(text_bases.shape)}")
+    if out_dir is not None:
+        os.makedirs(out_dir, exist_ok=True)
+        torch.save(image_bases.cpu(), os.path.join(out_dir, "cc_image_databases.pt"))
+        torch.save(text_bases.cpu(), os.path.join(out_dir, "cc_text_databases.pt"))
+        for name, base in (("cc_image_index.pt", image_bases), ("cc_text_index.pt", text_bases)):
+            idx = FlatIndex(base.shape[1], "l2", device=base.device)
+            idx.add(base)
+            idx.save(os.path.join(out_dir, name))
+    return image_bases, text_bases
+
+
 def get_retrieved_features(feature: torch.Tensor, database, args=None, topk: int = 16, use_faiss: bool = True):
     """eval_utils.py:153-186.  feature [B,D] (any norm) -> (topk_image [B,k,D], topk_text [B,k,D]).
     The reference shuffles the image neighbours along K (a numerical no-op for attention over keys);

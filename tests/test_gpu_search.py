@@ -283,3 +283,43 @@ def test_exchange_merge_gather_over_rccl_single_rank():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_index_save_load_and_database_extraction(tmp_path):
+    """On-disk forms: FlatIndex.save/load round trip (no re-pack, identical results), loading the
+    reference's plain [N, d] tensor files, and the device-side database builder."""
+    db = O.synth_database(5000, 256, seed=31)
+    q = O.synth_database(9, 256, seed=32).cuda()
+    idx = keds_amd.FlatIndex(256, row0=640)
+    idx.add(db)
+    D, I, R = idx.search_gather(q, 16)
+    path = str(tmp_path / "idx.pt")
+    idx.save(path)
+    back = keds_amd.FlatIndex.load(path)
+    assert back.ntotal == 5000 and back.row0 == 640 and torch.equal(back.packed, idx.packed)
+    D2, I2, R2 = back.search_gather(q, 16)
+    assert torch.equal(D, D2) and torch.equal(I, I2) and torch.equal(R, R2)
+    plain = str(tmp_path / "cc_image_databases.pt")
+    torch.save(db, plain)                                            # the reference's own format (eval_retrieval.py:281)
+    ref = keds_amd.FlatIndex.load(plain)
+    _, I3, _ = ref.search_device(q, 16)
+    assert torch.equal(I3 + 640, I)
+    with pytest.raises(RuntimeError):
+        torch.save({"x": 1}, str(tmp_path / "bad.pt"))
+        keds_amd.FlatIndex.load(str(tmp_path / "bad.pt"))
+    # database extraction with the tiny model: rows are unit norm and equal to encode(...) of the same batches
+    from tests.test_gpu_model import TINY
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    m = keds_amd.build_model(dict(sd), fp16=False).cuda()
+    rs = np.random.RandomState(1)
+    imgs = [torch.from_numpy(rs.standard_normal((3, 3, 56, 56)).astype(np.float32)).cuda() for _ in range(2)]
+    g = dict(np.load(golden_path("clip_tiny.npz")))
+    toks = [torch.from_numpy(g["text"][:3]).cuda(), torch.from_numpy(g["text"][1:4]).cuda()]
+    ib, tb = keds_amd.extract_feature_database(m, imgs, toks, out_dir=str(tmp_path / "db"))
+    assert ib.shape == (6, 128) and tb.shape == (6, 128)
+    assert torch.allclose(ib.norm(dim=1), torch.ones(6, device="cuda"), atol=1e-5)
+    assert torch.equal(ib[:3], m.encode_image(imgs[0], normalize=True))
+    assert torch.equal(torch.load(str(tmp_path / "db" / "cc_text_databases.pt")), tb.cpu())
+    li = keds_amd.FlatIndex.load(str(tmp_path / "db" / "cc_image_index.pt"))
+    _, Iq, _ = li.search_device(ib[:2], 1)
+    assert Iq[:, 0].tolist() == [0, 1]
