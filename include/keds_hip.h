@@ -304,6 +304,12 @@ size_t keds_tower_workspace_bytes(int width, int seq, int B);
 int keds_tower_forward(const keds_tower_params* p, float* x, int B,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* _transform of src/model/clip.py:107-123 (eval branch) on the device: raw uint8 images [B,H,W,3] of one size (device) ->
+ * fp32 [B,3,n_px,n_px]: bicubic Resize of the shorter side to n_px (PIL semantics: two antialiased passes with a uint8
+ * intermediate), CenterCrop, /255, (x - mean) / std.  mean3 / std3: HOST arrays of 3 floats. */
+int keds_preprocess(const unsigned char* images, int B, int H, int W, int n_px, const float* mean3, const float* std3,
+                    float* out, void* stream);
+
 /* CLIP.encode_image (model.py:569-575,393-415): image fp32 [B,3,R,R] -> out fp32 [B, embed_dim] */
 size_t keds_vit_workspace_bytes(const keds_vit_params* p, int B);
 int keds_vit_run(const keds_vit_params* p, const float* image, int B, float* out, int normalize,

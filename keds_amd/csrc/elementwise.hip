@@ -129,6 +129,83 @@ __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __rest
     }
 }
 
+// ---- image preprocessing (src/model/clip.py:107-123 `_transform`, eval branch) on raw uint8 images ------------------
+// Resize(n_px, bicubic) on the shorter side + CenterCrop(n_px) + ToTensor + Normalize, as PIL / torchvision do them:
+// PIL resamples uint8 images in two separable passes (horizontal, then vertical), each with antialiasing support
+// 2 * max(scale, 1), cubic a = -0.5, weights normalised to 1, and rounds the intermediate image back to uint8.
+// One thread per output pixel re-creates that: for each source row under the vertical window it computes the
+// horizontally resampled 8-bit value, then the vertical pass.  (PIL quantises the weights to 22 fractional bits; here
+// they are fp32, so a rounding can flip by one 8-bit step on rare pixels.)
+__device__ __forceinline__ float pil_bicubic(float x) {
+    const float a = -0.5f;
+    x = fabsf(x);
+    if (x < 1.f) return ((a + 2.f) * x - (a + 3.f)) * x * x + 1.f;
+    if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * a;
+    return 0.f;
+}
+__device__ __forceinline__ void pil_window(int out_i, float scale, int in_size, int& lo, int& hi, float& center, float& ss) {
+    const float fs = fmaxf(scale, 1.f);
+    const float support = 2.f * fs;
+    center = (out_i + 0.5f) * scale;
+    ss = 1.f / fs;
+    lo = (int)(center - support + 0.5f);
+    hi = (int)(center + support + 0.5f);
+    lo = lo < 0 ? 0 : lo;
+    hi = hi > in_size ? in_size : hi;
+}
+__device__ __forceinline__ float clip8(float v) {               // PIL clip8 after its rounding shift
+    v = floorf(v + 0.5f);
+    return fminf(fmaxf(v, 0.f), 255.f);
+}
+
+__global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __restrict__ img, int B, int H, int W,
+                                                         int RW, int RH, int left, int top, int n_px,
+                                                         float m0, float m1, float m2, float s0, float s1, float s2,
+                                                         float* __restrict__ out) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * n_px * n_px) return;
+    const int b = idx / (n_px * n_px), rem = idx - b * n_px * n_px;
+    const int oy = rem / n_px, ox = rem - oy * n_px;
+    const unsigned char* src = img + (size_t)b * H * W * 3;
+    const float sx = (float)W / (float)RW, sy = (float)H / (float)RH;
+    int xlo, xhi, ylo, yhi;
+    float xc, xss, yc, yss;
+    pil_window(ox + left, sx, W, xlo, xhi, xc, xss);
+    pil_window(oy + top, sy, H, ylo, yhi, yc, yss);
+    float wxs = 0.f, wys = 0.f;
+    for (int x = xlo; x < xhi; ++x) wxs += pil_bicubic((x - xc + 0.5f) * xss);
+    for (int y = ylo; y < yhi; ++y) wys += pil_bicubic((y - yc + 0.5f) * yss);
+    float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f;
+    for (int y = ylo; y < yhi; ++y) {
+        const float wy = pil_bicubic((y - yc + 0.5f) * yss) / wys;
+        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+        if (RW == W) {                                         // PIL skips a pass that does not change the size
+            const unsigned char* p = src + ((size_t)y * W + (ox + left)) * 3;
+            h0 = p[0]; h1 = p[1]; h2 = p[2];
+        } else {
+            const unsigned char* row = src + (size_t)y * W * 3;
+            for (int x = xlo; x < xhi; ++x) {
+                const float wx = pil_bicubic((x - xc + 0.5f) * xss) / wxs;
+                h0 += wx * row[x * 3];
+                h1 += wx * row[x * 3 + 1];
+                h2 += wx * row[x * 3 + 2];
+            }
+            h0 = clip8(h0); h1 = clip8(h1); h2 = clip8(h2);     // the horizontal pass is stored as uint8
+        }
+        if (RH == H) {
+            if (y == oy + top) { acc0 = h0; acc1 = h1; acc2 = h2; }
+        } else {
+            acc0 += wy * h0; acc1 += wy * h1; acc2 += wy * h2;
+        }
+    }
+    if (RH != H) { acc0 = clip8(acc0); acc1 = clip8(acc1); acc2 = clip8(acc2); }
+    const size_t plane = (size_t)n_px * n_px;
+    float* o = out + (size_t)b * 3 * plane + (size_t)oy * n_px + ox;
+    o[0] = (acc0 * (1.f / 255.f) - m0) / s0;
+    o[plane] = (acc1 * (1.f / 255.f) - m1) / s1;
+    o[2 * plane] = (acc2 * (1.f / 255.f) - m2) / s2;
+}
+
 // one block per output row (b, patch); columns c*P*P + ky*P + kx, zero padded to Kpad
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int R,
                                                      int P, int Kpad) {
@@ -355,4 +432,26 @@ extern "C" int keds_fold_layernorm(const float* W, const float* bias, const floa
     fold_layernorm_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(W, bias, gamma, beta, N, K, (bf16_t*)w_folded,
                                                                         bias_csum);
     return keds_check_launch("fold_layernorm_kernel");
+}
+
+extern "C" int keds_preprocess(const unsigned char* images, int B, int H, int W, int n_px, const float* mean3,
+                               const float* std3, float* out, void* stream) {
+    KEDS_REQUIRE(images && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && n_px > 0, "keds_preprocess: bad argument");
+    // torchvision Resize(int): shorter side -> n_px, the other int(n_px * long / short); CenterCrop offsets round half up
+    int RW, RH;
+    if (W <= H) {
+        RW = n_px;
+        RH = (int)((long long)n_px * H / W);
+    } else {
+        RH = n_px;
+        RW = (int)((long long)n_px * W / H);
+    }
+    KEDS_REQUIRE(RW >= n_px && RH >= n_px, "keds_preprocess: resized image smaller than the crop");
+    const int left = (int)lrintf((RW - n_px) / 2.0f), top = (int)lrintf((RH - n_px) / 2.0f);
+    const long long total = (long long)B * n_px * n_px;
+    hipStream_t st = (hipStream_t)stream;
+    KedsProfScope prof(KEDS_PROF_OTHER, st);
+    preprocess_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(images, B, H, W, RW, RH, left, top, n_px, mean3[0],
+                                                                       mean3[1], mean3[2], std3[0], std3[1], std3[2], out);
+    return keds_check_launch("preprocess_kernel");
 }

@@ -72,6 +72,21 @@ def im2col(image: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
     return out
 
 
+def preprocess(images_u8: torch.Tensor, n_px: int, mean=(0.48145466, 0.4578275, 0.40821073),
+               std=(0.26862954, 0.26130258, 0.27577711)) -> torch.Tensor:
+    """uint8 [B,H,W,3] (one size per batch, device) -> fp32 [B,3,n_px,n_px]: the eval `_transform` of the reference
+    (bicubic resize of the shorter side, centre crop, normalise) in one kernel."""
+    import ctypes as C
+    if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3:
+        raise ValueError("expected uint8 images [B,H,W,3]")
+    images_u8 = images_u8.contiguous()
+    B, H, W, _ = images_u8.shape
+    out = torch.empty((B, 3, n_px, n_px), dtype=torch.float32, device=images_u8.device)
+    check(load().keds_preprocess(ptr(images_u8), B, H, W, n_px, (C.c_float * 3)(*mean), (C.c_float * 3)(*std), ptr(out),
+                                 stream()), "keds_preprocess")
+    return out
+
+
 def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor,
                  img_tokens: Optional[torch.Tensor] = None, insert_col: int = 0) -> torch.Tensor:
     B, L = tokens.shape
