@@ -135,11 +135,11 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
                 k.qkv_bc8 && k.fc_bc8;
     }
     const int Mm = M / 256 * 256;                  // rows in full 256-row tiles: MXFP8 GEMMs; the rest stays on the bf16 kernels
-    const bool fp8 = p->fp8 && folded && have8 && Mm > 0 && w % 256 == 0;
-    if (p->fp8 && !fp8) {
-        keds_set_error("keds_tower_forward: fp8 needs the folded and MXFP8 weights, width %% 256 == 0 and >= 256 rows");
+    if (p->fp8 && !(folded && have8 && w % 256 == 0)) {
+        keds_set_error("keds_tower_forward: fp8 needs the folded and MXFP8 weights and width %% 256 == 0");
         return KEDS_E_ARG;
     }
+    const bool fp8 = p->fp8 && Mm > 0;             // fewer than 256 rows: everything is "remainder rows" (bf16 kernels)
     if (fp8) return tower_forward_fp8(p, x, B, t, Mm, st);
     if (folded && (rc = keds_rowstats_cast(x, t.h, t.st1, M, w, st))) return rc;
     for (int l = 0; l < p->layers; ++l) {
