@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
                     help="fp8 = BASELINE config 5 (MXFP8 GEMM operands in the image tower); the headline metric is bf16")
+    ap.add_argument("--prof-every", type=int, default=4, help="record the per-launch hipEvents on every N-th timed step")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent pairs around every kernel class (default: only the "
                     "dominant GEMM class and the scan; the full breakdown costs ~1-2 %% of the step)")
     args = ap.parse_args()
@@ -182,14 +183,23 @@ def main():
         step()
     fence()
     _lib.prof_reset()
-    # hipEvent pair around every launch of the dominant kernel class (GEMM) and of the scan, inside the timed region
-    _lib.prof_enable(True, None if args.prof_all else (_lib.PROF_GEMM, _lib.PROF_SCAN))
+    # hipEvent pair around every launch of the dominant kernel class (GEMM) and of the scan, on the launch stream, inside
+    # the timed region -- on every `--prof-every`-th timed step (default 4: steps 0, 4, 8, ...).  An event pair costs ~3.5 us
+    # of stream time; around all 100 launches of every step that is 2.7 % of the step, sampled it is 0.7 %.
+    classes = None if args.prof_all else (_lib.PROF_GEMM, _lib.PROF_SCAN)
+    events = os.environ.get("KEDS_BENCH_NO_EVENTS") != "1"      # A/B of the event overhead only
+    prof_steps = 0
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        on = events and i % args.prof_every == 0
+        if on:
+            _lib.prof_enable(True, classes)
+            prof_steps += 1
         Dk, Ik = step()
+        if on:
+            _lib.prof_enable(False)
     fence()
     elapsed = time.perf_counter() - t0
-    _lib.prof_enable(False)
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -203,12 +213,13 @@ def main():
 
     if rank == 0:
         steps = args.steps
-        gemm_flops = 2.0 * GEMM_MAC_PER_IMAGE * B * steps      # this rank's GEMM launches
+        psteps = max(prof_steps, 1)                              # timed steps whose launches carried event pairs
+        gemm_flops = 2.0 * GEMM_MAC_PER_IMAGE * B * psteps     # this rank's GEMM launches on those steps
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B); a search issues two
         # scan launches (threshold pass over the first 1/16 of the rows + the full candidate pass): both are charged
         # to the time, only the single pass to the bytes
-        n_search = steps * world                                 # query blocks of 128 searched by this rank
+        n_search = psteps * world                                # query blocks of 128 searched by this rank (profiled steps)
         scan_bytes = (hi - lo) * D * 2.0 * n_search
         scan_ach = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
@@ -237,8 +248,9 @@ def main():
                               "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1),
                               # read-only stream over 4 GiB on this box: 7.15 TB/s (profiles/r01_microbench.txt)
                               "peak_measured": PEAK_HBM_MEASURED_GBPS, "frac_of_measured": scan_ach / PEAK_HBM_MEASURED_GBPS},
-            "stage_ms_per_step": {"gemm": gemm_ms / steps, "attention": attn_ms / steps, "layernorm": ln_ms / steps,
-                                  "scan": scan_ms / steps, "other": other_ms / steps},
+            "profiled_steps": prof_steps,
+            "stage_ms_per_step": {"gemm": gemm_ms / psteps, "attention": attn_ms / psteps, "layernorm": ln_ms / psteps,
+                                  "scan": scan_ms / psteps, "other": other_ms / psteps},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, N, D, k)
