@@ -476,9 +476,14 @@ constexpr int LDS_BYTES = 2 * PBUF_BYTES;       // 128 KiB
 // read bandwidth: dropping a third of the fragment reads changes nothing.  (c) The nominal matrix peak: a register-only
 // MFMA loop sustains 2.06 PFLOP/s on this chip (clock ~2.0 GHz under load), so 1.25-1.3 PF in this loop is ~62 % of the
 // practical peak; the vendor BLAS reaches 1.07 / 1.20 / 1.46 PF on the qkv / fc / proj shapes where this kernel does
-// 1.08 / 1.11 / 1.21.  A 4-wave variant (128 x 128 per wave, 256 accumulators pinned in AGPRs through inline-asm
-// MFMAs) was built and was not faster (1.29 vs 1.32 PF at 8192^3); with the MFMA builtin the register allocator moves
-// ~30 accumulators between AGPRs and VGPRs every K-tile (2 v_accvgpr ops per MFMA): correct, 1.21 vs 1.32 PF.
+// 1.08 / 1.11 / 1.21.  A 4-wave variant (2 x 2 waves, 128 x 128 per wave, 256 accumulators) was built three ways:
+// inline-asm MFMAs with "+a" operands (clean loop, results WRONG: the compiler does not know the asm reads its sources
+// over several cycles and lets the fragment prefetch overwrite them); the MFMA builtin alone (correct, but the register
+// allocator moves ~30 accumulators between AGPRs and VGPRs per K-tile: 1.21 vs 1.32 PF at 8192^3); the builtin plus an
+// empty `asm volatile("" : "+a"(acc[i][j]))` for every accumulator at each K-step boundary, which pins them in AGPRs
+// (clean loop: 128 MFMA, 32 ds_read_b128, 16 DMA, no v_accvgpr traffic; correct).  That last form reaches 1.39 vs 1.29 PF
+// at 8192^3 but LOSES on the shapes of this path (qkv -5 %, fc -9 %, out -3 %, proj -1 %): with one wave per SIMD the
+// per-tile prologue / epilogue is exposed, and K = 1024 tiles are mostly prologue and epilogue.  Not used.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
