@@ -95,7 +95,8 @@ int keds_topk_merge_parts(const float* D_parts, const int64_t* I_parts, int part
 int keds_gather_rows(const float* db, int dim, const int64_t* idx, int64_t count, float* out, void* stream);
 
 /* full gallery ranking for the recall metric (src/eval_utils.py:1040-1067):
- * order[q,:] = stable argsort of (1 - ref[q] . gallery[g]) ascending; G <= 8192. */
+ * order[q,:] = stable argsort of (1 - ref[q] . gallery[g]) ascending.  Up to 8192 gallery rows sort in LDS; larger
+ * galleries (ImageNet domain-conversion targets) sort 8192-row chunks and merge the runs in global memory. */
 size_t keds_rank_gallery_workspace_bytes(int nq, int ng);
 int keds_rank_gallery(const float* ref, int nq, const float* gallery, int ng, int dim,
                       int32_t* order, void* workspace, size_t workspace_bytes, void* stream);

@@ -80,6 +80,72 @@ __global__ __launch_bounds__(256) void sort_rows_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < ng; i += 256) order[(size_t)q * ng + i] = (int)(keys[i] & 0xFFFFFFFFu);
 }
 
+// ---- galleries beyond one LDS sort (> 8192 rows, e.g. the 17 k targets of the ImageNet domain-conversion eval):
+// sort 8192-column chunks in LDS into 64-bit keys (orderable(dist) << 32 | global column), then merge the sorted runs
+// pairwise in global memory; keys are unique, so an element's place in a merged pair is its offset in its own run plus
+// the number of smaller keys in the other run (one binary search per element).
+constexpr int SORT_CHUNK = 8192;
+
+__global__ __launch_bounds__(256) void sort_chunk_keys_kernel(const float* __restrict__ dist, int ng,
+                                                              unsigned long long* __restrict__ keys_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long keys[];
+    const int q = blockIdx.x, c0 = blockIdx.y * SORT_CHUNK;
+    const int len = min(SORT_CHUNK, ng - c0);
+    for (int i = threadIdx.x; i < SORT_CHUNK; i += 256)
+        keys[i] = i < len ? (((unsigned long long)orderable(dist[(size_t)q * ng + c0 + i])) << 32) | (unsigned)(c0 + i)
+                          : 0xFFFFFFFFFFFFFFFFull;
+    __syncthreads();
+    for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < SORT_CHUNK; i += 256) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const unsigned long long a = keys[i], b = keys[l];
+                    if ((a > b) == up) {
+                        keys[i] = b;
+                        keys[l] = a;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = threadIdx.x; i < len; i += 256) keys_out[(size_t)q * ng + c0 + i] = keys[i];
+}
+
+__device__ __forceinline__ int count_less(const unsigned long long* __restrict__ run, int n, unsigned long long key) {
+    int lo = 0, hi = n;                                  // first position whose key is >= `key` == number of smaller keys
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (run[mid] < key) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// one thread per element: runs of length `run` (the last one shorter) are merged in pairs
+__global__ __launch_bounds__(256) void merge_runs_kernel(const unsigned long long* __restrict__ in,
+                                                         unsigned long long* __restrict__ out, int nq, int ng, int run) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long long)nq * ng) return;
+    const int q = (int)(t / ng), i = (int)(t - (long long)q * ng);
+    const unsigned long long* row = in + (size_t)q * ng;
+    const int pair0 = (i / (2 * run)) * (2 * run);       // start of this pair of runs
+    const int a_len = min(run, ng - pair0), b0 = pair0 + a_len, b_len = max(0, min(run, ng - b0));
+    const unsigned long long key = row[i];
+    int pos;
+    if (i < b0) pos = (i - pair0) + count_less(row + b0, b_len, key);
+    else pos = (i - b0) + count_less(row + pair0, a_len, key);
+    out[(size_t)q * ng + pair0 + pos] = key;
+}
+
+__global__ __launch_bounds__(256) void keys_to_order_kernel(const unsigned long long* __restrict__ keys, long long total,
+                                                            int* __restrict__ order) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t < total) order[t] = (int)(keys[t] & 0xFFFFFFFFu);
+}
+
 // one wave per query
 __global__ __launch_bounds__(256) void cirr_rank_kernel(const int* __restrict__ order, int nq, int ng,
                                                         const int* __restrict__ gallery_ids,
@@ -159,13 +225,15 @@ int next_pow2(int n) {
 
 extern "C" size_t keds_rank_gallery_workspace_bytes(int nq, int ng) {
     if (nq <= 0 || ng <= 0) return 0;
-    return keds_align_up((size_t)nq * ng * sizeof(float), 256);
+    const size_t d = keds_align_up((size_t)nq * ng * sizeof(float), 256);
+    if (ng <= SORT_CHUNK) return d;
+    return d + 2 * keds_align_up((size_t)nq * ng * sizeof(unsigned long long), 256);   // two key buffers for the run merges
 }
 
 extern "C" int keds_rank_gallery(const float* ref, int nq, const float* gallery, int ng, int dim, int32_t* order,
                                  void* workspace, size_t workspace_bytes, void* stream) {
     KEDS_REQUIRE(ref && gallery && order && workspace && nq > 0 && ng > 0 && dim > 0, "keds_rank_gallery: bad argument");
-    KEDS_REQUIRE(ng <= 8192, "keds_rank_gallery: gallery of %d rows exceeds the 8192-row LDS sort", ng);
+    KEDS_REQUIRE((long long)nq * ng < (1LL << 40), "keds_rank_gallery: problem too large");
     if (workspace_bytes < keds_rank_gallery_workspace_bytes(nq, ng)) {
         keds_set_error("keds_rank_gallery: workspace too small");
         return KEDS_E_WORKSPACE;
@@ -176,6 +244,35 @@ extern "C" int keds_rank_gallery(const float* ref, int nq, const float* gallery,
     dist_kernel<<<grid, 256, 0, st>>>(ref, nq, gallery, ng, dim, dist);
     int rc = keds_check_launch("dist_kernel");
     if (rc) return rc;
+    if (ng > SORT_CHUNK) {
+        static bool chunk_attr = false;
+        if (!chunk_attr) {
+            if (hipFuncSetAttribute((const void*)sort_chunk_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) !=
+                hipSuccess) {
+                keds_set_error("keds_rank_gallery: cannot set dynamic LDS size");
+                return KEDS_E_LAUNCH;
+            }
+            chunk_attr = true;
+        }
+        const size_t db = keds_align_up((size_t)nq * ng * sizeof(float), 256);
+        const size_t kb = keds_align_up((size_t)nq * ng * sizeof(unsigned long long), 256);
+        unsigned long long* ka = (unsigned long long*)((char*)workspace + db);
+        unsigned long long* kbuf = (unsigned long long*)((char*)workspace + db + kb);
+        const int chunks = (ng + SORT_CHUNK - 1) / SORT_CHUNK;
+        sort_chunk_keys_kernel<<<dim3(nq, chunks), 256, 65536, st>>>(dist, ng, ka);
+        if ((rc = keds_check_launch("sort_chunk_keys_kernel"))) return rc;
+        const long long total = (long long)nq * ng;
+        const unsigned blocks = (unsigned)((total + 255) / 256);
+        for (int run = SORT_CHUNK; run < ng; run *= 2) {
+            merge_runs_kernel<<<blocks, 256, 0, st>>>(ka, kbuf, nq, ng, run);
+            if ((rc = keds_check_launch("merge_runs_kernel"))) return rc;
+            unsigned long long* t = ka;
+            ka = kbuf;
+            kbuf = t;
+        }
+        keys_to_order_kernel<<<blocks, 256, 0, st>>>(ka, total, order);
+        return keds_check_launch("keys_to_order_kernel");
+    }
     const int P = next_pow2(ng);
     const size_t lds = (size_t)P * 8;
     static bool attr_set = false;

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 
+import keds_amd
 from keds_amd import _lib, ops
 from oracle import keds_oracle as O
 from tests.gpu_util import bf16_round, max_abs, rel_l2, report
@@ -372,3 +373,37 @@ def test_gpu_preprocess_matches_pil_transform(H, W):
     assert float(diff.max()) <= 1.01 and frac_off <= 2e-3
     two = ops.preprocess(torch.from_numpy(np.stack([arr, arr[::-1].copy()])).cuda(), 224)
     assert torch.equal(two[0].cpu(), got)
+
+
+@pytest.mark.parametrize("nq,ng", [(37, 8193), (20, 17000), (5, 40000)])
+def test_large_gallery_ranking_and_imgnet_metric(nq, ng):
+    """Galleries beyond one LDS sort (chunk sort + run merges): the full ordering equals torch's stable argsort, and the
+    ImageNet-style multi-positive metric on top of it equals the oracle's."""
+    dim = 64
+    g = torch.Generator().manual_seed(ng)
+    gal = torch.nn.functional.normalize(torch.randn(ng, dim, generator=g), dim=1)
+    ref = torch.nn.functional.normalize(torch.randn(nq, dim, generator=g), dim=1)
+    gal[5] = gal[3]                                               # exact ties: lower index first
+    gal[ng - 1] = gal[ng - 2]
+    order = ops.rank_gallery(ref.cuda(), gal.cuda()).cpu()
+    dist = 1.0 - ref.cuda() @ gal.cuda().t()                       # same fp32 evaluation order is not guaranteed: compare by keys
+    want = torch.sort(dist, dim=1, stable=True).indices.cpu()
+    same = (order.long() == want)
+    if not bool(same.all()):                                       # tolerate swaps of keys that differ only by fp32 summation order
+        d = dist.cpu()
+        got_d = torch.gather(d, 1, order.long())
+        assert bool((got_d[:, 1:] >= got_d[:, :-1] - 2e-6).all()), "not sorted"
+        assert float(1.0 - same.float().mean()) < 1e-3
+    assert bool((torch.sort(order.long(), dim=1).values == torch.arange(ng)[None, :]).all()), "not a permutation"
+    tl = torch.randint(0, 30, (ng,), generator=g)
+    ql = torch.randint(0, 30, (nq,), generator=g)
+    mg = keds_amd.get_metrics_imgnet(ref.cuda(), gal.cuda(), ql, tl)
+    same_label = tl[order.long()] == ql[:, None]                   # the metric's definition evaluated on this very ordering
+    total = same_label.sum(1).float()
+    for k in (1, 5, 10, 50, 100, 200):
+        hits = same_label[:, :k].sum(1).float()
+        assert abs(float((hits / (total + 1e-5)).mean()) - mg[f"Real2Sketch_R@{k}"]) < 1e-6
+        assert abs(float((hits / k).mean()) - mg[f"Real2Sketch_P@{k}"]) < 1e-6
+    mo = O.get_metrics_imgnet(ref, gal, ql, tl)                    # and close to the oracle (near-tie flips move single hits)
+    for k, v in mo.items():
+        assert abs(v - mg[k]) <= 1.0 / nq + 1e-6, (k, v, mg[k])
