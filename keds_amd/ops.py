@@ -68,7 +68,8 @@ def im2col(image: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
     B, _, R, _ = image.shape
     g = R // patch
     out = torch.zeros((_pad128(B * g * g), kpad), dtype=torch.bfloat16, device=image.device)
-    check(load().keds_im2col(ptr(image.contiguous().float()), ptr(out), B, R, patch, kpad, stream()), "keds_im2col")
+    image = image.contiguous().float()           # a named reference: a temporary would be freed (and its block reused) before launch
+    check(load().keds_im2col(ptr(image), ptr(out), B, R, patch, kpad, stream()), "keds_im2col")
     return out
 
 
@@ -93,8 +94,9 @@ def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor,
     d = table.shape[1]
     x = torch.empty((B, L, d), dtype=torch.float32, device=table.device)
     n_tok = 0 if img_tokens is None else img_tokens.shape[1]
-    check(load().keds_embed_tokens(ptr(tokens.to(torch.int32).contiguous()), ptr(table), ptr(pos),
-                                   ptr(None if img_tokens is None else img_tokens.contiguous().float()),
+    tok32 = tokens.to(torch.int32).contiguous()
+    it32 = None if img_tokens is None else img_tokens.contiguous().float()
+    check(load().keds_embed_tokens(ptr(tok32), ptr(table), ptr(pos), ptr(it32),
                                    n_tok, insert_col, ptr(x), B, L, d, stream()), "keds_embed_tokens")
     return x
 
@@ -141,9 +143,10 @@ def cirr_target_rank(order: torch.Tensor, gallery_ids: torch.Tensor, ref_ids: to
     nq, ng = order.shape
     rank = torch.empty(nq, dtype=torch.int32, device=order.device)
     counts = torch.empty((nq, 2), dtype=torch.int32, device=order.device)
-    check(load().keds_cirr_target_rank(ptr(order), nq, ng, ptr(gallery_ids.to(torch.int32).contiguous()),
-                                       ptr(ref_ids.to(torch.int32).contiguous()),
-                                       ptr(target_ids.to(torch.int32).contiguous()), ptr(rank), ptr(counts), stream()),
+    # named references keep the converted copies alive until the launch is enqueued (a temporary passed straight to ptr()
+    # is freed at once and the allocator may hand its block to the next conversion)
+    gid, rid, tid = (t.to(order.device, torch.int32).contiguous() for t in (gallery_ids, ref_ids, target_ids))
+    check(load().keds_cirr_target_rank(ptr(order), nq, ng, ptr(gid), ptr(rid), ptr(tid), ptr(rank), ptr(counts), stream()),
           "keds_cirr_target_rank")
     return rank, counts
 
@@ -155,8 +158,9 @@ def label_hits(order: torch.Tensor, gallery_labels: torch.Tensor, query_labels: 
     hits = torch.empty((nq, len(ks)), dtype=torch.int32, device=order.device)
     total = torch.empty(nq, dtype=torch.int32, device=order.device)
     karr = (C.c_int * len(ks))(*[int(k) for k in ks])
-    check(load().keds_label_hits(ptr(order), nq, ng, ptr(gallery_labels.to(order.device, torch.int32).contiguous()),
-                                 ptr(query_labels.to(order.device, torch.int32).contiguous()), karr, len(ks), ptr(hits),
+    gl = gallery_labels.to(order.device, torch.int32).contiguous()       # named: see cirr_target_rank
+    ql = query_labels.to(order.device, torch.int32).contiguous()
+    check(load().keds_label_hits(ptr(order), nq, ng, ptr(gl), ptr(ql), karr, len(ks), ptr(hits),
                                  ptr(total), stream()), "keds_label_hits")
     return hits, total
 
@@ -166,6 +170,7 @@ def topk_merge_parts(D_parts: torch.Tensor, I_parts: torch.Tensor, metric: int):
     parts, nq, k = D_parts.shape
     D = torch.empty((nq, k), dtype=torch.float32, device=D_parts.device)
     I = torch.empty((nq, k), dtype=torch.int64, device=D_parts.device)
-    check(load().keds_topk_merge_parts(ptr(D_parts.contiguous().float()), ptr(I_parts.contiguous().to(torch.int64)),
+    D_parts, I_parts = D_parts.contiguous().float(), I_parts.contiguous().to(torch.int64)
+    check(load().keds_topk_merge_parts(ptr(D_parts), ptr(I_parts),
                                        parts, nq, k, metric, ptr(D), ptr(I), stream()), "keds_topk_merge_parts")
     return D, I
