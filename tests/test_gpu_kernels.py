@@ -393,7 +393,7 @@ def test_large_gallery_ranking_and_imgnet_metric(nq, ng):
         d = dist.cpu()
         got_d = torch.gather(d, 1, order.long())
         assert bool((got_d[:, 1:] >= got_d[:, :-1] - 2e-6).all()), "not sorted"
-        assert float(1.0 - same.float().mean()) < 1e-3
+        assert float(1.0 - same.float().mean()) < 1e-2
     assert bool((torch.sort(order.long(), dim=1).values == torch.arange(ng)[None, :]).all()), "not a permutation"
     tl = torch.randint(0, 30, (ng,), generator=g)
     ql = torch.randint(0, 30, (nq,), generator=g)
