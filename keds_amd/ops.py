@@ -127,6 +127,10 @@ def gather_rows(db: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
 
 def rank_gallery(ref: torch.Tensor, gallery: torch.Tensor) -> torch.Tensor:
     """order[q,:] = stable argsort(1 - ref[q] @ gallery.T) as int32 [Q,G]  (eval_utils.py:1042-1043)"""
+    if not ref.is_cuda or not gallery.is_cuda:          # the eval drivers sometimes hand over features they moved to the CPU
+        _lib.require_gpu()
+        dev = ref.device if ref.is_cuda else (gallery.device if gallery.is_cuda else torch.device("cuda", torch.cuda.current_device()))
+        ref, gallery = ref.to(dev), gallery.to(dev)
     ref = ref.contiguous().float()
     gallery = gallery.contiguous().float()
     nq, ng = ref.shape[0], gallery.shape[0]

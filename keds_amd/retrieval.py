@@ -104,8 +104,8 @@ def get_metrics_cirr(image_features: torch.Tensor, ref_features: torch.Tensor, r
     gal = _intern(index_names, table)
     ref = _intern(reference_names, table)
     tgt = _intern(target_names, table)
-    dev = image_features.device
     order = ops.rank_gallery(ref_features, image_features)
+    dev = order.device
     rank, counts = ops.cirr_target_rank(order, torch.from_numpy(gal).to(dev), torch.from_numpy(ref).to(dev),
                                         torch.from_numpy(tgt).to(dev))
     counts = counts.cpu()
@@ -128,8 +128,8 @@ def get_metrics_fashion(image_features: torch.Tensor, ref_features: torch.Tensor
     table: Dict[str, int] = {}
     gal = _intern_whole(target_names, table)
     ans = _intern_whole(answer_names, table)
-    dev = image_features.device
     order = ops.rank_gallery(ref_features, image_features)
+    dev = order.device
     none = torch.full((len(ans),), -1, dtype=torch.int32, device=dev)          # nothing is removed from the ranking
     rank, counts = ops.cirr_target_rank(order, torch.from_numpy(gal).to(dev), none, torch.from_numpy(ans).to(dev))
     if not bool((counts[:, 1] == 1).all()):                                    # eval_utils.py:1033
@@ -145,12 +145,12 @@ def get_metrics_coco(image_features: torch.Tensor, ref_features: torch.Tensor, l
     n = ref_features.shape[0]
     if image_features.shape[0] != n:
         raise RuntimeError("get_metrics_coco needs paired features")
-    dev = image_features.device
-    ids = torch.arange(n, dtype=torch.int32, device=dev)
-    none = torch.full((n,), -1, dtype=torch.int32, device=dev)
     out: Dict[str, float] = {}
     for name, a, b in (("image_to_ref", image_features, ref_features), ("ref_to_image", ref_features, image_features)):
         order = ops.rank_gallery(a, b)                 # ascending 1 - a.b == descending logits
+        dev = order.device
+        ids = torch.arange(n, dtype=torch.int32, device=dev)
+        none = torch.full((n,), -1, dtype=torch.int32, device=dev)
         rank, _ = ops.cirr_target_rank(order, ids, none, ids)
         preds = rank.cpu().numpy()
         out[f"{name}_mean_rank"] = float(preds.mean() + 1)

@@ -284,3 +284,34 @@ def test_deterministic_switch_gives_bitwise_reproducible_embeddings(monkeypatch)
     assert m._engine().vit.tower.blocks[0].qkv_wf is None
     _assert_close("deterministic.vs_folded", a, fast, cos_min=0.99995, rel_max=1e-2)
     _assert_close("deterministic.golden", m.encode_image(torch.from_numpy(g["image"]).cuda()), g["encode_image"])
+
+
+def test_user_style_inputs_cpu_features_and_other_neighbour_counts():
+    """Call shapes a reference user produces: metric functions fed CPU feature tensors (the drivers .cpu() their features,
+    eval_utils.py:549-553), CrossFormer with neighbour counts other than 16, half-precision images."""
+    g = dict(np.load(golden_path("metrics_cirr.npz")))
+    G = g["gallery"].shape[0]
+    index_names = [f"/data/cirr/dev/img_{i:05d}.png" for i in range(G)]
+    ref_names = [os.path.basename(index_names[i]) for i in g["ref_idx"]]
+    tgt_names = [os.path.basename(index_names[i]) for i in g["tgt_idx"]]
+    m = keds_amd.get_metrics_cirr(torch.from_numpy(g["gallery"]), torch.from_numpy(g["ref"]), ref_names, index_names, tgt_names)
+    for k in (1, 5, 10, 50, 100):
+        assert abs(m[f"recall_R@{k}"] - float(g[f"recall_R_at_{k}"])) < 1e-4
+    e = dict(np.load(golden_path("eval_glue.npz")))
+    mc = keds_amd.get_metrics_coco(torch.from_numpy(e["coco_image"]), torch.from_numpy(e["coco_ref"]), torch.tensor(100.0))
+    assert abs(mc["image_to_ref_R@1"] - float(e["coco_image_to_ref_R_at_1"])) < 1e-6
+    dim = 128
+    fuse = O.synth_crossformer_state_dict(dim, 3, seed=5, tag="fuse")
+    xf = keds_amd.CrossFormer(dim, dim, dim, num_layers=3).eval()
+    xf.load_state_dict(fuse)
+    xf = xf.cuda()
+    for K in (1, 5, 32):
+        q = O.synth_database(4, dim, seed=K)
+        kv = O.synth_database(4 * K, dim, seed=K + 1).reshape(4, K, dim)
+        got = xf(q.cuda().unsqueeze(1), kv.cuda(), kv.cuda())
+        want = O.crossformer(fuse, q.unsqueeze(1), kv, kv)
+        _assert_close(f"crossformer.K{K}", got, want, rel_max=2e-2)
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    mm = keds_amd.build_model(dict(sd), fp16=False).cuda()
+    img = torch.from_numpy(dict(np.load(golden_path("clip_tiny.npz")))["image"])
+    _assert_close("tiny.encode_image.half_input", mm.encode_image(img.cuda().half()), O.encode_image(sd, img.half().float()))
