@@ -262,6 +262,8 @@ class CLIP(nn.Module):
                                f"got {tuple(image.shape)}")
         img = image.to(eng.device, dtype=torch.float32).contiguous()
         B = img.shape[0]
+        if B == 0:                                    # an empty last batch of a loader: the reference returns [0, embed_dim]
+            return torch.empty((0, self.embed_dim), dtype=self.dtype, device=eng.device)
         lib = load()
         nbytes = lib.keds_vit_workspace_bytes(C.byref(eng.vit), B)
         ws = self._ws.get(nbytes, eng.device)
@@ -281,6 +283,8 @@ class CLIP(nn.Module):
         eng = self._engine()
         lib = load()
         B = text.shape[0]
+        if B == 0:
+            return torch.empty((0, self.embed_dim), dtype=self.dtype, device=eng.device)
         tok = text.to(eng.device, dtype=torch.int32).contiguous()
         ro = readout.to(eng.device, dtype=torch.int32).contiguous()
         it = None if img_tokens is None else img_tokens.to(eng.device, dtype=torch.float32).contiguous()

@@ -315,3 +315,21 @@ def test_user_style_inputs_cpu_features_and_other_neighbour_counts():
     mm = keds_amd.build_model(dict(sd), fp16=False).cuda()
     img = torch.from_numpy(dict(np.load(golden_path("clip_tiny.npz")))["image"])
     _assert_close("tiny.encode_image.half_input", mm.encode_image(img.cuda().half()), O.encode_image(sd, img.half().float()))
+
+
+def test_default_fp16_checkpoint_model_and_empty_batches():
+    """build_model(state_dict) with the reference's default fp16 conversion (model.py:988): half outputs, results within the
+    tolerance of the fp16-rounded weights; empty batches return empty tensors like the reference."""
+    g = dict(np.load(golden_path("clip_tiny.npz")))
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    m = keds_amd.build_model(dict(sd)).cuda()                      # fp16=True default
+    assert m.dtype == torch.float16
+    img = torch.from_numpy(g["image"]).cuda()
+    out = m.encode_image(img.half())
+    assert out.dtype == torch.float16
+    _assert_close("tiny.fp16_model.encode_image", out, g["encode_image"], cos_min=0.9995, rel_max=4e-2)
+    txt = m.encode_text(torch.from_numpy(g["text"]).cuda())
+    assert txt.dtype == torch.float16
+    _assert_close("tiny.fp16_model.encode_text", txt, g["encode_text"], cos_min=0.9995, rel_max=4e-2)
+    assert tuple(m.encode_image(img[:0]).shape) == (0, 128)
+    assert tuple(m.encode_text(torch.from_numpy(g["text"][:0]).cuda()).shape) == (0, 128)
