@@ -323,3 +323,25 @@ def test_index_save_load_and_database_extraction(tmp_path):
     li = keds_amd.FlatIndex.load(str(tmp_path / "db" / "cc_image_index.pt"))
     _, Iq, _ = li.search_device(ib[:2], 1)
     assert Iq[:, 0].tolist() == [0, 1]
+
+
+def test_exact_ties_larger_than_k():
+    """Groups of identical rows around the best match.  Up to the 64 re-ranked candidates the (distance, id) order is exact
+    (lowest ids first, like the oracle's stable sort); beyond that the distances are still exact and the ids are members of
+    the tied group (which of > 64 identical rows are reported is not defined by the reference either: Faiss does not order ties)."""
+    dim = 256
+    db = O.synth_database(20000, dim, seed=77)
+    q = O.synth_database(3, dim, seed=78)
+    for group, start in ((40, 5000), (200, 9000)):
+        d2 = db.clone()
+        d2[start:start + group] = q[0]                              # `group` exact copies of query 0
+        idx = keds_amd.FlatIndex(dim)
+        idx.add(d2)
+        D, I, _ = idx.search_device(q.cuda(), 16)
+        Do, Io = O.flat_l2_search(d2, q, 16)
+        assert max_abs(D, Do) <= D_ATOL
+        assert torch.equal(I.cpu()[1:], Io[1:])                     # the other queries are untouched
+        got = I.cpu()[0]
+        assert bool(((got >= start) & (got < start + group)).all()) and len(set(got.tolist())) == 16
+        if group <= 64:
+            assert torch.equal(got, Io[0])
