@@ -304,6 +304,7 @@ struct keds_ctx {
 
 struct keds_vit {
     keds_ctx* ctx;
+    int device = 0;            // copied from the context: destroy must not touch a context that may already be gone
     Arena mem;
     std::vector<keds_block_params> blocks;
     keds_vit_params p;
@@ -312,6 +313,7 @@ struct keds_vit {
 
 struct keds_text {
     keds_ctx* ctx;
+    int device = 0;            // copied from the context: destroy must not touch a context that may already be gone
     Arena mem;
     std::vector<keds_block_params> blocks;
     keds_text_params p;
@@ -320,6 +322,7 @@ struct keds_text {
 
 struct keds_knowledge {
     keds_ctx* ctx;
+    int device = 0;            // copied from the context: destroy must not touch a context that may already be gone
     Arena mem;
     std::vector<keds_cross_layer_params> fuse, cond;
     keds_knowledge_params p;
@@ -328,6 +331,7 @@ struct keds_knowledge {
 
 struct keds_index {
     keds_ctx* ctx;
+    int device = 0;            // copied from the context: destroy must not touch a context that may already be gone
     int dim, metric;
     int64_t n = 0, row0 = 0;
     float* rows = nullptr;
@@ -383,6 +387,7 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
     const keds_tensor *conv, *pos, *proj;
     keds_vit* v = new keds_vit();
     v->ctx = ctx;
+    v->device = ctx->device;
     Loader L{W, v->mem, what};
     auto fail = [&](int code) {
         delete v;
@@ -441,7 +446,7 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
 
 extern "C" int keds_vit_destroy(keds_vit* vit) {
     if (vit) {
-        (void)hipSetDevice(vit->ctx->device);
+        (void)hipSetDevice(vit->device);
         delete vit;
     }
     return KEDS_OK;
@@ -487,6 +492,7 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
     Weights W(weights, n);
     keds_text* t = new keds_text();
     t->ctx = ctx;
+    t->device = ctx->device;
     Loader L{W, t->mem, what};
     auto fail = [&](int code) {
         delete t;
@@ -532,7 +538,7 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
 
 extern "C" int keds_text_destroy(keds_text* txt) {
     if (txt) {
-        (void)hipSetDevice(txt->ctx->device);
+        (void)hipSetDevice(txt->device);
         delete txt;
     }
     return KEDS_OK;
@@ -607,6 +613,7 @@ extern "C" int keds_knowledge_create(keds_ctx* ctx, const keds_tensor* im2text, 
     if (rc) return rc;
     keds_knowledge* k = new keds_knowledge();
     k->ctx = ctx;
+    k->device = ctx->device;
     memset(&k->p, 0, sizeof(k->p));
     auto fail = [&](int code) {
         delete k;
@@ -656,7 +663,7 @@ extern "C" int keds_knowledge_create(keds_ctx* ctx, const keds_tensor* im2text, 
 
 extern "C" int keds_knowledge_destroy(keds_knowledge* kn) {
     if (kn) {
-        (void)hipSetDevice(kn->ctx->device);
+        (void)hipSetDevice(kn->device);
         delete kn;
     }
     return KEDS_OK;
@@ -684,6 +691,7 @@ extern "C" int keds_index_create(keds_ctx* ctx, int dim, int metric, int storage
     if (rc) return rc;
     keds_index* idx = new keds_index();
     idx->ctx = ctx;
+    idx->device = ctx->device;
     idx->dim = dim;
     idx->metric = metric;
     *out = idx;
@@ -692,7 +700,7 @@ extern "C" int keds_index_create(keds_ctx* ctx, int dim, int metric, int storage
 
 extern "C" int keds_index_destroy(keds_index* idx) {
     if (idx) {
-        (void)hipSetDevice(idx->ctx->device);
+        (void)hipSetDevice(idx->device);
         if (idx->rows) (void)hipFree(idx->rows);
         if (idx->packed) (void)hipFree(idx->packed);
         delete idx;

@@ -164,3 +164,25 @@ def test_sharded_search_through_rccl_single_rank():
         idx.close()
     finally:
         c.close()
+
+
+def test_handle_lifetimes_and_batch_sequences(tiny):
+    """Handles survive growing / shrinking batches, several handles share a context, and destroying the context before its
+    handles does not crash (handles keep their own device id)."""
+    g, sd, m = tiny
+    c = session.Context(0)
+    a = session.Vit(c, {k: v.numpy() for k, v in sd.items()})
+    b = session.Vit(c, {k: v.cuda() for k, v in sd.items()})
+    rs = np.random.RandomState(2)
+    for B in (1, 9, 2, 33, 1):
+        img = torch.from_numpy(rs.standard_normal((B, 3, 56, 56)).astype(np.float32)).cuda()
+        ya, yb = a.forward(img), b.forward(img)
+        assert torch.equal(ya, yb) and torch.equal(ya, m.encode_image(img))
+    idx = session.Index(c, 128)
+    db = O.synth_database(700, 128, seed=3)
+    for lo, hi in ((0, 1), (1, 33), (33, 700)):
+        idx.add(db[lo:hi].numpy())
+    D, I = idx.search(db[:5].cuda(), 3)
+    assert I[:, 0].tolist() == [0, 1, 2, 3, 4]
+    c.close()                                                       # context first ...
+    a.close(); b.close(); idx.close()                               # ... handles afterwards
