@@ -215,6 +215,12 @@ def main():
         steps = args.steps
         psteps = max(prof_steps, 1)                              # timed steps whose launches carried event pairs
         gemm_flops = 2.0 * GEMM_MAC_PER_IMAGE * B * psteps     # this rank's GEMM launches on those steps
+        # rows the towers run on the side lane (B*257 mod 256 = 128 of 32,896): those launches overlap the main stream and
+        # carry no event pairs, so their flops leave the numerator as well
+        side_rows = _lib.load().keds_tower_side_rows(VITL["vision_width"], 257, B, int(args.precision == "fp8"))
+        if side_rows:
+            tower_mac = 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL
+            gemm_flops -= 2.0 * tower_mac * B * psteps * side_rows / (B * 257.0)
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B); a search issues two
         # scan launches (threshold pass over the first 1/16 of the rows + the full candidate pass): both are charged
@@ -248,7 +254,7 @@ def main():
                               "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1),
                               # read-only stream over 4 GiB on this box: 7.15 TB/s (profiles/r01_microbench.txt)
                               "peak_measured": PEAK_HBM_MEASURED_GBPS, "frac_of_measured": scan_ach / PEAK_HBM_MEASURED_GBPS},
-            "profiled_steps": prof_steps,
+            "profiled_steps": prof_steps, "side_lane_rows": side_rows,
             "stage_ms_per_step": {"gemm": gemm_ms / psteps, "attention": attn_ms / psteps, "layernorm": ln_ms / psteps,
                                   "scan": scan_ms / psteps, "other": other_ms / psteps},
         }

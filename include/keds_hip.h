@@ -300,6 +300,11 @@ typedef struct {
 } keds_text_params;
 
 size_t keds_tower_workspace_bytes(int width, int seq, int B);
+/* Rows (B*seq mod 256) that keds_tower_forward runs as their own chain on a second, high-priority stream beside the
+ * full 256-row tiles (0: one stream; always 0 with KEDS_SIDE_STREAM=0).  Their launches carry no profiling events:
+ * keds_prof_read(KEDS_PROF_GEMM) then covers the full-tile launches only (bench.py scales the flops to match). */
+int keds_tower_side_rows(int width, int seq, int B, int fp8);
+int keds_side_lane_enable(int on);            /* run-time override of KEDS_SIDE_STREAM (default: on); results are identical */
 
 /* x fp32 [B*seq (padded to 128), width] in place through all residual blocks (model.py:372-373) */
 int keds_tower_forward(const keds_tower_params* p, float* x, int B,

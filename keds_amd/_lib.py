@@ -147,6 +147,8 @@ SIGNATURES = {
     "keds_mix_normalize": (i32, [vp, vp, f32, f32, vp, vp, vp, i32, i32, vp]),
     "keds_cast_bf16": (i32, [vp, vp, i64, vp]),
     "keds_tower_workspace_bytes": (sz, [i32, i32, i32]),
+    "keds_tower_side_rows": (i32, [i32, i32, i32, i32]),
+    "keds_side_lane_enable": (i32, [i32]),
     "keds_tower_forward": (i32, [C.POINTER(TowerParams), vp, i32, vp, sz, vp]),
     "keds_vit_workspace_bytes": (sz, [C.POINTER(VitParams), i32]),
     "keds_vit_run": (i32, [C.POINTER(VitParams), vp, i32, vp, i32, vp, sz, vp]),

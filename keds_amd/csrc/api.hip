@@ -2,6 +2,7 @@
 #include "keds_common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -26,6 +27,55 @@ int keds_check_launch(const char* what) {
 extern "C" int keds_abi_version(void) { return KEDS_ABI_VERSION; }
 extern "C" const char* keds_last_error(void) { return g_err; }
 
+// ---- side lane ---------------------------------------------------------------------------
+namespace {
+std::mutex g_lane_mu;
+KedsSideLane g_lanes[64];
+int g_lane_state[64];                          // 0 untried, 1 ready, -1 unavailable
+bool is_side_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> g(g_lane_mu);
+    for (int d = 0; d < 64; ++d)
+        if (g_lane_state[d] == 1 && g_lanes[d].s == s) return true;
+    return false;
+}
+}  // namespace
+
+static int g_lane_on = -1;                     // -1: take KEDS_SIDE_STREAM (default on)
+bool keds_side_lane_enabled() {
+    if (g_lane_on < 0) {
+        const char* e = getenv("KEDS_SIDE_STREAM");
+        g_lane_on = !(e && e[0] == '0');
+    }
+    return g_lane_on != 0;
+}
+extern "C" int keds_side_lane_enable(int on) {
+    g_lane_on = on ? 1 : 0;
+    return KEDS_OK;
+}
+
+KedsSideLane* keds_side_lane() {
+    if (!keds_side_lane_enabled()) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> g(g_lane_mu);
+    if (g_lane_state[dev] == 0) {
+        int least = 0, greatest = 0;           // the "greatest" priority is the numerically lowest value
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        const bool ok = hipStreamCreateWithPriority(&g_lanes[dev].s, hipStreamNonBlocking, greatest) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        g_lane_state[dev] = ok ? 1 : -1;
+    }
+    return g_lane_state[dev] == 1 ? &g_lanes[dev] : nullptr;
+}
+
+int keds_stream_order(hipStream_t from, hipEvent_t ev, hipStream_t to) {
+    if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
+        keds_set_error("stream ordering failed: %s", hipGetErrorString(hipGetLastError()));
+        return KEDS_E_LAUNCH;
+    }
+    return KEDS_OK;
+}
+
 // ---- profiling ---------------------------------------------------------------------------
 namespace {
 struct EvPair {
@@ -46,6 +96,9 @@ ProfState& prof() {
 KedsProfScope::KedsProfScope(int k, hipStream_t s) : klass(k), stream(s), slot(nullptr) {
     ProfState& p = prof();
     if (!(p.mask >> klass & 1u)) return;
+    // side-lane launches overlap the caller's stream (and their event pairs would also time the wait for a free CU):
+    // summing them with the main-lane durations would double-count the time, so they carry no events
+    if (s && is_side_stream(s)) return;
     std::lock_guard<std::mutex> g(p.mu);
     EvPair ev;
     if (!p.pool.empty()) {

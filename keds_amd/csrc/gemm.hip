@@ -648,6 +648,12 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
 
 int g_force_small = 0;   // test hook: route everything through the 128^2 kernel
 
+bool big_tiles_ok(int M, int N, int K) {
+    const long bt = (long)(M / pr::TM) * (N / pr::TN);
+    const long rounds = (bt + 255) / 256;
+    return !g_force_small && N % pr::TN == 0 && K % 64 == 0 && K >= 128 && bt >= 512 && bt * 100 >= rounds * 256 * 85;
+}
+
 template <int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                 int aux_i, void* aux2, long long lda, long long ldc, hipStream_t st) {
@@ -656,10 +662,7 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     // (ViT-L/14 at B=128: M = 32896 = 128*256 + 128, so 512..2048 big tiles = whole rounds on 256 CUs.)
     // the 256^2 kernel runs one workgroup per CU: use it when its full tiles fill at least two rounds of 256 CUs
     // with >= 85% of the last round busy; otherwise the 128^2 kernel's finer tiles quantise better
-    const long bt = (long)(M / pr::TM) * (N / pr::TN);
-    const long rounds = (bt + 255) / 256;
-    const bool big_ok = !g_force_small && lda == K && ldc == N && N % pr::TN == 0 && K % 64 == 0 && K >= 128 && bt >= 512 &&
-                        bt * 100 >= rounds * 256 * 85 && (EPI != KEDS_EPI_PATCH_F32 || M % pr::TM == 0);
+    const bool big_ok = big_tiles_ok(M, N, K) && lda == K && ldc == N && (EPI != KEDS_EPI_PATCH_F32 || M % pr::TM == 0);
     if (!big_ok) return launch_small<EPI>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
     const int m_main = M / pr::TM * pr::TM;
     int rc = launch_big<EPI>(A, W, bias, out, m_main, N, K, aux, aux_i, aux2, st);
@@ -682,6 +685,9 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
 }  // namespace
 
 bool keds_gemm_workspace_registered() { return g_ws != nullptr; }
+// true when a dense [M,K] x [N,K]^T problem sends its full 256-row tiles to the 256^2 kernel (and M % 256 rows to a
+// second, small launch): the towers then run those remainder rows as their own chain on the side lane
+bool keds_gemm_splits_rows(int M, int N, int K) { return big_tiles_ok(M, N, K) && M % pr::TM != 0; }
 
 extern "C" int keds_gemm_set_workspace(void* ptr, size_t bytes) {
     g_ws = (float*)ptr;

@@ -37,6 +37,17 @@ struct KedsProfScope {
     ~KedsProfScope();
 };
 
+// ---- side lane (host): a second, high-priority stream per device for the remainder-row chain of the towers ----------
+// Callers fork to it / join from it with their own events (keds_stream_order).  nullptr when disabled (KEDS_SIDE_STREAM=0)
+// or when the stream cannot be created: callers then run everything on their own stream.
+struct KedsSideLane {
+    hipStream_t s;
+};
+KedsSideLane* keds_side_lane();
+bool keds_side_lane_enabled();
+// record on `from`, make `to` wait: everything enqueued on `to` afterwards runs after everything enqueued on `from` so far
+int keds_stream_order(hipStream_t from, hipEvent_t ev, hipStream_t to);
+
 static inline size_t keds_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- device helpers ----------------------------------------------------------------------

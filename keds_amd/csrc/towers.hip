@@ -5,22 +5,25 @@
 // Host code only: every launch is asynchronous on the caller's stream, the caller owns the
 // workspace, nothing is allocated or synchronised here.
 #include "keds_common.h"
+#include <cstdlib>
 
 int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
 int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int S, int d, hipStream_t st);
 
+bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
+
 namespace {
 
 size_t pad_rows(size_t m) { return keds_align_up(m, 128); }
 
-// scratch of one tower: h [Mp,w] bf16 | big [Mp,4w] bf16 (qkv [Mp,3w] + attn [Mp,w], later the MLP hidden) |
-// two row-statistics buffers [Mp,2] of 64-bit fixed point (LayerNorm folded into the GEMMs: ln_1 / ln_2 statistics)
+// scratch of one tower: h [Mp,w] bf16 | qkv [Mp,3w] | attn [Mp,w] | MLP hidden [Mp,4w] (all bf16) |
+// two row-statistics buffers [Mp,2] of 64-bit fixed point (LayerNorm folded into the GEMMs: ln_1 / ln_2 statistics).
+// No buffer aliases another: the remainder-row chain runs beside the full-tile chain (see RowLanes) and the two touch
+// disjoint ROWS of every buffer, which only keeps them apart if the buffers themselves are distinct.
 struct TowerWs {
-    char* h;
-    char* big;
-    float* st1;
-    float* st2;
+    bf16_t *h, *qkv, *att, *hid;
+    keds_stat_t *st1, *st2;
     // MXFP8 operands of the full 256-row tiles (fp8 towers): residual copy, attention output, MLP hidden (+ scale dwords)
     unsigned char *xq, *xs, *aq, *as, *hq, *hs;
     size_t bytes;
@@ -30,99 +33,151 @@ TowerWs carve_tower(void* ws, int width, int seq, int B) {
     const size_t Mp = pad_rows((size_t)B * seq);
     TowerWs t;
     char* p = (char*)ws;
-    const size_t hb = keds_align_up(Mp * width * 2, 256);
-    const size_t bb = keds_align_up(Mp * (size_t)width * 4 * 2, 256);
-    const size_t sb = keds_align_up(Mp * 2 * sizeof(keds_stat_t), 256);
-    t.h = p;
-    t.big = p ? p + hb : nullptr;
-    t.st1 = p ? (float*)(p + hb + bb) : nullptr;
-    t.st2 = p ? (float*)(p + hb + bb + sb) : nullptr;
-    const size_t Mm = (size_t)B * seq / 256 * 256;
-    const size_t q1 = keds_align_up(Mm * width, 256), s1 = keds_align_up(Mm * (size_t)(width / 32), 256);   // 1 scale byte / 32
-    size_t off = hb + bb + 2 * sb;
+    size_t off = 0;
     auto take = [&](size_t n) {
-        unsigned char* r = p ? (unsigned char*)(p + off) : nullptr;
-        off += n;
+        char* r = p ? p + off : nullptr;
+        off += keds_align_up(n, 256);
         return r;
     };
-    t.xq = take(q1);
-    t.xs = take(s1);
-    t.aq = take(q1);
-    t.as = take(s1);
-    t.hq = take(4 * q1);
-    t.hs = take(4 * s1);
+    t.h = (bf16_t*)take(Mp * width * 2);
+    t.qkv = (bf16_t*)take(Mp * (size_t)width * 3 * 2);
+    t.att = (bf16_t*)take(Mp * (size_t)width * 2);
+    t.hid = (bf16_t*)take(Mp * (size_t)width * 4 * 2);
+    t.st1 = (keds_stat_t*)take(Mp * 2 * sizeof(keds_stat_t));
+    t.st2 = (keds_stat_t*)take(Mp * 2 * sizeof(keds_stat_t));
+    const size_t Mm = (size_t)B * seq / 256 * 256;
+    const size_t q1 = Mm * width, s1 = Mm * (size_t)(width / 32);   // 1 scale byte / 32
+    t.xq = (unsigned char*)take(q1);
+    t.xs = (unsigned char*)take(s1);
+    t.aq = (unsigned char*)take(q1);
+    t.as = (unsigned char*)take(s1);
+    t.hq = (unsigned char*)take(4 * q1);
+    t.hs = (unsigned char*)take(4 * s1);
     t.bytes = off;
     return t;
 }
 
+// Two lanes for one tower pass.  At B = 128 a ViT-L/14 tower has 32,896 rows = 128 full 256-row tiles + 128 remainder
+// rows; every GEMM of the remainder is a handful of workgroups whose time is pure latency (13-14 us each, 61 us per block,
+// 5.6 % of the step when it runs between the full-tile launches).  Rows only meet in the attention, so per block the
+// remainder chain (out-proj, fc, proj, next qkv) runs on the side lane while the caller's stream runs the same four GEMMs
+// on the full tiles: fork after the attention, join before the next one.
+struct RowLanes {
+    hipStream_t main = nullptr, side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool split = false;
+    int init(hipStream_t st, bool want) {
+        main = side = st;
+        KedsSideLane* lane = want ? keds_side_lane() : nullptr;
+        if (!lane) return KEDS_OK;
+        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            return KEDS_OK;                                   // no events: one lane
+        }
+        side = lane->s;
+        split = true;
+        return KEDS_OK;
+    }
+    int to_side() { return split ? keds_stream_order(main, fork, side) : KEDS_OK; }
+    int to_main() { return split ? keds_stream_order(side, join, main) : KEDS_OK; }
+    ~RowLanes() {                                             // destroying a recorded event releases it when it completes
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+    }
+};
+
+struct RowSpan {
+    size_t r0;
+    int n;
+    hipStream_t st;
+};
+
+// the four GEMMs of a block on a span of rows, bf16 operands, LayerNorm folded (keds_hip.h, KEDS_EPI_LN_*)
+int qkv_rows(const TowerWs& t, const keds_block_params& k, int w, RowSpan s) {
+    return keds_gemm_bt_ex2(t.h + s.r0 * w, w, k.qkv_wf, k.qkv_bc, t.qkv + s.r0 * 3 * w, 3 * w, s.n, 3 * w, w,
+                            KEDS_EPI_LN_BIAS_BF16, (const float*)(t.st1 + 2 * s.r0), 0, t.st2 + 2 * s.r0, s.st);
+}
+int out_rows(const TowerWs& t, const keds_block_params& k, float* x, int w, RowSpan s) {
+    return keds_gemm_bt_ex2(t.att + s.r0 * w, w, k.out_w, k.out_b, x + s.r0 * w, w, s.n, w, w, KEDS_EPI_RESID_STATS_F32,
+                            (const float*)(t.st2 + 2 * s.r0), 0, t.h + s.r0 * w, s.st);
+}
+int fc_rows(const TowerWs& t, const keds_block_params& k, int w, RowSpan s) {
+    return keds_gemm_bt_ex2(t.h + s.r0 * w, w, k.fc_wf, k.fc_bc, t.hid + s.r0 * 4 * w, 4 * w, s.n, 4 * w, w,
+                            KEDS_EPI_LN_QGELU_BF16, (const float*)(t.st2 + 2 * s.r0), 0, t.st1 + 2 * s.r0, s.st);
+}
+// the last block's output feeds no further ln_1: plain residual update
+int proj_rows(const TowerWs& t, const keds_block_params& k, float* x, int w, bool last, RowSpan s) {
+    return keds_gemm_bt_ex2(t.hid + s.r0 * 4 * w, 4 * w, k.proj_w, k.proj_b, x + s.r0 * w, w, s.n, w, 4 * w,
+                            last ? KEDS_EPI_BIAS_RESID_F32 : KEDS_EPI_RESID_STATS_F32,
+                            last ? nullptr : (const float*)(t.st1 + 2 * s.r0), 0, last ? nullptr : (void*)(t.h + s.r0 * w),
+                            s.st);
+}
+
+// After the last block only token 0 of every sample is read (ln_post(x[:,0,:]), model.py:412), so the attention
+// queries, out-proj, ln_2 and the MLP run on those B rows only (row stride S*w in x / attn); bf16 kernels.
+int cls_rows_tail(const keds_tower_params* p, const keds_block_params& k, const TowerWs& t, float* x, int B, hipStream_t st) {
+    const int w = p->width, S = p->seq;
+    const long long ld = (long long)S * w;
+    int rc;
+    if ((rc = keds_attention_ex(t.qkv, t.att, B, S, p->heads, p->causal, 1, st))) return rc;
+    if ((rc = keds_gemm_bt_ex(t.att, ld, k.out_w, k.out_b, x, ld, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
+    if ((rc = keds_layernorm_impl(x, w, nullptr, S, k.ln2_g, k.ln2_b, t.h, 0, B, w, st))) return rc;
+    if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, t.hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
+    return keds_gemm_bt_ex(t.hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st);
+}
+
+bool bf16_rows_split(int M, int w) {
+    return keds_gemm_splits_rows(M, 3 * w, w) && keds_gemm_splits_rows(M, w, w) && keds_gemm_splits_rows(M, 4 * w, w) &&
+           keds_gemm_splits_rows(M, w, 4 * w);
+}
+
 // BASELINE config 5: the four GEMMs of every block on MXFP8 operands (gemm_fp8.hip).  The residual stream stays fp32;
 // its MXFP8 copy (xq, xs), the attention output (aq) and the MLP hidden (hq) are e4m3 + one e8m0 scale per 32 columns,
-// produced by the GEMM epilogues themselves (the attention output by one quantisation pass).  Rows beyond the last full
-// 256-row tile (128 of 32,896 at B = 128) keep the bf16 path: every producer below has a bf16 twin for those rows.
+// produced by the GEMM epilogues themselves (the attention output by the attention kernel).  Rows beyond the last full
+// 256-row tile (128 of 32,896 at B = 128) keep the bf16 path, on the side lane: every producer has a bf16 twin for them.
 int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs& t, int Mm, hipStream_t st) {
     const int w = p->width, S = p->seq;
     const int M = B * S, Mt = M - Mm;
-    const size_t Mp = pad_rows((size_t)M);
-    bf16_t* h = (bf16_t*)t.h;
-    bf16_t* qkv = (bf16_t*)t.big;
-    bf16_t* att = qkv + Mp * (size_t)w * 3;
-    bf16_t* hid = qkv;
-    float* st1t = (float*)((keds_stat_t*)t.st1 + 2 * (size_t)Mm);      // statistics rows are two 64-bit words
-    float* st2t = (float*)((keds_stat_t*)t.st2 + 2 * (size_t)Mm);
+    RowLanes lanes;
     int rc;
-    if ((rc = keds_rowstats_cast(x, h, t.st1, M, w, st))) return rc;
+    if ((rc = lanes.init(st, Mt > 0))) return rc;
+    const RowSpan rem{(size_t)Mm, Mt, lanes.side};
+    if ((rc = keds_rowstats_cast(x, t.h, (float*)t.st1, M, w, st))) return rc;
     if ((rc = keds_quantize_mxfp8(x, 0, Mm, w, Mm, t.xq, t.xs, st))) return rc;
+    if ((rc = lanes.to_side())) return rc;
     for (int l = 0; l < p->layers; ++l) {
         const keds_block_params& k = p->blocks[l];
         const bool last = l == p->layers - 1;
-        if ((rc = keds_gemm_mxfp8_ex(t.xq, t.xs, Mm, k.qkv_q8, k.qkv_s8, 3 * w, k.qkv_bc8, qkv, Mm, 3 * w, w,
-                                     KEDS_FP8_EPI_LN_BIAS_BF16, t.st1, t.st2, nullptr, nullptr, 0, st)))
+        if ((rc = keds_gemm_mxfp8_ex(t.xq, t.xs, Mm, k.qkv_q8, k.qkv_s8, 3 * w, k.qkv_bc8, t.qkv, Mm, 3 * w, w,
+                                     KEDS_FP8_EPI_LN_BIAS_BF16, (float*)t.st1, (float*)t.st2, nullptr, nullptr, 0, st)))
             return rc;
-        if (Mt && (rc = keds_gemm_bt_ex2(h + (size_t)Mm * w, w, k.qkv_wf, k.qkv_bc, qkv + (size_t)Mm * 3 * w, 3 * w, Mt, 3 * w, w,
-                                         KEDS_EPI_LN_BIAS_BF16, st1t, 0, st2t, st)))
-            return rc;
-        if (last && p->last_cls_only) {           // CLS rows only (see tower_forward): a handful of rows, bf16 kernels
-            const long long ld = (long long)S * w;
-            if ((rc = keds_attention_ex(qkv, att, B, S, p->heads, p->causal, 1, st))) return rc;
-            if ((rc = keds_gemm_bt_ex(att, ld, k.out_w, k.out_b, x, ld, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
-                return rc;
-            if ((rc = keds_layernorm_impl(x, w, nullptr, S, k.ln2_g, k.ln2_b, h, 0, B, w, st))) return rc;
-            if ((rc = keds_gemm_bt(h, k.fc_w, k.fc_b, hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
-            return keds_gemm_bt_ex(hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st);
-        }
+        if (Mt && (rc = qkv_rows(t, k, w, rem))) return rc;
+        if ((rc = lanes.to_main())) return rc;
+        if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, B, st);
         // attention writes its output as MXFP8 for the full-tile rows and as bf16 for the remainder rows
-        if ((rc = keds_attention_mx(qkv, att, B, S, p->heads, p->causal, S, t.aq, t.as, Mm, st))) return rc;
+        if ((rc = keds_attention_mx(t.qkv, t.att, B, S, p->heads, p->causal, S, t.aq, t.as, Mm, st))) return rc;
+        if ((rc = lanes.to_side())) return rc;
         if ((rc = keds_gemm_mxfp8_ex(t.aq, t.as, Mm, k.out_q8, k.out_s8, w, k.out_b, x, Mm, w, w, KEDS_FP8_EPI_RESID_STATS_MX,
-                                     t.st2, nullptr, t.xq, t.xs, Mm, st)))
+                                     (float*)t.st2, nullptr, t.xq, t.xs, Mm, st)))
             return rc;
-        if (Mt && (rc = keds_gemm_bt_ex2(att + (size_t)Mm * w, w, k.out_w, k.out_b, x + (size_t)Mm * w, w, Mt, w, w,
-                                         KEDS_EPI_RESID_STATS_F32, st2t, 0, h + (size_t)Mm * w, st)))
-            return rc;
+        if (Mt && (rc = out_rows(t, k, x, w, rem))) return rc;
         if ((rc = keds_gemm_mxfp8_ex(t.xq, t.xs, Mm, k.fc_q8, k.fc_s8, 4 * w, k.fc_bc8, nullptr, Mm, 4 * w, w,
-                                     KEDS_FP8_EPI_LN_QGELU_MX, t.st2, t.st1, t.hq, t.hs, Mm, st)))
+                                     KEDS_FP8_EPI_LN_QGELU_MX, (float*)t.st2, (float*)t.st1, t.hq, t.hs, Mm, st)))
             return rc;
-        if (Mt && (rc = keds_gemm_bt_ex2(h + (size_t)Mm * w, w, k.fc_wf, k.fc_bc, hid + (size_t)Mm * 4 * w, 4 * w, Mt, 4 * w, w,
-                                         KEDS_EPI_LN_QGELU_BF16, st2t, 0, st1t, st)))
-            return rc;
+        if (Mt && (rc = fc_rows(t, k, w, rem))) return rc;
         if ((rc = keds_gemm_mxfp8_ex(t.hq, t.hs, Mm, k.proj_q8, k.proj_s8, w, k.proj_b, x, Mm, w, 4 * w,
-                                     KEDS_FP8_EPI_RESID_STATS_MX, t.st1, nullptr, t.xq, t.xs, Mm, st)))
+                                     KEDS_FP8_EPI_RESID_STATS_MX, (float*)t.st1, nullptr, t.xq, t.xs, Mm, st)))
             return rc;
-        if (Mt && (rc = keds_gemm_bt_ex2(hid + (size_t)Mm * 4 * w, 4 * w, k.proj_w, k.proj_b, x + (size_t)Mm * w, w, Mt, w, 4 * w,
-                                         last ? KEDS_EPI_BIAS_RESID_F32 : KEDS_EPI_RESID_STATS_F32, last ? nullptr : st1t, 0,
-                                         last ? nullptr : (void*)(h + (size_t)Mm * w), st)))
-            return rc;
+        if (Mt && (rc = proj_rows(t, k, x, w, last, rem))) return rc;
     }
-    return KEDS_OK;
+    return lanes.to_main();
 }
 
 int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st) {
     const int w = p->width, S = p->seq;
     const int M = B * S;
-    const size_t Mp = pad_rows((size_t)M);
     TowerWs t = carve_tower(ws, w, S, B);
-    void* qkv = t.big;                         // [Mp, 3w]
-    void* att = t.big + Mp * (size_t)w * 3 * 2;  // [Mp, w]
-    void* hid = t.big;                         // [Mp, 4w] (aliases qkv|att, both dead by then)
     int rc;
     // LayerNorm folded into the GEMMs (keds_hip.h, KEDS_EPI_LN_*): t.h holds the bf16 copy of the residual stream,
     // st1 / st2 the {sum, sum sq} of its rows as seen by ln_1 / ln_2.  Each LN-consuming GEMM also clears the
@@ -141,53 +196,46 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
     }
     const bool fp8 = p->fp8 && Mm > 0;             // fewer than 256 rows: everything is "remainder rows" (bf16 kernels)
     if (fp8) return tower_forward_fp8(p, x, B, t, Mm, st);
-    if (folded && (rc = keds_rowstats_cast(x, t.h, t.st1, M, w, st))) return rc;
+    if (folded) {
+        // When every GEMM of the block would split into full 256-row tiles + a remainder launch anyway, the remainder
+        // rows become their own chain on the side lane; otherwise one span covers all rows.
+        const bool two = bf16_rows_split(M, w);
+        RowLanes lanes;
+        if ((rc = lanes.init(st, two))) return rc;
+        const RowSpan body{0, lanes.split ? Mm : M, st};
+        const RowSpan rem{(size_t)Mm, lanes.split ? M - Mm : 0, lanes.side};
+        if ((rc = keds_rowstats_cast(x, t.h, (float*)t.st1, M, w, st))) return rc;
+        if ((rc = lanes.to_side())) return rc;
+        for (int l = 0; l < p->layers; ++l) {
+            const keds_block_params& k = p->blocks[l];
+            const bool last = l == p->layers - 1;
+            if ((rc = qkv_rows(t, k, w, body))) return rc;
+            if (rem.n && (rc = qkv_rows(t, k, w, rem))) return rc;
+            if ((rc = lanes.to_main())) return rc;
+            if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, B, st);
+            if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
+            if ((rc = lanes.to_side())) return rc;
+            if ((rc = out_rows(t, k, x, w, body))) return rc;
+            if (rem.n && (rc = out_rows(t, k, x, w, rem))) return rc;
+            if ((rc = fc_rows(t, k, w, body))) return rc;
+            if (rem.n && (rc = fc_rows(t, k, w, rem))) return rc;
+            if ((rc = proj_rows(t, k, x, w, last, body))) return rc;
+            if (rem.n && (rc = proj_rows(t, k, x, w, last, rem))) return rc;
+        }
+        return lanes.to_main();
+    }
+    // KEDS_DETERMINISTIC / unfolded weights: stand-alone LayerNorm launches, plain bias epilogues
     for (int l = 0; l < p->layers; ++l) {
         const keds_block_params& k = p->blocks[l];
         const bool last = l == p->layers - 1;
-        if (folded) {
-            if ((rc = keds_gemm_bt_ex2(t.h, w, k.qkv_wf, k.qkv_bc, qkv, 3 * w, M, 3 * w, w, KEDS_EPI_LN_BIAS_BF16, t.st1, 0,
-                                       t.st2, st)))
-                return rc;
-        } else {
-            if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
-            if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
-        }
-        if (last && p->last_cls_only) {
-            // After the last block only token 0 of every sample is read (ln_post(x[:,0,:]), model.py:412), so the
-            // attention queries, out-proj, ln_2 and the MLP run on those B rows only (row stride S*w in x / attn).
-            const long long ld = (long long)S * w;
-            if ((rc = keds_attention_ex(qkv, att, B, S, p->heads, p->causal, 1, st))) return rc;
-            if ((rc = keds_gemm_bt_ex(att, ld, k.out_w, k.out_b, x, ld, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
-                return rc;
-            if ((rc = keds_layernorm_impl(x, w, nullptr, S, k.ln2_g, k.ln2_b, t.h, 0, B, w, st))) return rc;
-            if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st)))
-                return rc;
-            if ((rc = keds_gemm_bt_ex(hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr,
-                                      0, st)))
-                return rc;
-            break;
-        }
-        if ((rc = keds_attention(qkv, att, B, S, p->heads, p->causal, st))) return rc;
-        if (folded) {
-            if ((rc = keds_gemm_bt_ex2(att, w, k.out_w, k.out_b, x, w, M, w, w, KEDS_EPI_RESID_STATS_F32, t.st2, 0, t.h, st)))
-                return rc;
-            if ((rc = keds_gemm_bt_ex2(t.h, w, k.fc_wf, k.fc_bc, hid, 4 * w, M, 4 * w, w, KEDS_EPI_LN_QGELU_BF16, t.st2, 0,
-                                       t.st1, st)))
-                return rc;
-            // the last block's output feeds no further ln_1: plain residual update
-            if ((rc = keds_gemm_bt_ex2(hid, 4 * w, k.proj_w, k.proj_b, x, w, M, w, 4 * w,
-                                       last ? KEDS_EPI_BIAS_RESID_F32 : KEDS_EPI_RESID_STATS_F32, last ? nullptr : t.st1, 0,
-                                       last ? nullptr : t.h, st)))
-                return rc;
-        } else {
-            if ((rc = keds_gemm_bt(att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
-            if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;
-            if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, hid, M, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st)))
-                return rc;
-            if ((rc = keds_gemm_bt(hid, k.proj_w, k.proj_b, x, M, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st)))
-                return rc;
-        }
+        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
+        if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, t.qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
+        if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, B, st);
+        if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
+        if ((rc = keds_gemm_bt(t.att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
+        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;
+        if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, t.hid, M, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
+        if ((rc = keds_gemm_bt(t.hid, k.proj_w, k.proj_b, x, M, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
     }
     return KEDS_OK;
 }
@@ -212,6 +260,13 @@ int check_tower(const keds_tower_params* p, const char* who) {
 
 extern "C" size_t keds_tower_workspace_bytes(int width, int seq, int B) {
     return carve_tower(nullptr, width, seq, B).bytes;
+}
+
+extern "C" int keds_tower_side_rows(int width, int seq, int B, int fp8) {
+    if (width <= 0 || seq <= 0 || B <= 0) return 0;
+    const int M = B * seq, Mt = M % 256;
+    const bool split = fp8 ? (M >= 256 && Mt > 0) : bf16_rows_split(M, width);
+    return split && keds_side_lane_enabled() ? Mt : 0;    // only a query: no stream is created here (no GPU needed)
 }
 
 extern "C" int keds_tower_forward(const keds_tower_params* p, float* x, int B, void* workspace, size_t workspace_bytes,

@@ -184,6 +184,32 @@ def test_vitl14_full_size_against_reference_golden():
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize("precision", ["bf16", "fp8"])
+def test_side_lane_for_remainder_rows_changes_no_bit(precision):
+    """At B = 128 the ViT-L/14 tower has 128 full 256-row tiles + 128 remainder rows; the remainder chain runs on a second
+    stream beside the full tiles (towers.hip, RowLanes).  Same kernels on the same rows: the embeddings must be the very
+    same bits with the lane on and off, run after run (a missing fork / join would show up here as a race)."""
+    from keds_amd import _lib
+    lib = _lib.load()
+    sd = O.synth_clip_state_dict(**VITL, seed=7)
+    m = keds_amd.build_model(sd, fp16=False).cuda()
+    m.set_precision(precision)
+    del sd
+    img = torch.from_numpy(O.synth_tensor("imgs", [128, 3, 224, 224], 1.0).numpy()).cuda()
+    try:
+        lib.keds_side_lane_enable(1)
+        assert lib.keds_tower_side_rows(1024, 257, 128, int(precision == "fp8")) == 128
+        on = [m.encode_image(img).clone() for _ in range(3)]
+        lib.keds_side_lane_enable(0)
+        assert lib.keds_tower_side_rows(1024, 257, 128, int(precision == "fp8")) == 0
+        off = m.encode_image(img).clone()
+    finally:
+        lib.keds_side_lane_enable(1)
+    assert torch.isfinite(off).all()
+    for o in on:
+        assert torch.equal(o, off)
+
+
 def test_recall_equal_to_cpu_reference():
     """Recall@1/5/10 of a synthetic retrieval problem: GPU features vs oracle features, same ranking metric.
     Queries are encoded images; the gallery holds the oracle's embeddings of the same images plus

@@ -58,8 +58,11 @@ def test_size_queries_need_no_gpu():
     assert lib.keds_index_packed_bytes(33, 128) == 2 * (32 * 128 * 2 + 128)
     assert lib.keds_index_packed_bytes(10, 100) == 0               # unsupported dim
     assert lib.keds_index_search_workspace_bytes(128, 768) > 16 * 1024 * 1024
-    assert lib.keds_tower_workspace_bytes(1024, 257, 128) == (32896 * 1024 * 2 + 32896 * 4096 * 2 + 2 * 32896 * 16
+    assert lib.keds_tower_workspace_bytes(1024, 257, 128) == (32896 * 1024 * 2 + 2 * 32896 * 4096 * 2 + 2 * 32896 * 16
                                                               + 6 * (32768 * 1024 + 32768 * 32))       # + MXFP8 operands
+    # remainder rows of a tower pass run beside the full tiles (side lane): 128 of 32,896 at B = 128, none for a text tower
+    assert lib.keds_tower_side_rows(1024, 257, 128, 0) in (0, 128)      # 0 with KEDS_SIDE_STREAM=0
+    assert lib.keds_tower_side_rows(768, 77, 128, 0) == 0
 
 
 def test_argument_errors_are_reported():
