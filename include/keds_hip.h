@@ -138,6 +138,11 @@ int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery
 #define KEDS_EPI_LN_QGELU_BF16 7    /* same, then QuickGELU */
 #define KEDS_EPI_RESID_STATS_F32 8  /* out f32 += acc + bias (in place); aux2 = bf16 copy [M,N] of the new rows;
                                        aux = statistics [M,2] (64-bit fixed point) += {sum, sum sq} of the new rows (zeroed before) */
+#define KEDS_EPI_RESID_STATS_F16 9  /* out f16 += acc + bias (in place, fp32 sum rounded once): the residual stream kept in
+                                       the reference's own storage type (convert_weights, model.py:531-548), one copy that is
+                                       also the next GEMM's operand; aux = statistics as above (of the fp32 sums) or NULL */
+#define KEDS_EPI_LN_BIAS_BF16_H 10  /* KEDS_EPI_LN_BIAS_BF16 with fp16 operands: A = the fp16 residual stream, W' fp16 */
+#define KEDS_EPI_LN_QGELU_BF16_H 11 /* KEDS_EPI_LN_QGELU_BF16 with fp16 operands */
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W bf16 row-major (W is the nn.Linear
  * weight as stored).  N % 128 == 0, K % 64 == 0; rows of A / out up to the next multiple of
@@ -158,10 +163,14 @@ int keds_gemm_bt_ex2(const void* A, int64_t lda, const void* W, const float* bia
  * w_folded bf16 [N,K] = W diag(gamma), bias_csum fp32 [2N] = [bias + W beta | row sums of w_folded (as rounded)]. */
 int keds_fold_layernorm(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                         void* w_folded, float* bias_csum, void* stream);
+/* out_f16 != 0: w_folded in fp16 (operand of the KEDS_EPI_LN_*_H GEMMs, which read the fp16 residual stream) */
+int keds_fold_layernorm_ex(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                           void* w_folded, int out_f16, float* bias_csum, void* stream);
 
 /* Row statistics + bf16 copy of a residual stream (what KEDS_EPI_RESID_STATS_F32 emits, for the first block):
  * x fp32 [rows, dim] dense -> xb bf16 [rows, dim], stats [rows,2] = {sum, sum of squares} as 64-bit fixed point (* 2^28). */
 int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim, void* stream);
+int keds_rowstats_cast_ex(const float* x, void* xb, int out_f16, float* stats, int rows, int dim, void* stream);  /* xb fp16 */
 
 /* ---- MXFP8 (BASELINE config 5: fp8 encoders).  OCP e4m3 elements, one e8m0 scale per 32 consecutive K (OCP MX),
  * multiplied by v_mfma_scale_f32_16x16x128_f8f6f4 (block scales applied in hardware, 2x the bf16 MFMA rate).
@@ -183,6 +192,7 @@ int keds_gemm_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, c
 #define KEDS_FP8_EPI_LN_BIAS_BF16 1
 #define KEDS_FP8_EPI_LN_QGELU_MX 2
 #define KEDS_FP8_EPI_RESID_STATS_MX 3
+#define KEDS_FP8_EPI_RESID_STATS_MX_H 4   /* the same on an fp16 residual stream: out fp16 += acc + bias */
 int keds_gemm_mxfp8_ex(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad,
                        const float* bias, void* out, int M, int N, int K, int epilogue, float* aux, float* aux2,
                        void* qout, void* qscale, int q_pad, void* stream);
@@ -257,10 +267,10 @@ typedef struct {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;     /* fp32 [d] */
     const void *qkv_w, *out_w, *fc_w, *proj_w;      /* bf16 [3d,d] [d,d] [4d,d] [d,4d] */
     const float *qkv_b, *out_b, *fc_b, *proj_b;     /* fp32 */
-    /* optional (all four or none): ln_1 folded into in_proj and ln_2 into c_fc by keds_fold_layernorm.  When present
-     * the tower runs without LayerNorm passes (KEDS_EPI_LN_* / KEDS_EPI_RESID_STATS_F32); qkv_w / fc_w and the ln
-     * parameters are still needed (CLS-only last block). */
-    const void *qkv_wf, *fc_wf;                     /* bf16 [3d,d], [4d,d] */
+    /* optional (all four or none): ln_1 folded into in_proj and ln_2 into c_fc by keds_fold_layernorm_ex(out_f16 = 1).
+     * When present the tower runs without LayerNorm passes on an fp16 residual stream (KEDS_EPI_LN_*_H /
+     * KEDS_EPI_RESID_STATS_F16); qkv_w / fc_w and the ln parameters are still needed (CLS-only last block). */
+    const void *qkv_wf, *fc_wf;                     /* fp16 [3d,d], [4d,d] */
     const float *qkv_bc, *fc_bc;                    /* fp32 [2*3d], [2*4d]: folded bias | column sums */
     /* optional (all or none; needs the folded set above): MXFP8 copies for keds_tower_params.fp8
      * (keds_fold_layernorm_mxfp8: in_proj / c_fc with their LayerNorm folded in, out_proj / c_proj plain);

@@ -20,8 +20,9 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 ABI_VERSION = 3
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
-EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32 = 6, 7, 8
-FP8_EPI_BIAS_BF16, FP8_EPI_LN_BIAS_BF16, FP8_EPI_LN_QGELU_MX, FP8_EPI_RESID_STATS_MX = range(4)
+EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
+EPI_LN_BIAS_BF16_H, EPI_LN_QGELU_BF16_H = 10, 11
+FP8_EPI_BIAS_BF16, FP8_EPI_LN_BIAS_BF16, FP8_EPI_LN_QGELU_MX, FP8_EPI_RESID_STATS_MX, FP8_EPI_RESID_STATS_MX_H = range(5)
 PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
 SCAN_MAX_K = 16
 
@@ -126,6 +127,8 @@ SIGNATURES = {
     "keds_gemm_bt_ex2": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp]),
     "keds_fold_layernorm": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "keds_rowstats_cast": (i32, [vp, vp, vp, i32, i32, vp]),
+    "keds_rowstats_cast_ex": (i32, [vp, vp, i32, vp, i32, i32, vp]),
+    "keds_fold_layernorm_ex": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, vp, vp]),
     "keds_mxfp8_scale_bytes": (sz, [i32, i32]),
     "keds_mxfp8_debug": (i32, [i32]),
     "keds_quantize_mxfp8": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),

@@ -73,7 +73,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 
 // one wave per row: bf16 copy + {sum, sum of squares} of a residual-stream row (what the RESID_STATS GEMM epilogue
 // emits for every later block; this kernel provides them for the first one)
-__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, bf16_t* __restrict__ xb,
+template <typename T>   // bf16_t, or f16_t for the fp16 residual stream
+__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, T* __restrict__ xb,
                                                             float* __restrict__ stats, int rows, int dim) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -91,9 +92,10 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
         const int i = j * 256 + lane * 4;
         s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
         q += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
-        if (i < dim)
-            *reinterpret_cast<bf16x4*>(xb + (size_t)r * dim + i) =
-                bf16x4{(bf16_t)v[j][0], (bf16_t)v[j][1], (bf16_t)v[j][2], (bf16_t)v[j][3]};
+        if (i < dim) {
+            typedef __attribute__((ext_vector_type(4))) T tx4;
+            *reinterpret_cast<tx4*>(xb + (size_t)r * dim + i) = tx4{(T)v[j][0], (T)v[j][1], (T)v[j][2], (T)v[j][3]};
+        }
     }
     s = wave_sum(s);
     q = wave_sum(q);
@@ -106,17 +108,18 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
 
 // one wave per output row n of W [N,K]: w_folded = bf16(W * gamma), csum = sum of the ROUNDED products (what the MFMA
 // will multiply the row mean with), bias' = bias + W . beta in fp32
+template <typename T>
 __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __restrict__ W, const float* __restrict__ bias,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, int N, int K,
-                                                             bf16_t* __restrict__ wf, float* __restrict__ bias_csum) {
+                                                             T* __restrict__ wf, float* __restrict__ bias_csum) {
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (n >= N) return;
     float cs = 0.f, bb = 0.f;
     for (int k = lane; k < K; k += 64) {
         const float w = W[(size_t)n * K + k];
-        const bf16_t f = (bf16_t)(w * gamma[k]);
+        const T f = (T)(w * gamma[k]);
         wf[(size_t)n * K + k] = f;
         cs += (float)f;
         bb += w * beta[k];
@@ -127,6 +130,19 @@ __global__ __launch_bounds__(256) void fold_layernorm_kernel(const float* __rest
         bias_csum[n] = (bias ? bias[n] : 0.f) + bb;
         bias_csum[N + n] = cs;
     }
+}
+
+// rows of the fp16 residual stream back to fp32 (row r at r * stride elements in both): one thread per 8 elements
+__global__ __launch_bounds__(256) void cast_rows_f16_f32_kernel(const f16_t* __restrict__ x16, float* __restrict__ x32,
+                                                                int rows, int dim, long long stride) {
+    const int per_row = dim >> 3;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (long long)rows * per_row) return;
+    const int r = (int)(id / per_row), i = (int)(id - (long long)r * per_row) << 3;
+    const f16x8 v = *reinterpret_cast<const f16x8*>(x16 + (size_t)r * stride + i);
+    float* o = x32 + (size_t)r * stride + i;
+    *reinterpret_cast<f32x4*>(o) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
 }
 
 // ---- image preprocessing (src/model/clip.py:107-123 `_transform`, eval branch) on raw uint8 images ------------------
@@ -417,21 +433,45 @@ extern "C" int keds_cast_bf16(const float* x, void* out, int64_t count, void* st
     return keds_check_launch("cast_bf16_kernel");
 }
 
-extern "C" int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim, void* stream) {
+extern "C" int keds_rowstats_cast_ex(const float* x, void* xb, int out_f16, float* stats, int rows, int dim, void* stream) {
     KEDS_REQUIRE(x && xb && stats && rows > 0, "keds_rowstats_cast: bad argument");
     KEDS_REQUIRE(dim % 4 == 0 && dim >= 4 && dim <= 256 * LN_MAXV, "keds_rowstats_cast: dim %d unsupported", dim);
     hipStream_t st = (hipStream_t)stream;
     KedsProfScope prof(KEDS_PROF_LN, st);
-    rowstats_cast_kernel<<<(rows + 3) / 4, 256, 0, st>>>(x, (bf16_t*)xb, stats, rows, dim);
+    if (out_f16)
+        rowstats_cast_kernel<f16_t><<<(rows + 3) / 4, 256, 0, st>>>(x, (f16_t*)xb, stats, rows, dim);
+    else
+        rowstats_cast_kernel<bf16_t><<<(rows + 3) / 4, 256, 0, st>>>(x, (bf16_t*)xb, stats, rows, dim);
     return keds_check_launch("rowstats_cast_kernel");
+}
+
+extern "C" int keds_rowstats_cast(const float* x, void* xb, float* stats, int rows, int dim, void* stream) {
+    return keds_rowstats_cast_ex(x, xb, 0, stats, rows, dim, stream);
+}
+
+int keds_cast_rows_f16_f32_impl(const void* x16, float* x32, int rows, int dim, long long stride, hipStream_t st) {
+    KEDS_REQUIRE(x16 && x32 && rows > 0 && dim % 8 == 0 && stride >= dim, "cast_rows_f16_f32: bad argument");
+    KedsProfScope prof(KEDS_PROF_OTHER, st);
+    const long long threads = (long long)rows * (dim / 8);
+    cast_rows_f16_f32_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const f16_t*)x16, x32, rows, dim, stride);
+    return keds_check_launch("cast_rows_f16_f32_kernel");
+}
+
+extern "C" int keds_fold_layernorm_ex(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
+                                      void* w_folded, int out_f16, float* bias_csum, void* stream) {
+    KEDS_REQUIRE(W && gamma && beta && w_folded && bias_csum && N > 0 && K > 0, "keds_fold_layernorm: bad argument");
+    if (out_f16)
+        fold_layernorm_kernel<f16_t><<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(W, bias, gamma, beta, N, K, (f16_t*)w_folded,
+                                                                                   bias_csum);
+    else
+        fold_layernorm_kernel<bf16_t><<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(W, bias, gamma, beta, N, K,
+                                                                                    (bf16_t*)w_folded, bias_csum);
+    return keds_check_launch("fold_layernorm_kernel");
 }
 
 extern "C" int keds_fold_layernorm(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                                    void* w_folded, float* bias_csum, void* stream) {
-    KEDS_REQUIRE(W && gamma && beta && w_folded && bias_csum && N > 0 && K > 0, "keds_fold_layernorm: bad argument");
-    fold_layernorm_kernel<<<(N + 3) / 4, 256, 0, (hipStream_t)stream>>>(W, bias, gamma, beta, N, K, (bf16_t*)w_folded,
-                                                                        bias_csum);
-    return keds_check_launch("fold_layernorm_kernel");
+    return keds_fold_layernorm_ex(W, bias, gamma, beta, N, K, w_folded, 0, bias_csum, stream);
 }
 
 extern "C" int keds_preprocess(const unsigned char* images, int B, int H, int W, int n_px, const float* mean3,

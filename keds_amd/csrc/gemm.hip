@@ -76,9 +76,21 @@ __device__ __forceinline__ void epilogue_store(f32x4 v0, f32x4 v1, void* __restr
     }
 }
 
-constexpr bool epi_is_ln(int e) { return e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_QGELU_BF16; }
+// KEDS_EPI_LN_*_H: the same epilogues with fp16 operands (A = the fp16 residual stream, W' folded to fp16)
+constexpr bool epi_f16(int e) { return e == KEDS_EPI_LN_BIAS_BF16_H || e == KEDS_EPI_LN_QGELU_BF16_H; }
+constexpr bool epi_is_ln(int e) { return e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_QGELU_BF16 || epi_f16(e); }
 constexpr int epi_base(int e) {
-    return e == KEDS_EPI_LN_BIAS_BF16 ? KEDS_EPI_BIAS_BF16 : e == KEDS_EPI_LN_QGELU_BF16 ? KEDS_EPI_BIAS_QGELU_BF16 : e;
+    return (e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_BIAS_BF16_H)     ? KEDS_EPI_BIAS_BF16
+           : (e == KEDS_EPI_LN_QGELU_BF16 || e == KEDS_EPI_LN_QGELU_BF16_H) ? KEDS_EPI_BIAS_QGELU_BF16
+                                                                            : e;
+}
+// one 16x16x32 MFMA on fragments staged as raw 16-byte chunks: bf16 or fp16 operands, fp32 accumulate (same rate)
+template <bool F16>
+__device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
 constexpr float LN_EPS = 1e-5f;
 
@@ -163,6 +175,41 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
             s = rows_sum(s);
             ss = rows_sum(ss);
             if (valid && zero_lane) keds_stat_add(stats + 2 * (size_t)m, s, ss);
+        }
+    } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        // the residual stream kept in fp16 (the reference's own storage type, model.py:531-548 convert_weights): one
+        // copy is both the residual and the next GEMM's operand, 4 B per element of traffic instead of 10
+        keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
+        f32x4 b[2][2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            b[p][0] = b[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (bias) {
+                b[p][0] = *reinterpret_cast<const f32x4*>(bias + n_lane + 32 * p);
+                b[p][1] = *reinterpret_cast<const f32x4*>(bias + n_lane + 32 * p + 4);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m_lane + 16 * mi;
+            const bool valid = m < M;
+            float s = 0.f, ss = 0.f;
+            if (valid) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    f16x8* o = reinterpret_cast<f16x8*>(reinterpret_cast<f16_t*>(out) + (size_t)m * ldc + n_lane + 32 * p);
+                    const f16x8 r = *o;
+                    const f32x4 v0 = f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]} + (acc[2 * p][mi] + b[p][0]);
+                    const f32x4 v1 = f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]} + (acc[2 * p + 1][mi] + b[p][1]);
+                    *o = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3],
+                               (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+                    s += sum8(v0, v1);
+                    ss += sum8(v0 * v0, v1 * v1);
+                }
+            }
+            s = rows_sum(s);
+            ss = rows_sum(ss);
+            if (valid && zero_lane && stats) keds_stat_add(stats + 2 * (size_t)m, s, ss);
         }
     } else {
 #pragma unroll
@@ -286,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     {                                                                                                          \
         _Pragma("unroll") for (int mi = 0; mi < 4; ++mi) {                                                     \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);   \
+                acc[ni][mi] = mma<epi_f16(EPI)>(wc[ni], xc[mi], acc[ni][mi]);   \
             if (PREFETCH) {                                                                                    \
                 xn[mi] = *reinterpret_cast<const bf16x8*>((nb) + xoff[kkn] + mi * 2048);                       \
                 wn_[mi] = *reinterpret_cast<const bf16x8*>((nb) + woff[kkn] + mi * 2048);                      \
@@ -346,6 +393,25 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     tile_epilogue<EPI, 4>(acc, bias, out, m0 + 64 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, ldc, zl);
 }
 
+// split-K reduce: add this thread's partial {sum, sum sq} of a row to its statistics.  Lanes that are known to sit in
+// one row (per_row % 64 == 0: the wave, % 32: its halves) add once; per-thread atomics on one address serialise
+// (measured 56 us for 128 x 1024 outputs).  Every lane of the wave must call this.
+__device__ __forceinline__ void row_stats_add(keds_stat_t* row, float s, float ss, int per_row) {
+    const int seg = (per_row & 63) == 0 ? 64 : (per_row & 31) == 0 ? 32 : 1;
+    if (seg > 1) {
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+            s += __shfl_xor(s, o, 64);
+            ss += __shfl_xor(ss, o, 64);
+        }
+        if (seg == 64) {
+            s += __shfl_xor(s, 32, 64);
+            ss += __shfl_xor(ss, 32, 64);
+        }
+    }
+    if ((threadIdx.x & (seg - 1)) == 0) keds_stat_add(row, s, ss);
+}
+
 // sum the split-K slices, add bias, apply the epilogue; one thread per 8 consecutive outputs of one row
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
@@ -383,23 +449,16 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(aux2) + (size_t)m * N + n) =
             bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
                    (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+        row_stats_add(reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)) + 2 * (size_t)m, sum8(v0, v1),
+                      sum8(v0 * v0, v1 * v1), per_row);
+    } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        f16x8* o = reinterpret_cast<f16x8*>(reinterpret_cast<f16_t*>(out) + (size_t)m * ldc + n);
+        const f16x8 r = *o;
+        v0 += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]} + b0;
+        v1 += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]} + b1;
+        *o = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
         keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
-        float s = sum8(v0, v1), ss = sum8(v0 * v0, v1 * v1);
-        // lanes that are known to sit in one row (N % 512 == 0: the wave, N % 256 == 0: its halves) add once;
-        // per-thread atomics on one address serialise (measured 56 us for 128 x 1024 outputs)
-        const int seg = (per_row & 63) == 0 ? 64 : (per_row & 31) == 0 ? 32 : 1;   // lanes known to share the row
-        if (seg > 1) {
-#pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                s += __shfl_xor(s, o, 64);
-                ss += __shfl_xor(ss, o, 64);
-            }
-            if (seg == 64) {
-                s += __shfl_xor(s, 32, 64);
-                ss += __shfl_xor(ss, 32, 64);
-            }
-        }
-        if ((threadIdx.x & (seg - 1)) == 0) keds_stat_add(stats + 2 * (size_t)m, s, ss);
+        if (stats) row_stats_add(stats + 2 * (size_t)m, sum8(v0, v1), sum8(v0 * v0, v1 * v1), per_row);
     } else {
         epilogue_store<EPI>(v0 + b0, v1 + b1, out, m, n, N, aux, aux_i, ldc);
     }
@@ -565,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) {                                                     \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
-                acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[ni], xc[mi], acc[ni][mi], 0, 0, 0);   \
+                acc[ni][mi] = mma<epi_f16(EPI)>(wc[ni], xc[mi], acc[ni][mi]);   \
             if constexpr (PREFETCH) {                                                                          \
                 if (mi == 0) {                                                                                 \
                     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                           \
@@ -677,6 +736,8 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F32) {
         aux_t = (const float*)((const keds_stat_t*)aux + 2 * (size_t)m_main);
         aux2_t = (char*)aux2 + (size_t)m_main * N * 2;
+    } else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        if (aux) aux_t = (const float*)((const keds_stat_t*)aux + 2 * (size_t)m_main);
     }
     return launch_small<EPI>((const char*)A + (size_t)m_main * K * 2, W, bias, (char*)out + (size_t)m_main * N * esz,
                              M - m_main, N, K, aux_t, aux_i, aux2_t, lda, ldc, st);
@@ -723,13 +784,20 @@ extern "C" int keds_gemm_bt_ex2(const void* A, int64_t lda, const void* W, const
             return launch_gemm<KEDS_EPI_PATCH_F32>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
         case KEDS_EPI_LN_BIAS_BF16:
         case KEDS_EPI_LN_QGELU_BF16:
+        case KEDS_EPI_LN_BIAS_BF16_H:
+        case KEDS_EPI_LN_QGELU_BF16_H:
             KEDS_REQUIRE(bias && aux, "keds_gemm_bt: EPI_LN_* needs bias = [bias' | colsum] and aux = row statistics");
             if (epilogue == KEDS_EPI_LN_BIAS_BF16)
                 return launch_gemm<KEDS_EPI_LN_BIAS_BF16>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
+            if (epilogue == KEDS_EPI_LN_BIAS_BF16_H)
+                return launch_gemm<KEDS_EPI_LN_BIAS_BF16_H>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
+            if (epilogue == KEDS_EPI_LN_QGELU_BF16_H)
+                return launch_gemm<KEDS_EPI_LN_QGELU_BF16_H>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
             return launch_gemm<KEDS_EPI_LN_QGELU_BF16>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
         case KEDS_EPI_RESID_STATS_F32:
             KEDS_REQUIRE(aux && aux2, "keds_gemm_bt: EPI_RESID_STATS needs aux = statistics and aux2 = bf16 copy");
             return launch_gemm<KEDS_EPI_RESID_STATS_F32>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
+        KEDS_GEMM_CASE(KEDS_EPI_RESID_STATS_F16)
         default: keds_set_error("keds_gemm_bt: unknown epilogue %d", epilogue); return KEDS_E_ARG;
     }
 #undef KEDS_GEMM_CASE

@@ -339,12 +339,21 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
                     v1[j] = v1[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v1[j]));
                 }
             }
-            if constexpr (EPI == 3) {
-                float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
-                v0 += *reinterpret_cast<const f32x4*>(o);
-                v1 += *reinterpret_cast<const f32x4*>(o + 4);
-                *reinterpret_cast<f32x4*>(o) = v0;
-                *reinterpret_cast<f32x4*>(o + 4) = v1;
+            if constexpr (EPI == 3 || EPI == 4) {
+                if constexpr (EPI == 3) {
+                    float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
+                    v0 += *reinterpret_cast<const f32x4*>(o);
+                    v1 += *reinterpret_cast<const f32x4*>(o + 4);
+                    *reinterpret_cast<f32x4*>(o) = v0;
+                    *reinterpret_cast<f32x4*>(o + 4) = v1;
+                } else {                                          // fp16 residual stream (cf. KEDS_EPI_RESID_STATS_F16)
+                    f16x8* o = reinterpret_cast<f16x8*>(reinterpret_cast<f16_t*>(out) + (size_t)m * N + n);
+                    const f16x8 r = *o;
+                    v0 += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                    v1 += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+                    *o = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3],
+                               (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+                }
                 rs[mi] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
                 rss[mi] += ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) +
                            ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
@@ -365,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
             }
         }
     }
-    if constexpr (EPI == 3) {
+    if constexpr (EPI == 3 || EPI == 4) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + 128 * wm + 16 * mi + c;
@@ -450,6 +459,9 @@ extern "C" int keds_gemm_mxfp8_ex(const void* Aq, const void* As, int m_pad, con
         case KEDS_FP8_EPI_RESID_STATS_MX:
             KEDS_REQUIRE(out && aux && qout && qscale && q_pad >= M, "keds_gemm_mxfp8: residual MX epilogue arguments");
             KEDS_FP8_GO(3, 0);
+        case KEDS_FP8_EPI_RESID_STATS_MX_H:
+            KEDS_REQUIRE(out && aux && qout && qscale && q_pad >= M, "keds_gemm_mxfp8: residual MX epilogue arguments");
+            KEDS_FP8_GO(4, 0);
         default: keds_set_error("keds_gemm_mxfp8: unknown epilogue %d", epilogue); return KEDS_E_ARG;
     }
 #undef KEDS_FP8_GO

@@ -215,8 +215,8 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
         float* qb = (float*)L.mem.alloc((size_t)2 * 3 * width * sizeof(float));
         float* fb = (float*)L.mem.alloc((size_t)2 * 4 * width * sizeof(float));
         KEDS_REQUIRE(qf && ff && qb && fb, "%s: out of device memory", L.what);
-        if ((rc = keds_fold_layernorm(wq, p.qkv_b, p.ln1_g, p.ln1_b, 3 * width, width, qf, qb, nullptr)) ||
-            (rc = keds_fold_layernorm(wf, p.fc_b, p.ln2_g, p.ln2_b, 4 * width, width, ff, fb, nullptr)))
+        if ((rc = keds_fold_layernorm_ex(wq, p.qkv_b, p.ln1_g, p.ln1_b, 3 * width, width, qf, 1, qb, nullptr)) ||
+            (rc = keds_fold_layernorm_ex(wf, p.fc_b, p.ln2_g, p.ln2_b, 4 * width, width, ff, 1, fb, nullptr)))
             return rc;
         HIP_TRY(hipDeviceSynchronize(), L.what);
         p.qkv_wf = qf;

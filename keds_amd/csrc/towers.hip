@@ -10,6 +10,7 @@
 int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
 int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int S, int d, hipStream_t st);
+int keds_cast_rows_f16_f32_impl(const void* x16, float* x32, int rows, int dim, long long stride, hipStream_t st);
 
 bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
 
@@ -17,7 +18,8 @@ namespace {
 
 size_t pad_rows(size_t m) { return keds_align_up(m, 128); }
 
-// scratch of one tower: h [Mp,w] bf16 | qkv [Mp,3w] | attn [Mp,w] | MLP hidden [Mp,4w] (all bf16) |
+// scratch of one tower: h [Mp,w] (the fp16 residual stream of the folded flow; the bf16 LayerNorm output of the unfolded
+// one) | qkv [Mp,3w] | attn [Mp,w] | MLP hidden [Mp,4w] (bf16) |
 // two row-statistics buffers [Mp,2] of 64-bit fixed point (LayerNorm folded into the GEMMs: ln_1 / ln_2 statistics).
 // No buffer aliases another: the remainder-row chain runs beside the full-tile chain (see RowLanes) and the two touch
 // disjoint ROWS of every buffer, which only keeps them apart if the buffers themselves are distinct.
@@ -93,33 +95,36 @@ struct RowSpan {
     hipStream_t st;
 };
 
-// the four GEMMs of a block on a span of rows, bf16 operands, LayerNorm folded (keds_hip.h, KEDS_EPI_LN_*)
+// The four GEMMs of a block on a span of rows, LayerNorm folded (keds_hip.h, KEDS_EPI_LN_*).  The residual stream lives
+// in t.h as fp16 (the reference's own storage type after convert_weights, model.py:531-548): one copy that the residual
+// GEMMs update in place (fp32 sum, rounded once) and the LN-folded GEMMs read as their fp16 operand.
 int qkv_rows(const TowerWs& t, const keds_block_params& k, int w, RowSpan s) {
     return keds_gemm_bt_ex2(t.h + s.r0 * w, w, k.qkv_wf, k.qkv_bc, t.qkv + s.r0 * 3 * w, 3 * w, s.n, 3 * w, w,
-                            KEDS_EPI_LN_BIAS_BF16, (const float*)(t.st1 + 2 * s.r0), 0, t.st2 + 2 * s.r0, s.st);
+                            KEDS_EPI_LN_BIAS_BF16_H, (const float*)(t.st1 + 2 * s.r0), 0, t.st2 + 2 * s.r0, s.st);
 }
-int out_rows(const TowerWs& t, const keds_block_params& k, float* x, int w, RowSpan s) {
-    return keds_gemm_bt_ex2(t.att + s.r0 * w, w, k.out_w, k.out_b, x + s.r0 * w, w, s.n, w, w, KEDS_EPI_RESID_STATS_F32,
-                            (const float*)(t.st2 + 2 * s.r0), 0, t.h + s.r0 * w, s.st);
+int out_rows(const TowerWs& t, const keds_block_params& k, int w, RowSpan s) {
+    return keds_gemm_bt_ex2(t.att + s.r0 * w, w, k.out_w, k.out_b, t.h + s.r0 * w, w, s.n, w, w, KEDS_EPI_RESID_STATS_F16,
+                            (const float*)(t.st2 + 2 * s.r0), 0, nullptr, s.st);
 }
 int fc_rows(const TowerWs& t, const keds_block_params& k, int w, RowSpan s) {
     return keds_gemm_bt_ex2(t.h + s.r0 * w, w, k.fc_wf, k.fc_bc, t.hid + s.r0 * 4 * w, 4 * w, s.n, 4 * w, w,
-                            KEDS_EPI_LN_QGELU_BF16, (const float*)(t.st2 + 2 * s.r0), 0, t.st1 + 2 * s.r0, s.st);
+                            KEDS_EPI_LN_QGELU_BF16_H, (const float*)(t.st2 + 2 * s.r0), 0, t.st1 + 2 * s.r0, s.st);
 }
-// the last block's output feeds no further ln_1: plain residual update
-int proj_rows(const TowerWs& t, const keds_block_params& k, float* x, int w, bool last, RowSpan s) {
-    return keds_gemm_bt_ex2(t.hid + s.r0 * 4 * w, 4 * w, k.proj_w, k.proj_b, x + s.r0 * w, w, s.n, w, 4 * w,
-                            last ? KEDS_EPI_BIAS_RESID_F32 : KEDS_EPI_RESID_STATS_F32,
-                            last ? nullptr : (const float*)(t.st1 + 2 * s.r0), 0, last ? nullptr : (void*)(t.h + s.r0 * w),
-                            s.st);
+// (the last block's output feeds no further ln_1: no statistics)
+int proj_rows(const TowerWs& t, const keds_block_params& k, int w, bool last, RowSpan s) {
+    return keds_gemm_bt_ex2(t.hid + s.r0 * 4 * w, 4 * w, k.proj_w, k.proj_b, t.h + s.r0 * w, w, s.n, w, 4 * w,
+                            KEDS_EPI_RESID_STATS_F16, last ? nullptr : (const float*)(t.st1 + 2 * s.r0), 0, nullptr, s.st);
 }
 
 // After the last block only token 0 of every sample is read (ln_post(x[:,0,:]), model.py:412), so the attention
-// queries, out-proj, ln_2 and the MLP run on those B rows only (row stride S*w in x / attn); bf16 kernels.
-int cls_rows_tail(const keds_tower_params* p, const keds_block_params& k, const TowerWs& t, float* x, int B, hipStream_t st) {
+// queries, out-proj, ln_2 and the MLP run on those B rows only (row stride S*w in x / attn); fp32 rows, bf16 kernels.
+// x16: the fp16 residual stream whose CLS rows are brought back to fp32 first (folded flow), or nullptr.
+int cls_rows_tail(const keds_tower_params* p, const keds_block_params& k, const TowerWs& t, float* x, const void* x16, int B,
+                  hipStream_t st) {
     const int w = p->width, S = p->seq;
     const long long ld = (long long)S * w;
     int rc;
+    if (x16 && (rc = keds_cast_rows_f16_f32_impl(x16, x, B, w, ld, st))) return rc;
     if ((rc = keds_attention_ex(t.qkv, t.att, B, S, p->heads, p->causal, 1, st))) return rc;
     if ((rc = keds_gemm_bt_ex(t.att, ld, k.out_w, k.out_b, x, ld, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
     if ((rc = keds_layernorm_impl(x, w, nullptr, S, k.ln2_g, k.ln2_b, t.h, 0, B, w, st))) return rc;
@@ -143,7 +148,7 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
     int rc;
     if ((rc = lanes.init(st, Mt > 0))) return rc;
     const RowSpan rem{(size_t)Mm, Mt, lanes.side};
-    if ((rc = keds_rowstats_cast(x, t.h, (float*)t.st1, M, w, st))) return rc;
+    if ((rc = keds_rowstats_cast_ex(x, t.h, 1, (float*)t.st1, M, w, st))) return rc;
     if ((rc = keds_quantize_mxfp8(x, 0, Mm, w, Mm, t.xq, t.xs, st))) return rc;
     if ((rc = lanes.to_side())) return rc;
     for (int l = 0; l < p->layers; ++l) {
@@ -154,24 +159,25 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
             return rc;
         if (Mt && (rc = qkv_rows(t, k, w, rem))) return rc;
         if ((rc = lanes.to_main())) return rc;
-        if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, B, st);
+        if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, t.h, B, st);
         // attention writes its output as MXFP8 for the full-tile rows and as bf16 for the remainder rows
         if ((rc = keds_attention_mx(t.qkv, t.att, B, S, p->heads, p->causal, S, t.aq, t.as, Mm, st))) return rc;
         if ((rc = lanes.to_side())) return rc;
-        if ((rc = keds_gemm_mxfp8_ex(t.aq, t.as, Mm, k.out_q8, k.out_s8, w, k.out_b, x, Mm, w, w, KEDS_FP8_EPI_RESID_STATS_MX,
-                                     (float*)t.st2, nullptr, t.xq, t.xs, Mm, st)))
+        if ((rc = keds_gemm_mxfp8_ex(t.aq, t.as, Mm, k.out_q8, k.out_s8, w, k.out_b, t.h, Mm, w, w,
+                                     KEDS_FP8_EPI_RESID_STATS_MX_H, (float*)t.st2, nullptr, t.xq, t.xs, Mm, st)))
             return rc;
-        if (Mt && (rc = out_rows(t, k, x, w, rem))) return rc;
+        if (Mt && (rc = out_rows(t, k, w, rem))) return rc;
         if ((rc = keds_gemm_mxfp8_ex(t.xq, t.xs, Mm, k.fc_q8, k.fc_s8, 4 * w, k.fc_bc8, nullptr, Mm, 4 * w, w,
                                      KEDS_FP8_EPI_LN_QGELU_MX, (float*)t.st2, (float*)t.st1, t.hq, t.hs, Mm, st)))
             return rc;
         if (Mt && (rc = fc_rows(t, k, w, rem))) return rc;
-        if ((rc = keds_gemm_mxfp8_ex(t.hq, t.hs, Mm, k.proj_q8, k.proj_s8, w, k.proj_b, x, Mm, w, 4 * w,
-                                     KEDS_FP8_EPI_RESID_STATS_MX, (float*)t.st1, nullptr, t.xq, t.xs, Mm, st)))
+        if ((rc = keds_gemm_mxfp8_ex(t.hq, t.hs, Mm, k.proj_q8, k.proj_s8, w, k.proj_b, t.h, Mm, w, 4 * w,
+                                     KEDS_FP8_EPI_RESID_STATS_MX_H, (float*)t.st1, nullptr, t.xq, t.xs, Mm, st)))
             return rc;
-        if (Mt && (rc = proj_rows(t, k, x, w, last, rem))) return rc;
+        if (Mt && (rc = proj_rows(t, k, w, last, rem))) return rc;
     }
-    return lanes.to_main();
+    if ((rc = lanes.to_main())) return rc;
+    return keds_cast_rows_f16_f32_impl(t.h, x, M, w, w, st);       // the caller reads x in fp32
 }
 
 int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st) {
@@ -204,7 +210,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         if ((rc = lanes.init(st, two))) return rc;
         const RowSpan body{0, lanes.split ? Mm : M, st};
         const RowSpan rem{(size_t)Mm, lanes.split ? M - Mm : 0, lanes.side};
-        if ((rc = keds_rowstats_cast(x, t.h, (float*)t.st1, M, w, st))) return rc;
+        if ((rc = keds_rowstats_cast_ex(x, t.h, 1, (float*)t.st1, M, w, st))) return rc;
         if ((rc = lanes.to_side())) return rc;
         for (int l = 0; l < p->layers; ++l) {
             const keds_block_params& k = p->blocks[l];
@@ -212,17 +218,18 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
             if ((rc = qkv_rows(t, k, w, body))) return rc;
             if (rem.n && (rc = qkv_rows(t, k, w, rem))) return rc;
             if ((rc = lanes.to_main())) return rc;
-            if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, B, st);
+            if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, t.h, B, st);
             if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
             if ((rc = lanes.to_side())) return rc;
-            if ((rc = out_rows(t, k, x, w, body))) return rc;
-            if (rem.n && (rc = out_rows(t, k, x, w, rem))) return rc;
+            if ((rc = out_rows(t, k, w, body))) return rc;
+            if (rem.n && (rc = out_rows(t, k, w, rem))) return rc;
             if ((rc = fc_rows(t, k, w, body))) return rc;
             if (rem.n && (rc = fc_rows(t, k, w, rem))) return rc;
-            if ((rc = proj_rows(t, k, x, w, last, body))) return rc;
-            if (rem.n && (rc = proj_rows(t, k, x, w, last, rem))) return rc;
+            if ((rc = proj_rows(t, k, w, last, body))) return rc;
+            if (rem.n && (rc = proj_rows(t, k, w, last, rem))) return rc;
         }
-        return lanes.to_main();
+        if ((rc = lanes.to_main())) return rc;
+        return keds_cast_rows_f16_f32_impl(t.h, x, M, w, w, st);   // the caller reads x in fp32
     }
     // KEDS_DETERMINISTIC / unfolded weights: stand-alone LayerNorm launches, plain bias epilogues
     for (int l = 0; l < p->layers; ++l) {
@@ -230,7 +237,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         const bool last = l == p->layers - 1;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
         if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, t.qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
-        if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, B, st);
+        if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, nullptr, B, st);
         if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
         if ((rc = keds_gemm_bt(t.att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;

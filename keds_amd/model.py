@@ -101,10 +101,10 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
         for name, lin_w, lin_b, ln in folds:
             w32 = _f32(lin_w)
             n, k = w32.shape
-            wf = torch.empty((n, k), dtype=torch.bfloat16, device=w32.device)
+            wf = torch.empty((n, k), dtype=torch.float16, device=w32.device)     # fp16: multiplies the fp16 residual stream
             bc = torch.empty(2 * n, dtype=torch.float32, device=w32.device)
-            check(lib.keds_fold_layernorm(ptr(w32), ptr(lin_b), ptr(t[ln[0]]), ptr(t[ln[1]]), n, k, ptr(wf), ptr(bc),
-                                          stream()), "keds_fold_layernorm")
+            check(lib.keds_fold_layernorm_ex(ptr(w32), ptr(lin_b), ptr(t[ln[0]]), ptr(t[ln[1]]), n, k, ptr(wf), 1, ptr(bc),
+                                             stream()), "keds_fold_layernorm")
             t[name + "_wf"], t[name + "_bc"] = wf, bc
         if fp8 and folds:
             # BASELINE config 5: MXFP8 copies of the four weights (in_proj / c_fc with their LayerNorm folded in)

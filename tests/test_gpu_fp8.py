@@ -160,6 +160,34 @@ def test_mxfp8_layernorm_epilogues(M, N, K, gelu):
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1024, 1024, 4096)])
+def test_mxfp8_residual_stats_epilogue_fp16_stream(M, N, K):
+    """KEDS_FP8_EPI_RESID_STATS_MX_H: the residual stream in fp16 (what the fp8 towers run); the MXFP8 copy and the
+    statistics come from the fp32 sum, the stored row is its fp16 rounding."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + K)
+    a = torch.randn(M, K, generator=g, device="cuda")
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    x = (3 * torch.randn(M, N, generator=g, device="cuda")).half()
+    aq, as_ = _quantize(a)
+    wq, ws = _quantize(w)
+    want = x.float() + _dequantize(aq, as_) @ _dequantize(wq, ws).t() + b
+    stats = torch.zeros((M, 2), dtype=torch.int64, device="cuda")
+    q = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+    qs = torch.full((N // 128, M, 4), 127, dtype=torch.uint8, device="cuda")
+    _lib.check(lib.keds_gemm_mxfp8_ex(_lib.ptr(aq), _lib.ptr(as_), as_.shape[1], _lib.ptr(wq), _lib.ptr(ws), ws.shape[1], _lib.ptr(b),
+                                      _lib.ptr(x), M, N, K, _lib.FP8_EPI_RESID_STATS_MX_H, _lib.ptr(stats), None, _lib.ptr(q),
+                                      _lib.ptr(qs), M, _lib.stream()), "gemm fp8 resid f16")
+    assert rel_l2(x.float(), want) <= 4e-4
+    assert float((x.float() - want).abs().max()) <= float(want.abs().max()) * 2.0 ** -10
+    qt, st = _torch_mx(want)                                       # MXFP8 copy of the fp32 sums (up to accumulation order)
+    same = (q == qt).float().mean().item()
+    assert same >= 0.999, same
+    sf = (stats.double() / 2.0 ** 28).float()
+    assert torch.allclose(sf[:, 0], want.sum(1), rtol=1e-4, atol=5e-3) and torch.allclose(sf[:, 1], (want * want).sum(1), rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 256), (1024, 1024, 4096)])
 def test_mxfp8_residual_stats_epilogue(M, N, K):
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(M + K)

@@ -228,39 +228,54 @@ def test_gallery_ranking_and_recall_metric():
 
 
 # ---- LayerNorm folded into the GEMMs (KEDS_EPI_LN_* / KEDS_EPI_RESID_STATS_F32) ------------------------------
-def _fold(w, b, gamma, beta):
+def _fold(w, b, gamma, beta, dt=torch.bfloat16):
     lib = _lib.load()
     n, k = w.shape
-    wf = torch.empty((n, k), dtype=torch.bfloat16, device="cuda")
+    wf = torch.empty((n, k), dtype=dt, device="cuda")
     bc = torch.empty(2 * n, dtype=torch.float32, device="cuda")
-    _lib.check(lib.keds_fold_layernorm(_lib.ptr(w), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), n, k, _lib.ptr(wf),
-                                       _lib.ptr(bc), _lib.stream()), "fold")
+    if dt == torch.bfloat16:
+        _lib.check(lib.keds_fold_layernorm(_lib.ptr(w), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), n, k, _lib.ptr(wf),
+                                           _lib.ptr(bc), _lib.stream()), "fold")
+    else:
+        _lib.check(lib.keds_fold_layernorm_ex(_lib.ptr(w), _lib.ptr(b), _lib.ptr(gamma), _lib.ptr(beta), n, k, _lib.ptr(wf), 1,
+                                              _lib.ptr(bc), _lib.stream()), "fold f16")
+    # the fp16 build rounds the exact product once (v_fma_mixlo_f16) where torch rounds to fp32 first: a 1-ulp difference
+    # on the few elements whose fp32 product is a tie
+    ref = (w * gamma).to(dt)
+    differ = wf != ref
+    assert float(differ.float().mean()) <= 1e-3
+    assert float((wf.float() - ref.float()).abs().max()) <= float(ref.abs().max()) * 2.0 ** -10
     return wf, bc
 
 
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float16], ids=["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K,epi", [(700, 384, 256, "ln"), (33024 + 128, 3072, 1024, "ln"), (1500, 1024, 256, "gelu"),
                                        (4224, 4096, 1024, "gelu")])
-def test_gemm_layernorm_epilogues_equal_layernorm_then_linear(M, N, K, epi):
+def test_gemm_layernorm_epilogues_equal_layernorm_then_linear(M, N, K, epi, dt):
     """rstd (x W'^T - mean colsum W') + (b + W beta) == Linear(LayerNorm(x)): against torch fp32 on the GPU's own
-    rounded operands, and the second statistics buffer is cleared for exactly the rows of the launch."""
+    rounded operands, and the second statistics buffer is cleared for exactly the rows of the launch.  bf16 operands
+    (KEDS_EPI_LN_*) and fp16 operands (KEDS_EPI_LN_*_H: what the towers run on their fp16 residual stream)."""
     lib = _lib.load()
+    f16 = dt == torch.float16
     g = torch.Generator(device="cuda").manual_seed(M + N)
     x = torch.randn(M, K, generator=g, device="cuda") * 1.7 + 0.3 * torch.randn(M, 1, generator=g, device="cuda")
     w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
     b = torch.randn(N, generator=g, device="cuda") * 0.1
     gamma = 1 + 0.2 * torch.randn(K, generator=g, device="cuda")
     beta = 0.1 * torch.randn(K, generator=g, device="cuda")
-    wf, bc = _fold(w, b, gamma, beta)
+    wf, bc = _fold(w, b, gamma, beta, dt)
     Mp = (M + 127) // 128 * 128
-    xb = torch.zeros((Mp, K), dtype=torch.bfloat16, device="cuda")
+    xb = torch.zeros((Mp, K), dtype=dt, device="cuda")
     stats = torch.zeros((Mp, 2), dtype=torch.int64, device="cuda")      # {sum, sum sq} as 64-bit fixed point (* 2^28)
-    _lib.check(lib.keds_rowstats_cast(_lib.ptr(x), _lib.ptr(xb), _lib.ptr(stats), M, K, _lib.stream()), "rowstats")
-    assert torch.equal(xb[:M], x.to(torch.bfloat16))
+    _lib.check(lib.keds_rowstats_cast_ex(_lib.ptr(x), _lib.ptr(xb), int(f16), _lib.ptr(stats), M, K, _lib.stream()), "rowstats")
+    assert torch.equal(xb[:M], x.to(dt))
     sf = stats.double() / 2.0 ** 28
     assert torch.allclose(sf[:M, 0].float(), x.sum(1), rtol=1e-5, atol=1e-3) and torch.allclose(sf[:M, 1].float(), (x * x).sum(1), rtol=1e-5)
     other = torch.full((Mp + 8, 2), 7, dtype=torch.int64, device="cuda")
     out = torch.zeros((Mp, N), dtype=torch.bfloat16, device="cuda")
     code = _lib.EPI_LN_BIAS_BF16 if epi == "ln" else _lib.EPI_LN_QGELU_BF16
+    if f16:
+        code = _lib.EPI_LN_BIAS_BF16_H if epi == "ln" else _lib.EPI_LN_QGELU_BF16_H
     _lib.ensure_gemm_workspace("cuda")
     _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(xb), K, _lib.ptr(wf), _lib.ptr(bc), _lib.ptr(out), N, M, N, K, code,
                                     _lib.ptr(stats), 0, _lib.ptr(other), _lib.stream()), "gemm ln")
@@ -272,13 +287,45 @@ def test_gemm_layernorm_epilogues_equal_layernorm_then_linear(M, N, K, epi):
     want = rstd * (xr @ wf.float().t() - mean * wf.float().sum(1)[None, :]) + (b + w @ beta)[None, :]
     if epi == "gelu":
         want = want * torch.sigmoid(1.702 * want)
-    report(f"gemm_ln_{epi}", M=M, N=N, K=K, rel_l2=rel_l2(out[:M], want))
+    report(f"gemm_ln_{epi}", M=M, N=N, K=K, operands=str(dt), rel_l2=rel_l2(out[:M], want))
     assert rel_l2(out[:M], want) <= 4e-3                       # bf16 output rounding
     # and it IS LayerNorm + Linear (fp32 torch), up to the bf16 operand rounding
     full = torch.nn.functional.layer_norm(x, (K,), gamma, beta) @ w.t() + b
     if epi == "gelu":
         full = full * torch.sigmoid(1.702 * full)
-    assert rel_l2(out[:M], full) <= 1.2e-2
+    assert rel_l2(out[:M], full) <= (5e-3 if f16 else 1.2e-2)       # fp16 operands carry 3 more mantissa bits
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 128, 256), (33024 + 128, 1024, 1024), (128, 1024, 4096), (2000, 768, 3072)])
+def test_gemm_residual_stats_epilogue_fp16_stream(M, N, K):
+    """KEDS_EPI_RESID_STATS_F16: x (fp16, in place) = round(x + a W^T + b) with the sum in fp32, and the per-row
+    {sum, sum sq} of the fp32 sums; statistics may be NULL (last block)."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(K + M)
+    Mp = (M + 127) // 128 * 128
+    a = torch.zeros((Mp, K), dtype=torch.bfloat16, device="cuda")
+    a[:M] = (torch.randn(M, K, generator=g, device="cuda")).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") * K ** -0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    x = torch.zeros((Mp, N), dtype=torch.float16, device="cuda")
+    x[:M] = (3 * torch.randn(M, N, generator=g, device="cuda")).half()
+    want = x[:M].float() + a[:M].float() @ w.float().t() + b             # fp32 sum
+    x0 = x.clone()
+    stats = torch.zeros((Mp, 2), dtype=torch.int64, device="cuda")
+    _lib.ensure_gemm_workspace("cuda")
+    _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x), N, M, N, K,
+                                    _lib.EPI_RESID_STATS_F16, _lib.ptr(stats), 0, None, _lib.stream()), "gemm resid f16")
+    # one fp16 rounding of the fp32 sum: within 1 ulp of the rounded reference (accumulation order differs from torch's)
+    assert max_abs(x[:M].float(), want.half().float()) <= float(want.abs().max()) * 2.0 ** -10
+    assert rel_l2(x[:M].float(), want) <= 4e-4
+    sf = (stats.double() / 2.0 ** 28).float()
+    assert torch.allclose(sf[:M, 0], want.sum(1), rtol=1e-4, atol=5e-3)
+    assert torch.allclose(sf[:M, 1], (want * want).sum(1), rtol=1e-4)
+    assert bool((stats[M:] == 0).all()) and bool((x[M:] == 0).all())
+    x2 = x0.clone()                                                      # reproducible bits; NULL statistics accepted
+    _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x2), N, M, N, K,
+                                    _lib.EPI_RESID_STATS_F16, None, 0, None, _lib.stream()), "gemm resid f16 2")
+    assert torch.equal(x2, x)
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 256), (33024 + 128, 1024, 1024), (128, 1024, 4096), (2000, 768, 3072)])
