@@ -210,6 +210,31 @@ def test_side_lane_for_remainder_rows_changes_no_bit(precision):
         assert torch.equal(o, off)
 
 
+def test_side_lane_under_foreign_stream_and_graph_capture():
+    """The two-lane tower pass forks from / joins to whatever stream the caller is on: same bits on a non-default torch
+    stream, and the whole encode_image can be captured into a graph (the side stream joins the capture through its fork
+    event) and replayed on new inputs."""
+    sd = O.synth_clip_state_dict(**VITL, seed=7)
+    m = keds_amd.build_model(sd, fp16=False).cuda()
+    del sd
+    img = torch.from_numpy(O.synth_tensor("imgs", [128, 3, 224, 224], 1.0).numpy()).cuda()
+    ref = m.encode_image(img).clone()
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        other = m.encode_image(img).clone()
+    s.synchronize()
+    assert torch.equal(other, ref)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = m.encode_image(img)
+    img2 = torch.from_numpy(O.synth_tensor("imgs2", [128, 3, 224, 224], 1.0).numpy()).cuda()
+    img.copy_(img2)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, m.encode_image(img2))
+
+
 def test_recall_equal_to_cpu_reference():
     """Recall@1/5/10 of a synthetic retrieval problem: GPU features vs oracle features, same ranking metric.
     Queries are encoded images; the gallery holds the oracle's embeddings of the same images plus
