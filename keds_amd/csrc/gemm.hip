@@ -546,6 +546,10 @@ constexpr int LDS_BYTES = 2 * PBUF_BYTES;       // 128 KiB
 // (clean loop: 128 MFMA, 32 ds_read_b128, 16 DMA, no v_accvgpr traffic; correct).  That last form reaches 1.39 vs 1.29 PF
 // at 8192^3 but LOSES on the shapes of this path (qkv -5 %, fc -9 %, out -3 %, proj -1 %): with one wave per SIMD the
 // per-tile prologue / epilogue is exposed, and K = 1024 tiles are mostly prologue and epilogue.  Not used.
+// NOTE (measured, round 1): where the 8 DMA pieces of a K-tile sit inside their K-step does not matter either.  All eight
+// before the first MFMA group, or two per group in the first half of the step (so the last piece has 1.5 K-steps to land
+// instead of one), against one piece per group: qkv 190 / 195 / 200 us, out 71 / 73 / 75, fc 264 / 268 / 275, proj
+// 229 / 228 / 234 (spread / early pairs / all first).  The K-loop does not wait for the last DMA piece.
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
