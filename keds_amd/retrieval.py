@@ -79,9 +79,17 @@ def compose_query_features(model: CLIP, stream_image: KnowledgeStream, stream_te
     q = model.encode_image(ref_images).float()
     topk_image, topk_text = get_retrieved_features(q, database, None, topk=topk)
     tok_a = stream_image(q, topk_image, topk_text)                                   # [B,3,D]
-    comp_a = model.encode_text_img_retrieval(text_with_blank, tok_a, split_ind=id_split, repeat=repeat)
     tok_b = stream_text(q, topk_image, topk_text)
-    comp_b = model.encode_text_img_retrieval(text_with_blank, tok_b, split_ind=id_split, repeat=repeat)
+    if not repeat and text_with_blank.shape[0] == tok_a.shape[0] == tok_b.shape[0]:
+        # the two text-tower passes share the captions and differ in the spliced tokens only: one pass over 2B rows
+        # (rows are independent; B = 128 -> 19,712 rows = 77 full 256-row GEMM tiles instead of two ragged 9,856-row passes)
+        B = tok_a.shape[0]
+        both = model.encode_text_img_retrieval(torch.cat([text_with_blank, text_with_blank]), torch.cat([tok_a, tok_b]),
+                                               split_ind=id_split, repeat=False)
+        comp_a, comp_b = both[:B], both[B:]
+    else:
+        comp_a = model.encode_text_img_retrieval(text_with_blank, tok_a, split_ind=id_split, repeat=repeat)
+        comp_b = model.encode_text_img_retrieval(text_with_blank, tok_b, split_ind=id_split, repeat=repeat)
     b_n, a_n, mix = ops.mix_normalize(comp_b.float(), comp_a.float(), float(w_text_stream), 1.0 - float(w_text_stream))
     return {"composed": a_n, "image": b_n, "mixture": mix, "query_image_features": q,
             "tokens_image_stream": tok_a, "tokens_text_stream": tok_b}
