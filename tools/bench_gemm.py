@@ -18,6 +18,10 @@ SHAPES = [  # (M, N, K, epilogue, tag)
     (9856, 768, 768, _lib.EPI_BIAS_RESID_F32, "text.out"),
     (9856, 3072, 768, _lib.EPI_BIAS_QGELU_BF16, "text.fc"),
     (9856, 768, 3072, _lib.EPI_BIAS_RESID_F32, "text.proj"),
+    (19712, 2304, 768, _lib.EPI_BIAS_BF16, "text2.qkv"),
+    (19712, 768, 768, _lib.EPI_BIAS_RESID_F32, "text2.out"),
+    (19712, 3072, 768, _lib.EPI_BIAS_QGELU_BF16, "text2.fc"),
+    (19712, 768, 3072, _lib.EPI_BIAS_RESID_F32, "text2.proj"),
 ]
 
 
