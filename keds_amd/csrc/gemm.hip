@@ -550,7 +550,9 @@ constexpr int LDS_BYTES = 2 * PBUF_BYTES;       // 128 KiB
 // before the first MFMA group, or two per group in the first half of the step (so the last piece has 1.5 K-steps to land
 // instead of one), against one piece per group: qkv 190 / 195 / 200 us, out 71 / 73 / 75, fc 264 / 268 / 275, proj
 // 229 / 228 / 234 (spread / early pairs / all first).  The K-loop does not wait for the last DMA piece.
-template <int EPI>
+// STAMP (diagnostic build of one instantiation, tools/stamp_gemm.py): s_memtime stamps around the prologue, every
+// K-tile's wait and barrier, the loop and the epilogue; aux2 then receives 8 counters per wave instead of its usual role.
+template <int EPI, int STAMP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int M, int N, int K, int n_tiles,
@@ -558,6 +560,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
                                                               void* __restrict__ aux2) {
     using namespace pr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long t_entry = 0, vm_wait = 0, bar_wait = 0;
+    if constexpr (STAMP) t_entry = __builtin_amdgcn_s_memtime();
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     // The 32 workgroups that run together on one XCD take consecutive logical ids.  Map each run of 32 ids to a
     // block of 8 m-tiles x 4 n-tiles (12 distinct operand panels per K-tile in that XCD's L2 instead of up to 18
@@ -583,13 +587,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     // ---- staging: piece j (8 LDS rows) of an operand; this wave owns pieces wave + 8*i (rows +64*i)
     const int R0 = 8 * wave + (lane >> 3);                        // 0..63
     const int sch = (lane & 7) ^ swz_f(R0);                        // swz_f(R0 + 64 i) == swz_f(R0)
-    const char* xsrc = reinterpret_cast<const char*>(X + (size_t)(m0 + R0) * K) + sch * 16;
-    const char* wsrc = reinterpret_cast<const char*>(W + (size_t)(n0 + perm_w(R0)) * K) + sch * 16;
-    const size_t rstride = (size_t)64 * K * 2;                    // 64 rows further down
+    // uniform tile bases (SGPR pairs) + 32-bit lane offsets: the DMA then takes the `global_load_lds v_off, s[base]` form --
+    // one address VGPR per lane instead of a 64-bit pointer, and no 64-bit VALU adds in the K-loop (16 per K-tile before)
+    const char* xt = reinterpret_cast<const char*>(X + (size_t)m0 * K);
+    const char* wt = reinterpret_cast<const char*>(W + (size_t)n0 * K);
+    const unsigned xoff = (unsigned)R0 * (unsigned)K * 2u + sch * 16;
+    const unsigned woff = (unsigned)perm_w(R0) * (unsigned)K * 2u + sch * 16;
+    const unsigned rstride = 64u * (unsigned)K * 2u;              // 64 rows further down
     // DMA piece q (0..7: X pieces 0..3 then W pieces 0..3) of K-tile p
     auto issue = [&](int p, int q) {
         const int i = q & 3;
-        const char* src = (q < 4 ? xsrc : wsrc) + i * rstride + (size_t)p * (TK * 2);
+        const char* src = q < 4 ? xt + (xoff + i * rstride + (unsigned)p * (TK * 2)) : wt + (woff + i * rstride + (unsigned)p * (TK * 2));
         char* dst = smem + (p & 1) * PBUF_BYTES + (q < 4 ? 0 : OP_BYTES) + (wave + 8 * i) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
@@ -613,6 +621,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(1, q);
     asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    unsigned long long t_loop0 = 0;
+    if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
     bf16x8 xa[8], wa[4], xb[8], wb[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) wa[ni] = *reinterpret_cast<const bf16x8*>(smem + wrow + slot0 + ni * 2048);
@@ -624,7 +634,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 #define KEDS_PAIR_STEP(xc, wc, xn, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                                  \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr (SYNC) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
+        if constexpr (SYNC && STAMP != 0) {                                                                    \
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();                                        \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+            const unsigned long long tb = __builtin_amdgcn_s_memtime();                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                    \
+            const unsigned long long tc = __builtin_amdgcn_s_memtime();                                        \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                 \
+            vm_wait += tb - ta;                                                                                \
+            bar_wait += tc - tb;                                                                               \
+        }                                                                                                      \
+        if constexpr (SYNC && STAMP == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) {                                                     \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
@@ -674,6 +694,25 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 
     // ---- epilogue (same ownership pattern as the 128^2 kernel)
     const bool zl = epi_is_ln(EPI) ? (n0 == 0 && wn == 0 && g == 0) : (g == 0);
+    if constexpr (STAMP) {
+        const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
+        tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, nullptr, N, zl);
+        const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(aux2) + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = t_loop0 - t_entry;   // prologue (address set-up, 16 DMA pieces, first K-tile landed)
+            o[1] = t_loop1 - t_loop0;   // K-loop
+            o[2] = t_issued - t_loop1;  // epilogue until the last store is issued
+            o[3] = vm_wait;             // summed over the K-tiles: s_waitcnt vmcnt(0) lgkmcnt(0)
+            o[4] = bar_wait;            // summed: s_barrier
+            o[5] = t_end - t_issued;    // store drain after the last issue
+            o[6] = t_end - t_entry;
+            o[7] = 0;
+        }
+        return;
+    }
     tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
 
@@ -690,6 +729,7 @@ int device_cus_gemm() {
 }
 
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
+int g_pair_stamp = 0;     // diagnostic: stamped build of the qkv instantiation (aux2 = stamp buffer)
 
 template <int EPI>
 int launch_big(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
@@ -702,6 +742,19 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
             return KEDS_E_LAUNCH;
         }
         attr_set = true;
+    }
+    if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H) {
+        if (g_pair_stamp) {
+            static bool set2 = false;
+            if (!set2) {
+                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          pr::LDS_BYTES);
+                set2 = true;
+            }
+            gemm_bt_pair_kernel<EPI, 1><<<(M / pr::TM) * (N / pr::TN), 512, pr::LDS_BYTES, st>>>(
+                (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
+            return keds_check_launch("gemm_bt_pair_kernel<stamp>");
+        }
     }
     const int m_tiles = M / pr::TM, n_tiles = N / pr::TN;         // M is a multiple of 256 here
     gemm_bt_pair_kernel<EPI><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
@@ -765,6 +818,7 @@ extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
+    g_pair_stamp = (on >> 12) & 1;      // bit 12: stamped diagnostic build of the qkv GEMM
     return KEDS_OK;
 }
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""In-kernel timeline of the 256^2 GEMM (qkv shape, 32768 x 3072 x 1024): s_memtime stamps of the stamped diagnostic
+build (keds_gemm_force_small bit 12): prologue / K-loop / epilogue cycles per wave and the cycles every wave spends in the
+K-loop's `s_waitcnt vmcnt(0)` and `s_barrier`.  GPU only; not a product path."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from keds_amd import _lib
+from keds_amd._lib import ptr, check, stream
+lib = _lib.load()
+M, N, K = 32768, 3072, 1024
+a = torch.randn(M, K, device="cuda").half()
+w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+bias = torch.randn(2 * N, device="cuda")
+out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+stats = torch.zeros(M, 2, device="cuda", dtype=torch.int64); stats[:, 1] = (1 << 28) * K
+tiles = (M // 256) * (N // 256)
+buf = torch.zeros(tiles * 8 * 8, device="cuda", dtype=torch.int64)
+_lib.ensure_gemm_workspace(torch.device("cuda"))
+def run(aux2):
+    check(lib.keds_gemm_bt_ex2(ptr(a), K, ptr(w), ptr(bias), ptr(out), N, M, N, K, _lib.EPI_LN_BIAS_BF16_H, ptr(stats), 0, ptr(aux2), stream()), "gemm")
+other = torch.zeros(M, 2, device="cuda", dtype=torch.int64)
+for _ in range(20):
+    run(other)
+torch.cuda.synchronize()
+lib.keds_gemm_force_small(1 << 12)
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+for _ in range(3):
+    run(buf)
+e0.record(); run(buf); e1.record()
+torch.cuda.synchronize()
+lib.keds_gemm_force_small(0)
+t = buf.view(tiles, 8, 8).double().cpu()
+print(f"stamped launch {e0.elapsed_time(e1) * 1e3:.1f} us, {tiles} tiles")
+names = ["prologue", "K-loop", "epilogue issue", "vm_wait(sum)", "barrier_wait(sum)", "store drain", "lifetime"]
+for i, n in enumerate(names):
+    v = t[:, :, i]
+    print(f"{n:18s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f} cycles;  per wave index: " +
+          " ".join(f"{v[:, wv].mean():7.0f}" for wv in range(8)))
+print(f"K-loop per K-tile {t[:, :, 1].mean() / (K // 64):.0f} cycles (MFMA alone: 2048)")
