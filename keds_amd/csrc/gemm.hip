@@ -14,6 +14,7 @@
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;        // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;       // X tile + W tile
@@ -104,11 +105,18 @@ __device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats_, i
     nmr = -mean * rstd;
 }
 
+__device__ __forceinline__ void ln_coeff_from(keds_stat_t s_fixed, keds_stat_t ss_fixed, float invk, float& rstd, float& nmr) {
+    const float mean = keds_stat_value(s_fixed) * invk;
+    const float var = fmaxf(keds_stat_value(ss_fixed) * invk - mean * mean, 0.f);
+    rstd = rsqrtf(var + LN_EPS);
+    nmr = -mean * rstd;
+}
+
 __device__ __forceinline__ float sum8(f32x4 a, f32x4 b) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])); }
 
 // Epilogue of one wave's accumulator tile, shared by the 128^2 and 256^2 kernels: lane (g, c) owns rows
 // m_lane + 16*mi (mi < MI) and columns n_lane + 32*p + 0..7 (p = 0, 1) held in acc[2p][mi], acc[2p+1][mi].
-template <int EPI, int MI>
+template <int EPI, int MI, int DBG = 0>   // DBG (stamped diagnostic build only): 2 = no statistics loads, 3 = no stores
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* __restrict__ bias, void* __restrict__ out,
                                               int m_lane, int M, int n_lane, int N, int K, const float* __restrict__ aux,
                                               int aux_i, void* __restrict__ aux2, long long ldc, bool zero_lane) {
@@ -119,7 +127,11 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const int m = m_lane + 16 * mi;
-            ln_row_coeff(aux, m < M ? m : M - 1, invk, rstd[mi], nmr[mi]);
+            if constexpr (DBG == 2) {
+                rstd[mi] = 1.0f + invk;
+                nmr[mi] = invk;
+            } else
+                ln_row_coeff(aux, m < M ? m : M - 1, invk, rstd[mi], nmr[mi]);
             if (zero && zero_lane && m < M) keds_stat_zero(zero + 2 * (size_t)m);
         }
 #pragma unroll
@@ -131,6 +143,18 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = m_lane + 16 * mi;
                 if (m >= M) continue;
+                if constexpr (DBG == 1) {      // TIMING ONLY (wrong placement): every store instruction covers 8 rows x 128 B
+                    const int c_ = m & 15, row = m - c_ + (c_ & 7) + 8 * p;
+                    const int col = (n - 32 * p) - (n & 31) + ((n & 31) >> 3) * 8 + 32 * (c_ >> 3);
+                    epilogue_store<epi_base(EPI)>(acc[2 * p][mi] * rstd[mi] + (c0 * nmr[mi] + b0),
+                                                  acc[2 * p + 1][mi] * rstd[mi] + (c1 * nmr[mi] + b1), out, row, col, N, nullptr, 0, ldc);
+                    continue;
+                }
+                if constexpr (DBG == 3) {      // keep the math alive, store (almost) nothing
+                    const f32x4 v = acc[2 * p][mi] * rstd[mi] + (c0 * nmr[mi] + b0) + acc[2 * p + 1][mi] * rstd[mi] + (c1 * nmr[mi] + b1);
+                    if (v[0] + v[1] + v[2] + v[3] == 12345.678f) reinterpret_cast<float*>(out)[0] = v[0];
+                    continue;
+                }
                 epilogue_store<epi_base(EPI)>(acc[2 * p][mi] * rstd[mi] + (c0 * nmr[mi] + b0),
                                               acc[2 * p + 1][mi] * rstd[mi] + (c1 * nmr[mi] + b1), out, m, n, N, nullptr, 0, ldc);
             }
@@ -226,6 +250,56 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
                 if (m >= M) continue;
                 epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
             }
+        }
+    }
+}
+
+// LN epilogues of the 256^2 kernel.  The row coefficients {rstd, -mean rstd} and the tile's bias' / column-sum slices were
+// computed once per workgroup in the prologue (their loads and the 64-bit fixed-point -> float conversions hide behind the
+// wait for the first K-tile) and sit in the LDS side area; every row of the tile is valid (M % 256 == 0), and a lane's store
+// address is a uniform tile base + a 32-bit offset.  DBG 3 (stamped diagnostic build): no stores.
+template <int EPI, int DBG>
+__device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char* __restrict__ side, void* __restrict__ out,
+                                                 int m0, int n0, int N, int wm, int wn, int g, int c,
+                                                 void* __restrict__ aux2) {
+    float rstd[8], nmr[8];
+    const int r0 = 128 * wm + c;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const f32x2 cf = *reinterpret_cast<const f32x2*>(side + (r0 + 16 * mi) * 8);
+        rstd[mi] = cf[0];
+        nmr[mi] = cf[1];
+    }
+    if (aux2 && n0 == 0 && wn == 0 && g == 0) {          // the one wave column that clears the other statistics buffer
+        keds_stat_t* zero = reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)(m0 + r0);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) keds_stat_zero(zero + 32 * mi);
+    }
+    char* tile_out = reinterpret_cast<char*>(out) + ((size_t)m0 * N + n0) * 2;          // wave-uniform
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int nl = 64 * wn + 32 * p + 8 * g;
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(side + 2048 + nl * 4), b1 = *reinterpret_cast<const f32x4*>(side + 2048 + nl * 4 + 16);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(side + 3072 + nl * 4), c1 = *reinterpret_cast<const f32x4*>(side + 3072 + nl * 4 + 16);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) {
+            f32x4 v0 = acc[2 * p][mi] * rstd[mi] + (c0 * nmr[mi] + b0);
+            f32x4 v1 = acc[2 * p + 1][mi] * rstd[mi] + (c1 * nmr[mi] + b1);
+            if constexpr (epi_base(EPI) == KEDS_EPI_BIAS_QGELU_BF16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v0[j] = qgelu(v0[j]);
+                    v1[j] = qgelu(v1[j]);
+                }
+            }
+            if constexpr (DBG == 3) {
+                const f32x4 v = v0 + v1;
+                if (v[0] + v[1] + v[2] + v[3] == 12345.678f) reinterpret_cast<float*>(out)[0] = v[0];
+                continue;
+            }
+            const unsigned off = ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)nl) * 2u;
+            *reinterpret_cast<bf16x8*>(tile_out + off) = bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                                                                (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
         }
     }
 }
@@ -525,7 +599,8 @@ namespace pr {
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int OP_BYTES = 256 * 128;             // 32 KiB per operand per K-tile
 constexpr int PBUF_BYTES = 2 * OP_BYTES;        // X | W
-constexpr int LDS_BYTES = 2 * PBUF_BYTES;       // 128 KiB
+constexpr int SIDE_OFF = 2 * PBUF_BYTES;        // side area: float2 {rstd, -mean rstd}[256 rows] | bias'[256 cols] | colsum[256 cols]
+constexpr int LDS_BYTES = SIDE_OFF + 4096;      // 132 KiB
 }  // namespace pr
 
 // NOTE (measured, round 1): a persistent variant of this kernel (one workgroup per CU walking its tiles, next tile's
@@ -615,12 +690,47 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int np = K / TK;                                         // >= 2
+    // LN epilogues: one row's statistics (threads 0-255) or one column's bias' / column sum (threads 256-511) per thread,
+    // fetched BEFORE the DMA pieces (vmcnt retires in order) and turned into the side-area image while those are in flight
+    [[maybe_unused]] u32x4 st_raw = u32x4{0, 0, 0, 0};
+    [[maybe_unused]] float pb = 0.f, pc = 0.f;
+    // (inline asm + a hand-counted s_waitcnt: for a plain load the compiler waits with vmcnt(0) at the first use, which
+    // here would also wait for all 16 DMA pieces)
+    if constexpr (epi_is_ln(EPI)) {
+        if (tid < 256) {
+            const keds_stat_t* sp = reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)(m0 + tid);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st_raw) : "v"(sp) : "memory");
+        } else {
+            const float* bp = bias + n0 + tid - 256;
+            const float* cp = bp + N;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pc) : "v"(cp) : "memory");
+        }
+    }
     // prologue: K-tiles 0 and 1 in flight, retire tile 0
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(0, q);
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(1, q);
-    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    if constexpr (epi_is_ln(EPI)) {
+        // everything older than the 16 DMA pieces has landed
+        asm volatile("s_waitcnt vmcnt(16)" : "+v"(st_raw), "+v"(pb), "+v"(pc)::"memory");
+        if (tid < 256) {
+            float rs, nm;
+            if constexpr (STAMP == 2) {
+                rs = 1.0f + 1.0f / (float)K;
+                nm = 1.0f / (float)K;
+            } else {
+                ln_coeff_from((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0]),
+                              (keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]), 1.0f / (float)K, rs, nm);
+            }
+            *reinterpret_cast<f32x2*>(smem + SIDE_OFF + tid * 8) = f32x2{rs, nm};
+        } else {
+            *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + (tid - 256) * 4) = pb;
+            *reinterpret_cast<float*>(smem + SIDE_OFF + 3072 + (tid - 256) * 4) = pc;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     unsigned long long t_loop0 = 0;
     if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
     bf16x8 xa[8], wa[4], xb[8], wb[4];
@@ -696,7 +806,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     const bool zl = epi_is_ln(EPI) ? (n0 == 0 && wn == 0 && g == 0) : (g == 0);
     if constexpr (STAMP) {
         const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
-        tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, nullptr, N, zl);
+        if constexpr (epi_is_ln(EPI))
+            pair_ln_epilogue<EPI, STAMP>(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c, nullptr);
+        else
+            tile_epilogue<EPI, 8, STAMP>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, nullptr, N, zl);
         const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned long long t_end = __builtin_amdgcn_s_memtime();
@@ -708,12 +821,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
             o[3] = vm_wait;             // summed over the K-tiles: s_waitcnt vmcnt(0) lgkmcnt(0)
             o[4] = bar_wait;            // summed: s_barrier
             o[5] = t_end - t_issued;    // store drain after the last issue
-            o[6] = t_end - t_entry;
-            o[7] = 0;
+            o[6] = t_entry;             // raw stamps + where the wave ran: gaps between consecutive workgroups of a CU
+            o[7] = t_end;
+            unsigned long long* o2 = reinterpret_cast<unsigned long long*>(aux2) + (size_t)gridDim.x * 64 + (size_t)blockIdx.x * 8 + wave;
+            *o2 = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
         }
         return;
     }
-    tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
+    if constexpr (epi_is_ln(EPI))
+        pair_ln_epilogue<EPI, 0>(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c, aux2);
+    else
+        tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
 
 int device_cus_gemm() {
@@ -747,12 +865,18 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         if (g_pair_stamp) {
             static bool set2 = false;
             if (!set2) {
-                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          pr::LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, pr::LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, pr::LDS_BYTES);
+                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, pr::LDS_BYTES);
                 set2 = true;
             }
-            gemm_bt_pair_kernel<EPI, 1><<<(M / pr::TM) * (N / pr::TN), 512, pr::LDS_BYTES, st>>>(
-                (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
+            const dim3 grid((M / pr::TM) * (N / pr::TN));
+            if (g_pair_stamp == 2)
+                gemm_bt_pair_kernel<EPI, 2><<<grid, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
+            else if (g_pair_stamp == 3)
+                gemm_bt_pair_kernel<EPI, 3><<<grid, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
+            else
+                gemm_bt_pair_kernel<EPI, 1><<<grid, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
             return keds_check_launch("gemm_bt_pair_kernel<stamp>");
         }
     }
@@ -818,7 +942,7 @@ extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
-    g_pair_stamp = (on >> 12) & 1;      // bit 12: stamped diagnostic build of the qkv GEMM
+    g_pair_stamp = (on >> 12) & 3;      // bits 12-13: stamped diagnostic build of the qkv GEMM (2: no statistics loads, 3: no stores)
     return KEDS_OK;
 }
 

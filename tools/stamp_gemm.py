@@ -14,7 +14,7 @@ bias = torch.randn(2 * N, device="cuda")
 out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
 stats = torch.zeros(M, 2, device="cuda", dtype=torch.int64); stats[:, 1] = (1 << 28) * K
 tiles = (M // 256) * (N // 256)
-buf = torch.zeros(tiles * 8 * 8, device="cuda", dtype=torch.int64)
+buf = torch.zeros(tiles * 8 * 8 + tiles * 8, device="cuda", dtype=torch.int64)
 _lib.ensure_gemm_workspace(torch.device("cuda"))
 def run(aux2):
     check(lib.keds_gemm_bt_ex2(ptr(a), K, ptr(w), ptr(bias), ptr(out), N, M, N, K, _lib.EPI_LN_BIAS_BF16_H, ptr(stats), 0, ptr(aux2), stream()), "gemm")
@@ -22,18 +22,35 @@ other = torch.zeros(M, 2, device="cuda", dtype=torch.int64)
 for _ in range(20):
     run(other)
 torch.cuda.synchronize()
-lib.keds_gemm_force_small(1 << 12)
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-for _ in range(3):
-    run(buf)
-e0.record(); run(buf); e1.record()
-torch.cuda.synchronize()
-lib.keds_gemm_force_small(0)
-t = buf.view(tiles, 8, 8).double().cpu()
-print(f"stamped launch {e0.elapsed_time(e1) * 1e3:.1f} us, {tiles} tiles")
-names = ["prologue", "K-loop", "epilogue issue", "vm_wait(sum)", "barrier_wait(sum)", "store drain", "lifetime"]
-for i, n in enumerate(names):
-    v = t[:, :, i]
-    print(f"{n:18s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f} cycles;  per wave index: " +
-          " ".join(f"{v[:, wv].mean():7.0f}" for wv in range(8)))
-print(f"K-loop per K-tile {t[:, :, 1].mean() / (K // 64):.0f} cycles (MFMA alone: 2048)")
+for variant, what in ((1, "product epilogue"), (2, "no statistics loads"), (3, "no stores"), (1, "product epilogue again")):
+    lib.keds_gemm_force_small(variant << 12)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        run(buf)
+    e0.record(); run(buf); e1.record()
+    torch.cuda.synchronize()
+    lib.keds_gemm_force_small(0)
+    t = buf[:tiles * 64].view(tiles, 8, 8).double().cpu()
+    hw = buf[tiles * 64:].view(tiles, 8).cpu()
+    print(f"== {what}: stamped launch {e0.elapsed_time(e1) * 1e3:.1f} us, {tiles} tiles")
+    names = ["prologue", "K-loop", "epilogue issue", "vm_wait(sum)", "barrier_wait(sum)", "store drain"]
+    for i, n in enumerate(names):
+        v = t[:, :, i]
+        print(f"{n:18s} mean {v.mean():9.0f}  min {v.min():9.0f}  max {v.max():9.0f} cycles;  per wave index: " +
+              " ".join(f"{v[:, wv].mean():7.0f}" for wv in range(8)))
+    print(f"K-loop per K-tile {t[:, :, 1].mean() / (K // 64):.0f} cycles (MFMA alone: 2048)")
+    # gaps between consecutive workgroups on one CU: wave 0 of each workgroup, CU = (xcc, se, sh, cu) of HW_ID
+    raw = buf[:tiles * 64].view(tiles, 8, 8).cpu()
+    ids = hw[:, 0]
+    cu_key = ((ids >> 32) & 0xF) * 4096 + ((ids >> 8) & 0xFF) * 1    # xcc | se/sh/cu bits [15:8] of HW_ID
+    ent, end = raw[:, :, 6].min(dim=1).values, raw[:, :, 7].max(dim=1).values
+    gaps, lifes = [], []
+    for key in cu_key.unique().tolist():
+        sel = (cu_key == key).nonzero().flatten()
+        order = sel[ent[sel].argsort()]
+        for a_, b_ in zip(order[:-1].tolist(), order[1:].tolist()):
+            gaps.append(int(ent[b_] - end[a_]))
+        lifes += [int(end[i] - ent[i]) for i in order.tolist()]
+    g = torch.tensor(gaps, dtype=torch.float64); l = torch.tensor(lifes, dtype=torch.float64)
+    print(f"CUs seen {len(cu_key.unique())}; workgroup lifetime (first wave in -> last wave out) mean {l.mean():.0f}; gap to the next workgroup on the same CU: "
+          f"mean {g.mean():.0f} median {g.median():.0f} min {g.min():.0f} max {g.max():.0f} cycles")
