@@ -263,7 +263,10 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
                                                  int m0, int n0, int N, int wm, int wn, int g, int c,
                                                  void* __restrict__ aux2) {
     float rstd[8], nmr[8];
-    const int r0 = 128 * wm + c;
+    int r0 = 128 * wm + c;
+    // opaque to the optimiser: inside the persistent kernel's tile loop the 16 lane-constant store offsets derived from r0
+    // would otherwise be hoisted out of the loop and, with no register to spare, kept in scratch (measured: +48 % time)
+    asm volatile("" : "+v"(r0));
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         const f32x2 cf = *reinterpret_cast<const f32x2*>(side + (r0 + 16 * mi) * 8);
@@ -833,6 +836,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     else
         tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
+
+// NOTE (measured twice in round 1): a PERSISTENT form of this kernel does not pay.  Second attempt, with the fp16 residual
+// stream and the LDS-staged LN epilogue in place: one workgroup per CU walks its tiles; before the LAST K-step of a tile
+// (all LDS reads complete, one extra barrier) it issues the next tile's first two K-tiles, so the prologue (in-kernel
+// stamps: 4-5k of a tile's ~55k cycles, plus ~0.8k between workgroups) lands under that step and the epilogue; the
+// epilogue's stores are younger than those DMA pieces in the in-order vmcnt queue, so "K-tile 0 landed" is
+// vmcnt(8 + stores), not a drain.  Bit-identical output, but at 256 VGPRs the tile loop has no register to spare: LICM
+// hoists the lane-constant store / DMA offsets out of the loop into scratch (+48 % time until they were made opaque with
+// empty asm), and what remains (8 K-loop offsets, 3 fragments: ~20 scratch round trips per tile, each a vmcnt(0)) eats the
+// gain: qkv 205 vs 199 us, fc 302 vs 270 us.  Not kept.
 
 int device_cus_gemm() {
     static int cus = 0;
