@@ -307,6 +307,47 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
     }
 }
 
+// KEDS_EPI_RESID_STATS_F16 in the 256^2 kernel: the same simplifications (every row valid, uniform tile base + 32-bit lane
+// offsets for the read-modify-write of the fp16 stream, bias slice from the LDS side area), all 16 loads of the lane issued
+// before the first is used.
+__device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const char* __restrict__ side, void* __restrict__ out,
+                                                    int m0, int n0, int N, int wm, int wn, int g, int c,
+                                                    keds_stat_t* __restrict__ stats) {
+    const int r0 = 128 * wm + c;
+    char* tile = reinterpret_cast<char*>(out) + ((size_t)m0 * N + n0) * 2;               // wave-uniform
+    const int nl = 64 * wn + 8 * g;
+    f16x8 r[2][8];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+            r[p][mi] = *reinterpret_cast<const f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
+    f32x4 b[2][2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        b[p][0] = *reinterpret_cast<const f32x4*>(side + 2048 + (nl + 32 * p) * 4);
+        b[p][1] = *reinterpret_cast<const f32x4*>(side + 2048 + (nl + 32 * p) * 4 + 16);
+    }
+    keds_stat_t* srow = stats ? stats + 2 * (size_t)(m0 + r0) : nullptr;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f16x8 q = r[p][mi];
+            const f32x4 v0 = f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]} + (acc[2 * p][mi] + b[p][0]);
+            const f32x4 v1 = f32x4{(float)q[4], (float)q[5], (float)q[6], (float)q[7]} + (acc[2 * p + 1][mi] + b[p][1]);
+            *reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u) =
+                f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+            s += sum8(v0, v1);
+            ss += sum8(v0 * v0, v1 * v1);
+        }
+        s = rows_sum(s);                 // the four lanes (g = 0..3) that share the row hold this wave's 64 columns of it
+        ss = rows_sum(ss);
+        if (srow && g == 0) keds_stat_add(srow + 32 * mi, s, ss);
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void small_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -710,11 +751,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
             asm volatile("global_load_dword %0, %1, off" : "=v"(pc) : "v"(cp) : "memory");
         }
     }
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        if (tid >= 256 && bias) {
+            const float* bp = bias + n0 + tid - 256;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+        }
+    }
     // prologue: K-tiles 0 and 1 in flight, retire tile 0
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(0, q);
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(1, q);
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pb)::"memory");
     if constexpr (epi_is_ln(EPI)) {
         // everything older than the 16 DMA pieces has landed
         asm volatile("s_waitcnt vmcnt(16)" : "+v"(st_raw), "+v"(pb), "+v"(pc)::"memory");
@@ -732,6 +780,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
             *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + (tid - 256) * 4) = pb;
             *reinterpret_cast<float*>(smem + SIDE_OFF + 3072 + (tid - 256) * 4) = pc;
         }
+    }
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {            // bias slice of the tile (zeros without a bias) -> side area
+        if (tid >= 256) *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + (tid - 256) * 4) = pb;
     }
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     unsigned long long t_loop0 = 0;
@@ -833,6 +884,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     }
     if constexpr (epi_is_ln(EPI))
         pair_ln_epilogue<EPI, 0>(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c, aux2);
+    else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)
+        pair_resid_epilogue(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c,
+                            reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)));
     else
         tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
