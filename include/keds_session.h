@@ -105,6 +105,19 @@ int keds_comm_init(keds_ctx* ctx, int rank, int world, const void* unique_id);
  * single-GPU search of the whole database. */
 int keds_index_search_sharded(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* stream);
 
+/* ---- host-side BPE tokenizer (no GPU) ------------------------------------------------------
+ * Replaces `tokenize` of src/third_party/open_clip/clip.py:191-227 with SimpleTokenizer (simple_tokenizer.py:62-132):
+ * html.unescape twice, strip, whitespace runs -> one space, lower (full Unicode), regex word pieces, byte symbols,
+ * greedy lowest-rank merges; ids = position in [256 byte symbols | the same + "</w>" | merges | <|startoftext|> <|endoftext|>].
+ * bpe_path: bpe_simple_vocab_16e6.txt(.gz) (first line is a header; not shipped with this library). */
+typedef struct keds_tokenizer keds_tokenizer;
+int keds_tokenizer_create(const char* bpe_path, keds_tokenizer** out);
+void keds_tokenizer_destroy(keds_tokenizer* t);
+int keds_tokenizer_special(const keds_tokenizer* t, int32_t* sot, int32_t* eot);
+/* texts: n NUL-terminated UTF-8 strings -> out int32 [n, context_length] = <|startoftext|> ids <|endoftext|> 0 0 ...;
+ * a row that does not fit is cut with its last id forced to <|endoftext|> (truncate != 0) or is an error (truncate == 0). */
+int keds_tokenize(keds_tokenizer* t, const char* const* texts, int n, int context_length, int truncate, int32_t* out);
+
 #ifdef __cplusplus
 }
 #endif

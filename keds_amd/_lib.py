@@ -150,6 +150,10 @@ SIGNATURES = {
     "keds_mix_normalize": (i32, [vp, vp, f32, f32, vp, vp, vp, i32, i32, vp]),
     "keds_cast_bf16": (i32, [vp, vp, i64, vp]),
     "keds_tower_workspace_bytes": (sz, [i32, i32, i32]),
+    "keds_tokenizer_create": (i32, [C.c_char_p, C.POINTER(vp)]),
+    "keds_tokenizer_destroy": (None, [vp]),
+    "keds_tokenizer_special": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
+    "keds_tokenize": (i32, [vp, C.POINTER(C.c_char_p), i32, i32, i32, vp]),
     "keds_tower_side_rows": (i32, [i32, i32, i32, i32]),
     "keds_side_lane_enable": (i32, [i32]),
     "keds_tower_forward": (i32, [C.POINTER(TowerParams), vp, i32, vp, sz, vp]),

@@ -221,7 +221,50 @@ class SimpleTokenizer:
         return bytearray(self.unsym[c] for c in text).decode("utf-8", errors="replace").replace(self.END, " ")
 
 
+class NativeTokenizer:
+    """The C++ tokenizer of libkeds_hip.so (include/keds_session.h, keds_tokenize): same ids as SimpleTokenizer.encode,
+    whole batches per call."""
+
+    def __init__(self, bpe_path: Optional[str] = None):
+        import ctypes as C
+        from . import _lib
+        bpe_path = bpe_path or os.environ.get("KEDS_BPE_VOCAB", "")
+        if not bpe_path or not os.path.isfile(bpe_path):
+            raise FileNotFoundError("BPE merge table not found: pass bpe_path or set KEDS_BPE_VOCAB to "
+                                    "bpe_simple_vocab_16e6.txt.gz (src/third_party/open_clip/ in the reference)")
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.keds_tokenizer_create(bpe_path.encode(), C.byref(h)), "keds_tokenizer_create")
+        self._h = h
+        sot, eot = C.c_int32(), C.c_int32()
+        _lib.check(self._lib.keds_tokenizer_special(self._h, C.byref(sot), C.byref(eot)), "keds_tokenizer_special")
+        self.sot, self.eot = sot.value, eot.value
+
+    def __call__(self, texts: List[str], context_length: int = 77, truncate: bool = True) -> torch.Tensor:
+        import ctypes as C
+        from . import _lib
+        out = torch.zeros(len(texts), context_length, dtype=torch.int32)
+        if not texts:
+            return out
+        enc = [t.encode("utf-8") for t in texts]
+        if any(b"\x00" in e for e in enc):
+            raise ValueError("text contains a NUL character")
+        arr = (C.c_char_p * len(enc))(*enc)
+        rc = self._lib.keds_tokenize(self._h, arr, len(enc), context_length, 1 if truncate else 0, out.data_ptr())
+        _lib.check(rc, "keds_tokenize")
+        return out
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.keds_tokenizer_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 _tokenizer: Optional[SimpleTokenizer] = None
+_native: Optional[NativeTokenizer] = None
 
 
 def _get_tokenizer(bpe_path: Optional[str] = None) -> SimpleTokenizer:
@@ -235,9 +278,15 @@ def tokenize(texts: Union[str, List[str]], context_length: int = 77, truncate: b
              bpe_path: Optional[str] = None) -> torch.Tensor:
     """[n, context_length] int32: <|startoftext|> ids <|endoftext|> 0 0 ...  (open_clip/clip.py:191-227).
     Over-long rows are cut to the context length with the last id forced to <|endoftext|>, or raise with
-    truncate=False."""
+    truncate=False.  Runs in the C++ tokenizer of libkeds_hip.so (keds_tokenize); KEDS_TOKENIZER=python selects the
+    pure-Python SimpleTokenizer (the checker of the tests; also provides decode())."""
     if isinstance(texts, str):
         texts = [texts]
+    if os.environ.get("KEDS_TOKENIZER", "native") != "python":      # the C++ tokenizer is the product path
+        global _native
+        if _native is None or bpe_path:
+            _native = NativeTokenizer(bpe_path)
+        return _native(list(texts), context_length, truncate)
     tk = _get_tokenizer(bpe_path)
     sot, eot = tk.encoder["<|startoftext|>"], tk.encoder["<|endoftext|>"]
     out = torch.zeros(len(texts), context_length, dtype=torch.int)

@@ -16,7 +16,8 @@ BPE = os.environ.get("KEDS_BPE_VOCAB", "/root/reference/src/third_party/open_cli
 
 
 @pytest.mark.skipif(not os.path.isfile(BPE), reason="BPE merge table (bpe_simple_vocab_16e6.txt.gz) not available")
-def test_tokenizer_matches_reference_ids():
+def test_tokenizer_matches_reference_ids(monkeypatch):
+    monkeypatch.setenv("KEDS_TOKENIZER", "python")                         # the pure-Python SimpleTokenizer (the checker)
     g = json.load(open(golden_path("tokenizer.json")))
     got = kclip.tokenize(g["texts"], bpe_path=BPE)
     assert got.dtype == torch.int32 and tuple(got.shape) == (len(g["texts"]), 77)
@@ -28,6 +29,90 @@ def test_tokenizer_matches_reference_ids():
     with pytest.raises(RuntimeError):
         kclip.tokenize(["word " * 100], truncate=False, bpe_path=BPE)
     assert int(kclip.tokenize(["word " * 100], bpe_path=BPE)[0, 76]) == 49407
+
+
+def _nasty_texts(n, seed):
+    import random
+    rnd = random.Random(seed)
+    pools = ["abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ", "0123456789",
+             " \t\n\r\x0b\x0c\x1c\x1d\x1e\x1f\x85\xa0\u1680\u2000\u2009\u2028\u2029\u202f\u205f\u3000",
+             "'`\".,;:!?-_()[]{}<>|*&#@/\\^~+=%$", "ΣσςΆέήίόύώΑΒΓabcİıǅǆßẞÀÉÎÕÜçñſ", "ʰʱ\u0345\u00ad\u0301\u0307’·\u200d",
+             "中文日本語한국어العربيةעבריתहिन्दीไทย", "😀🎉🚀👍🏽\U0001F1FA\U0001F1F8①②③ⅣⅤ½¾", "٠١०१１２①²³"]
+    ents = ["&amp;", "&lt;", "&gt", "&quot;", "&#39;", "&#x27;", "&#X41", "&#65", "&#0;", "&#128;", "&#x80;", "&#xD800;", "&#x110000;",
+            "&#99999999999999999999;", "&notit;", "&notin;", "&amp;amp;", "&ampx", "&nbsp;", "&copy", "&copyright", "&zzz;", "&#", "&#x",
+            "&#xg", "&;", "& ", "&&amp;", "&AMP;", "&Aacute", "&acE;", "&NotEqualTilde;", "<|startoftext|>", "<|endoftext|>",
+            "<|STARTOFTEXT|>", "<|ſtartoftext|>", "'s", "'ſ", "'T", "'re", "'VE", "'ll", "'d", "'m", "&ampΣ", "&amé;"]
+    out = []
+    for _ in range(n):
+        parts = []
+        for _ in range(rnd.randint(0, 14)):
+            k = rnd.random()
+            if k < 0.2:
+                parts.append(rnd.choice(ents))
+            elif k < 0.25:
+                parts.append(chr(rnd.choice([rnd.randint(1, 0xD7FF), rnd.randint(0xE000, 0x2FFFF)])))
+            else:
+                pool = rnd.choice(pools)
+                parts.append("".join(rnd.choice(pool) for _ in range(rnd.randint(1, 6))))
+        out.append("".join(parts))
+    return out
+
+
+def _synthetic_merges(path, n_merges, seed):
+    """A merge table in the file format of bpe_simple_vocab_16e6.txt (header line, then `a b` per line) over the byte
+    stand-ins: random, but a valid input for both tokenizers (ids are positions, so any table works)."""
+    import random
+    rnd = random.Random(seed)
+    sym = kclip._byte_symbols()
+    units = [sym[b] for b in range(256)]
+    units += [u + "</w>" for u in units]
+    lines, seen = ["#version: synthetic"], set()
+    while len(lines) <= n_merges:
+        a, b = rnd.choice(units), rnd.choice(units)
+        if a.endswith("</w>") or (a, b) in seen:
+            continue
+        seen.add((a, b))
+        lines.append(f"{a} {b}")
+        units.append(a + b)
+    with open(path, "w", encoding="utf-8") as f:
+        f.write("\n".join(lines) + "\n")
+
+
+def test_native_tokenizer_equals_python_tokenizer_on_nasty_text(tmp_path):
+    """keds_tokenize (C++: tokenizer.cpp + the generated Unicode / HTML tables) against SimpleTokenizer, id for id, on
+    text built to hit every rule: HTML references (valid, invalid, prefixes, double escaping), every kind of white space,
+    Final_Sigma, multi-code-point lower-casing, combining marks, the IGNORECASE corner cases (U+0345, U+017F), astral
+    characters, the special-token literals.  Synthetic merge table: runs anywhere."""
+    bpe = tmp_path / "merges.txt"
+    _synthetic_merges(str(bpe), 3000, seed=1)
+    py, nat = kclip.SimpleTokenizer(str(bpe)), kclip.NativeTokenizer(str(bpe))
+    assert (nat.sot, nat.eot) == (py.encoder["<|startoftext|>"], py.encoder["<|endoftext|>"]) == (512 + 3001, 512 + 3002)
+    texts = [t for t in _nasty_texts(4000, seed=5) if "\x00" not in t] + ["", " ", "a", "word " * 100]
+    got = nat(texts)
+    for t, row in zip(texts, got.tolist()):
+        ids = [nat.sot] + py.encode(t) + [nat.eot]
+        if len(ids) > 77:
+            ids = ids[:77]
+            ids[-1] = nat.eot
+        assert row == ids + [0] * (77 - len(ids)), repr(t)
+    with pytest.raises(RuntimeError, match="too long"):
+        nat(["word " * 100], truncate=False)
+    assert tuple(nat([]).shape) == (0, 77)
+
+
+@pytest.mark.skipif(not os.path.isfile(BPE), reason="BPE merge table (bpe_simple_vocab_16e6.txt.gz) not available")
+def test_native_tokenizer_matches_reference_ids(monkeypatch):
+    g = json.load(open(golden_path("tokenizer.json")))
+    monkeypatch.setenv("KEDS_TOKENIZER", "native")
+    assert kclip.tokenize(g["texts"], bpe_path=BPE).tolist() == g["tokens"]        # the default path of tokenize()
+    nat, py = kclip.NativeTokenizer(BPE), kclip.SimpleTokenizer(BPE)
+    texts = [t for t in _nasty_texts(2000, seed=9) if "\x00" not in t]
+    for t, row in zip(texts, nat(texts).tolist()):
+        ids = ([nat.sot] + py.encode(t) + [nat.eot])
+        if len(ids) > 77:
+            ids = ids[:77]
+            ids[-1] = nat.eot
+        assert row == ids + [0] * (77 - len(ids)), repr(t)
 
 
 def test_tokenizer_needs_the_merge_table(monkeypatch):
