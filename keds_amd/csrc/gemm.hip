@@ -901,6 +901,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // empty asm), and what remains (8 K-loop offsets, 3 fragments: ~20 scratch round trips per tile, each a vmcnt(0)) eats the
 // gain: qkv 205 vs 199 us, fc 302 vs 270 us.  Not kept.
 
+// NOTE (measured, round 1): TWO half-size workgroups per CU do not pay either.  256 threads (2 x 2 waves, 128 x 64 per wave),
+// tile 256 x 128, one 48 KiB LDS operand buffer per K-tile with all 24 fragments of the K-tile in registers (reads of
+// K-tile t -> barrier -> DMA of t+1 into the same buffer under the MFMAs of t), two such workgroups per CU (2 x 52 KiB LDS,
+// 8 waves x 246 VGPRs) started half a tile apart so that one's prologue / epilogue / DMA wait runs under the other's
+// MFMAs.  Bit-identical output; qkv 201 us vs 178 us, c_fc 271 vs 246 us (scheduled with sched_group_barrier like the
+// 256^2 kernel; 15 % behind before that): 50 % more DMA bytes per flop and two barriers per K-tile cost more than the
+// hidden fixed costs return.
+
 int device_cus_gemm() {
     static int cus = 0;
     if (cus == 0) {
