@@ -260,6 +260,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model, N, D, k)
+        try:                                   # RCCL writes its version banner through C stdio, which flushes at exit:
+            import ctypes                      # push it out now so that the JSON line is the last line on stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
