@@ -20,7 +20,8 @@ constexpr int TM = 256, TN = 256, TKB = 128;         // K-tile = 128 fp8 = 128 b
 constexpr int OP_BYTES = 256 * 128;                  // 32 KiB per operand per K-tile
 constexpr int SC_BYTES = 256 * 4;                    // scale dwords of one operand per K-tile
 constexpr int PBUF_BYTES = 2 * OP_BYTES + 2 * SC_BYTES;   // X | W | sX | sW
-constexpr int LDS_BYTES = 2 * PBUF_BYTES;            // 132 KiB
+constexpr int SIDE_OFF = 2 * PBUF_BYTES;             // side area of the LN epilogues: {rstd, -mean rstd}[256] | bias'[256] | colsum[256]
+constexpr int LDS_BYTES = SIDE_OFF + 4096;           // 136 KiB
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -185,9 +186,39 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
         for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int np = K / TKB;                                        // >= 2
+    // LN epilogues (cf. gemm_bt_pair_kernel): thread t < 256 fetches row t's statistics, thread 256 + j column j's bias' and
+    // column sum, BEFORE the first DMA piece; they become the side-area image while K-tile 0 is in flight
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    [[maybe_unused]] u32x4 st_raw = u32x4{0, 0, 0, 0};
+    [[maybe_unused]] float pb = 0.f, pc = 0.f;
+    if constexpr (EPI == 1 || EPI == 2) {
+        if (tid < 256) {
+            const keds_stat_t* sp = reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)(m0 + tid);
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st_raw) : "v"(sp) : "memory");
+        } else {
+            const float* bp = bias + n0 + tid - 256;
+            const float* cp = bp + N;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pc) : "v"(cp) : "memory");
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(0, q);
     issue_scales(0);
+    if constexpr (EPI == 1 || EPI == 2) {
+        asm volatile("s_waitcnt vmcnt(8)" : "+v"(st_raw), "+v"(pb), "+v"(pc)::"memory");   // older than the (8 or 9) DMA pieces
+        if (tid < 256) {
+            const float invk_ = 1.0f / (float)K;
+            const float mean = keds_stat_value((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0])) * invk_;
+            const float ss = keds_stat_value((keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]));
+            const float rsd = rsqrtf(fmaxf(ss * invk_ - mean * mean, 0.f) + 1e-5f);
+            *reinterpret_cast<f32x2*>(smem + SIDE_OFF + tid * 8) = f32x2{rsd, -mean * rsd};
+        } else {
+            *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + (tid - 256) * 4) = pb;
+            *reinterpret_cast<float*>(smem + SIDE_OFF + 3072 + (tid - 256) * 4) = pc;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 
     auto load_frag = [&](const char* buf, int row_off) {
         i32x8 v;
@@ -292,17 +323,14 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
     }
     // ---- epilogue: lane (g,c) owns rows m0 + 128*wm + 16*mi + c, columns n0 + 64*wn + 32*pp + 8*g + 0..7.  The four lanes
     // g = 0..3 of a row hold exactly one 32-column MX block per pp, so block amax / row sums are two xor-shuffles.
-    const float invk = 1.0f / (float)K;
     float rstd[8], nmr[8];
     if constexpr (EPI == 1 || EPI == 2) {
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
             const int m = m0 + 128 * wm + 16 * mi + c;
-            const keds_stat_t* strow = reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)m;
-            const float sm = keds_stat_value(strow[0]), ss = keds_stat_value(strow[1]);
-            const float mean = sm * invk;
-            rstd[mi] = rsqrtf(fmaxf(ss * invk - mean * mean, 0.f) + 1e-5f);
-            nmr[mi] = -mean * rstd[mi];
+            const f32x2 cf = *reinterpret_cast<const f32x2*>(smem + SIDE_OFF + (128 * wm + 16 * mi + c) * 8);
+            rstd[mi] = cf[0];
+            nmr[mi] = cf[1];
             if (aux2 && n0 == 0 && wn == 0 && g == 0) keds_stat_zero(reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)m);
         }
     }
@@ -313,13 +341,15 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
     for (int pp = 0; pp < 2; ++pp) {
         const int n = n0 + 64 * wn + 32 * pp + 8 * g;
         f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0, c0 = b0, c1 = b0;
-        if (bias) {
+        if constexpr (EPI == 1 || EPI == 2) {
+            const char* sb = smem + SIDE_OFF + 2048 + (64 * wn + 32 * pp + 8 * g) * 4;
+            b0 = *reinterpret_cast<const f32x4*>(sb);
+            b1 = *reinterpret_cast<const f32x4*>(sb + 16);
+            c0 = *reinterpret_cast<const f32x4*>(sb + 1024);
+            c1 = *reinterpret_cast<const f32x4*>(sb + 1024 + 16);
+        } else if (bias) {
             b0 = *reinterpret_cast<const f32x4*>(bias + n);
             b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
-        }
-        if constexpr (EPI == 1 || EPI == 2) {
-            c0 = *reinterpret_cast<const f32x4*>(bias + N + n);
-            c1 = *reinterpret_cast<const f32x4*>(bias + N + n + 4);
         }
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) {
