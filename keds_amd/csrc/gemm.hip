@@ -787,15 +787,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     unsigned long long t_loop0 = 0;
     if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
-    bf16x8 xa[8], wa[4], xb[8], wb[4];
+    bf16x8 xf[8], wa[4], wb[4];
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) wa[ni] = *reinterpret_cast<const bf16x8*>(smem + wrow + slot0 + ni * 2048);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(smem + xrow + slot0 + mi * 2048);
+    for (int mi = 0; mi < 8; ++mi) xf[mi] = *reinterpret_cast<const bf16x8*>(smem + xrow + slot0 + mi * 2048);
 
     // One K-step: 32 MFMAs from (xc, wc); the 12 fragment reads of the NEXT K-step go to (xn, wn_) from
     // buffer `nb` at chunk offset `nslot`; with ISSUE one DMA piece of K-tile `ip` follows each MFMA group.
-#define KEDS_PAIR_STEP(xc, wc, xn, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                                  \
+    // X fragments are refilled IN PLACE: xf[mi] is read by the four MFMAs of group mi only, so the next K-step's xf[mi] is
+    // loaded right behind them (a full K-step before its use); W fragments (read by every group) stay double-buffered.
+    // 80 fragment registers instead of 96.
+#define KEDS_PAIR_STEP(wc, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                                          \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if constexpr (SYNC && STAMP != 0) {                                                                    \
@@ -812,25 +815,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) {                                                     \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
-                acc[ni][mi] = mma<epi_f16(EPI)>(wc[ni], xc[mi], acc[ni][mi]);   \
+                acc[ni][mi] = mma<epi_f16(EPI)>(wc[ni], xf[mi], acc[ni][mi]);                                  \
             if constexpr (PREFETCH) {                                                                          \
                 if (mi == 0) {                                                                                 \
                     _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                           \
                         wn_[ni] = *reinterpret_cast<const bf16x8*>((nb) + wrow + (nslot) + ni * 2048);         \
-                    xn[0] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot));                           \
                 }                                                                                              \
-                if (mi < 7) xn[mi + 1] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + (mi + 1) * 2048); \
+                xf[mi] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + mi * 2048);                  \
             }                                                                                                  \
             if constexpr (ISSUE) issue((ip), mi);                                                              \
         }                                                                                                      \
         if constexpr (PREFETCH) {                                                                              \
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x100, 5, 0);                                                 \
             if constexpr (ISSUE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                            \
             KEDS_PAIR_G(ISSUE) KEDS_PAIR_G(ISSUE) KEDS_PAIR_G(ISSUE) KEDS_PAIR_G(ISSUE) KEDS_PAIR_G(ISSUE)     \
-            KEDS_PAIR_G(ISSUE)                                                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
-            if constexpr (ISSUE) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                            \
+            KEDS_PAIR_G(ISSUE) KEDS_PAIR_G(ISSUE)                                                              \
         }                                                                                                      \
     }
 #define KEDS_PAIR_G(ISSUE)                                                                                     \
@@ -842,16 +842,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     for (; p + 2 < np; ++p) {                                      // steady state: tile p+2 exists
         const char* cb = smem + (p & 1) * PBUF_BYTES;               // buffer of tile p
         const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;         // buffer of tile p+1
-        KEDS_PAIR_STEP(xa, wa, xb, wb, cb, slot1, false, false, 0, true)          // K-step 2p
-        KEDS_PAIR_STEP(xb, wb, xa, wa, ob, slot0, true, true, p + 2, true)       // K-step 2p+1
+        KEDS_PAIR_STEP(wa, wb, cb, slot1, false, false, 0, true)          // K-step 2p
+        KEDS_PAIR_STEP(wb, wa, ob, slot0, true, true, p + 2, true)       // K-step 2p+1
     }
     {                                                              // tile np-2: nothing left to issue
         const char* cb = smem + (p & 1) * PBUF_BYTES;
         const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;
-        KEDS_PAIR_STEP(xa, wa, xb, wb, cb, slot1, false, false, 0, true)
-        KEDS_PAIR_STEP(xb, wb, xa, wa, ob, slot0, true, false, 0, true)
-        KEDS_PAIR_STEP(xa, wa, xb, wb, ob, slot1, false, false, 0, true)          // tile np-1
-        KEDS_PAIR_STEP(xb, wb, xa, wa, ob, slot0, false, false, 0, false)
+        KEDS_PAIR_STEP(wa, wb, cb, slot1, false, false, 0, true)
+        KEDS_PAIR_STEP(wb, wa, ob, slot0, true, false, 0, true)
+        KEDS_PAIR_STEP(wa, wb, ob, slot1, false, false, 0, true)          // tile np-1
+        KEDS_PAIR_STEP(wb, wa, ob, slot0, false, false, 0, false)
     }
 #undef KEDS_PAIR_STEP
 #undef KEDS_PAIR_G
