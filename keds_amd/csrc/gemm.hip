@@ -899,7 +899,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // vmcnt(8 + stores), not a drain.  Bit-identical output, but at 256 VGPRs the tile loop has no register to spare: LICM
 // hoists the lane-constant store / DMA offsets out of the loop into scratch (+48 % time until they were made opaque with
 // empty asm), and what remains (8 K-loop offsets, 3 fragments: ~20 scratch round trips per tile, each a vmcnt(0)) eats the
-// gain: qkv 205 vs 199 us, fc 302 vs 270 us.  Not kept.
+// gain: qkv 205 vs 199 us, fc 302 vs 270 us.  A third build on top of the in-place X fragments (16 registers freed, 31 scratch
+// operations left in the tile loop) was no better: qkv 206 vs 190 us, fc 282 vs 264 us.  Issuing the next tile's 16 DMA pieces
+// costs the same ~1-1.5k cycles of vector issue wherever it sits, the extra barrier, the drain before the side-area staging
+// and the static tile -> CU assignment take the rest.  Not kept.
 
 // NOTE (measured, round 1): TWO half-size workgroups per CU do not pay either.  256 threads (2 x 2 waves, 128 x 64 per wave),
 // tile 256 x 128, one 48 KiB LDS operand buffer per K-tile with all 24 fragments of the K-tile in registers (reads of
