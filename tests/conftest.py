@@ -14,6 +14,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The suite goes through libkeds_hip.so everywhere (there is no CPU fallback): build it in-tree if a fresh checkout
+    has not done so yet (hipcc cross-compiles without a GPU; on the GPU box the prebuilt file travels with the snapshot)."""
+    from keds_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+
+
 def golden_path(name):
     return os.path.join(GOLDEN, name)
 
