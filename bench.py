@@ -240,7 +240,7 @@ def main():
                                    "over a synthetic unit-norm 0.5M x 768 database",
                        "batch_per_gpu": B, "global_batch": B * world, "db_rows": N, "dim": D, "k": k,
                        "db_shards": world, "parallelism": f"dp{world} encoders + {world}-way row-sharded scan"},
-            "roofline": {"kernel": "gemm_bt_kernel (all ViT GEMMs of the step)", "bound": "mfma",
+            "roofline": {"kernel": "gemm_bt_pair_kernel (256x256 tiles; all main-lane ViT GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
                          "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                          "traffic": pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
                          "over the 256x256 GEMM launches)", "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
