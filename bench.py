@@ -35,6 +35,8 @@ _PER_TOKEN_TAIL = 1024 * 1024 + 2 * 1024 * 4096                     # out-proj +
 GEMM_MAC_PER_IMAGE = (256 * 588 * 1024 + 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL + 1 * _PER_TOKEN_TAIL
                       + 1024 * 768)
 PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_FP8_TFLOPS = 5000.0      # dense MX-fp8 MFMA (--precision fp8 only; the headline is bf16 / fp16)
+PEAK_FP8_MEASURED_TFLOPS = 3400.0    # register-only v_mfma_scale_f32_16x16x128_f8f6f4 loop (profiles/r01_microbench.txt)
 PEAK_BF16_MEASURED_TFLOPS = 2060.0   # tools/micro/mfma_peak.hip on the gpurun MI355X
 PEAK_HBM_MEASURED_GBPS = 7150.0      # tools/micro/hbm_stream.hip (read-only)
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md
@@ -222,6 +224,9 @@ def main():
             tower_mac = 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL
             gemm_flops -= 2.0 * tower_mac * B * psteps * side_rows / (B * 257.0)
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        fp8 = args.precision == "fp8"
+        peak_tf = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS              # dense MFMA peak of the operand type
+        peak_meas_tf = PEAK_FP8_MEASURED_TFLOPS if fp8 else PEAK_BF16_MEASURED_TFLOPS
         # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B); a search issues two
         # scan launches (threshold pass over the first 1/16 of the rows + the full candidate pass): both are charged
         # to the time, only the single pass to the bytes
@@ -240,13 +245,13 @@ def main():
                                    "over a synthetic unit-norm 0.5M x 768 database",
                        "batch_per_gpu": B, "global_batch": B * world, "db_rows": N, "dim": D, "k": k,
                        "db_shards": world, "parallelism": f"dp{world} encoders + {world}-way row-sharded scan"},
-            "roofline": {"kernel": "gemm_bt_pair_kernel (256x256 tiles; all main-lane ViT GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
-                         "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+            "roofline": {"kernel": ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane ViT GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
+                         "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
                          "traffic": pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
                          "over the 256x256 GEMM launches)", "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          # practical ceiling of this chip, measured (profiles/r01_microbench.txt): a register-only
                          # v_mfma_f32_16x16x32_bf16 loop sustains 2.06 PFLOP/s (clock ~2.0 GHz under MFMA load)
-                         "peak_measured": PEAK_BF16_MEASURED_TFLOPS, "frac_of_measured": ach / PEAK_BF16_MEASURED_TFLOPS},
+                         "peak_measured": peak_meas_tf, "frac_of_measured": ach / peak_meas_tf},
             "roofline_scan": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_ach,
                               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": scan_ach / PEAK_HBM_GBPS,
                               "traffic": pmc_traffic("scan_topk_kernel<768, 16", B, N, world),
