@@ -247,7 +247,7 @@ def main():
                        "db_shards": world, "parallelism": f"dp{world} encoders + {world}-way row-sharded scan"},
             "roofline": {"kernel": ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane ViT GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
                          "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
-                         "traffic": pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
+                         "traffic": None if fp8 else pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
                          "over the 256x256 GEMM launches)", "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          # practical ceiling of this chip, measured (profiles/r01_microbench.txt): a register-only
                          # v_mfma_f32_16x16x32_bf16 loop sustains 2.06 PFLOP/s (clock ~2.0 GHz under MFMA load)
