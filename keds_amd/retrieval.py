@@ -95,6 +95,27 @@ def compose_query_features(model: CLIP, stream_image: KnowledgeStream, stream_te
             "tokens_image_stream": tok_a, "tokens_text_stream": tok_b}
 
 
+def all_gather_features(features: torch.Tensor, group=None) -> torch.Tensor:
+    """Multi-GPU evaluation glue (gallery ranking): every rank encoded its slice of the gallery (or of the
+    queries); returns the row-wise concatenation in rank order on every rank, ragged slices allowed.  The metric functions
+    then run on the full matrices exactly as on one GPU -- galleries are 1e3..1e5 rows, the exchange is one small
+    collective (the 0.5 M-row databases stay sharded: `ShardedFlatIndex`)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return features
+    world = dist.get_world_size(group)
+    n = torch.tensor([features.shape[0]], dtype=torch.int64, device=features.device)
+    counts = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(counts, n, group=group)
+    counts = [int(c.item()) for c in counts]
+    pad = max(counts)
+    buf = features.new_zeros((pad,) + tuple(features.shape[1:]))
+    buf[:features.shape[0]] = features
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return torch.cat([p[:c] for p, c in zip(parts, counts)])
+
+
 def _intern(names: Sequence[str], table: Dict[str, int]) -> np.ndarray:
     out = np.empty(len(names), dtype=np.int32)
     for i, n in enumerate(names):

@@ -206,6 +206,12 @@ def _gloo_worker(rank, world, port, out):
         D2, I2, R2 = exchange_merge_gather(dp, ip + lo, rows_p, 4, _lib.METRIC_L2, group=None)
         Dg2, Ig2 = O.flat_l2_search(db, qall[rank * 4:(rank + 1) * 4], 16)
         ok = ok and bool(torch.equal(I2, Ig2) and torch.allclose(D2, Dg2) and torch.equal(R2, db[Ig2.reshape(-1)].reshape(4, 16, 64)))
+        # evaluation glue: ragged per-rank gallery slices gathered in rank order, then the metric on the full matrices
+        from keds_amd.retrieval import all_gather_features
+        gal = O.synth_database(101, 64, seed=12)
+        cut = 37
+        mine = gal[:cut] if rank == 0 else gal[cut:]
+        ok = ok and bool(torch.equal(all_gather_features(mine), gal))
         out[rank] = ok
     finally:
         dist.destroy_process_group()
