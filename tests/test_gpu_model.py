@@ -210,6 +210,35 @@ def test_side_lane_for_remainder_rows_changes_no_bit(precision):
         assert torch.equal(o, off)
 
 
+def test_batch_size_sweep_lane_split_and_dispatch_boundaries():
+    """ViT-L/14 at batch sizes that land on every dispatch rule of the tower (128^2 / 256^2 tiles, rows split over the two
+    lanes or not, fp8 main rows + fp16 remainder rows): lane on == lane off bit for bit, finite, and image 0's embedding
+    independent of the batch it travels in (different kernels per batch size: close, not bit-equal)."""
+    from keds_amd import _lib
+    lib = _lib.load()
+    sd = O.synth_clip_state_dict(**VITL, seed=7)
+    m = keds_amd.build_model(sd, fp16=False).cuda()
+    del sd
+    base = torch.from_numpy(O.synth_tensor("imgs", [200, 3, 224, 224], 1.0).numpy()).cuda()
+    try:
+        for precision, cos_min in (("bf16", 0.9999), ("fp8", 0.995)):
+            m.set_precision(precision)
+            first, splits = None, set()
+            for B in (1, 2, 33, 64, 127, 128, 129, 200):
+                lib.keds_side_lane_enable(1)
+                on = m.encode_image(base[:B]).clone()
+                splits.add(lib.keds_tower_side_rows(1024, 257, B, int(precision == "fp8")) > 0)
+                lib.keds_side_lane_enable(0)
+                off = m.encode_image(base[:B]).clone()
+                assert torch.equal(on, off) and torch.isfinite(on).all(), (precision, B)
+                first = on[:1].clone() if first is None else first
+                c = float(torch.nn.functional.cosine_similarity(on[:1], first).item())
+                assert c >= cos_min, (precision, B, c)
+            assert splits == {True, False} or precision == "fp8"
+    finally:
+        lib.keds_side_lane_enable(1)
+
+
 def test_side_lane_under_foreign_stream_and_graph_capture():
     """The two-lane tower pass forks from / joins to whatever stream the caller is on: same bits on a non-default torch
     stream, and the whole encode_image can be captured into a graph (the side stream joins the capture through its fork
