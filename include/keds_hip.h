@@ -30,10 +30,19 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 3
+#define KEDS_ABI_VERSION 4
 
 int keds_abi_version(void);
 const char* keds_last_error(void);
+
+/* ---- numerics guard of the fast tower flow ---------------------------------------------------------------------
+ * The default tower flow keeps the residual stream in fp16 and evaluates LayerNorm inside the GEMMs on un-centred rows.
+ * That is accurate while |row mean| / row std stays small (CLIP: a few) and the stream stays inside the fp16 range.
+ * While a device flag is registered for the calling thread, every LayerNorm-consuming GEMM it enqueues sets *flag = 1 if
+ * it meets a row with |mean| / std > 32 or non-finite statistics; the host reads the flag after the pass and re-runs it
+ * on the fp32-stream flow (stand-alone LayerNorm: unfolded weights) -- keds_amd.CLIP does so automatically.
+ * nullptr unregisters.  The flag is only ever set, never cleared, by the library. */
+int keds_numerics_guard_set(int32_t* device_flag);
 
 /* ---- profiling of kernel classes with hipEvents on the launch stream -------------
  * bench.py switches this on over its timed region to get the dominant kernel's average
@@ -58,29 +67,44 @@ int keds_prof_read(int klass, double* total_ms, int64_t* launches);  /* synchron
 
 #define KEDS_SCAN_STAGE_KEYS 32     /* keys per packed stage */
 #define KEDS_SCAN_MAX_QUERIES 128   /* queries per scan launch (one query block) */
-#define KEDS_SCAN_LIST 16           /* per-lane exact list depth == max k of the fast path */
-#define KEDS_SCAN_CAND 64           /* candidates re-ranked in fp32 per query */
+#define KEDS_SCAN_LIST 16           /* per-lane exact list depth */
+#define KEDS_SCAN_CAND 64           /* candidates re-ranked in fp32 per query for k <= 16 (256 for larger k) */
+#define KEDS_SCAN_MAX_K 128         /* largest k of keds_index_search_packed */
 
 /* timing-only ablation hook of the D=768 scan kernel (0 = product path) */
 int keds_scan_debug(int variant);
 
-/* bytes of the packed bf16 scan image for n rows of dimension dim (dim % 128 == 0) */
+/* bytes of the packed bf16 scan image for n rows of dimension dim (dim % 128 == 0); the image ends with a 128-byte
+ * trailer holding max ||bf16(x)||, max ||x - bf16(x)||, max ||x|| over the rows (the search certificate's bounds) */
 size_t keds_index_packed_bytes(int64_t n, int dim);
 
 /* `.add`: build the scan image from fp32 rows [n, dim] (device).  The image is the exact
  * LDS layout the scan kernel streams: per stage of 32 keys, XOR-swizzled bf16 rows followed
  * by 32 fp32 bias terms (-0.5*||x||^2 for L2, 0 for IP; -inf for rows >= n). */
 int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream);
+/* chunked `.add`: `packed` already holds the image of rows [0, old_n) of `db` (same buffer, sized for n rows); pack rows
+ * [old_n, n) only (the stage that old_n falls into is rewritten), keeping the bounds of the earlier rows. */
+int keds_index_pack_append(const float* db, int64_t old_n, int64_t n, int dim, int metric, void* packed, void* stream);
 
-/* workspace bytes for keds_index_search_packed with up to `nq` queries */
+/* workspace bytes for keds_index_search_packed(_ex): nq queries against n rows, top-k.  The two-argument form is sized
+ * for k <= 16 over at most 4 M rows. */
+size_t keds_index_search_workspace_bytes_ex(int nq, int dim, int64_t n, int k);
 size_t keds_index_search_workspace_bytes(int nq, int dim);
 
-/* `.search`: exact top-k (k <= 16) of nq fp32 queries [nq, dim] against the index.
+/* `.search`: exact top-k (k <= KEDS_SCAN_MAX_K) of nq fp32 queries [nq, dim] against the index.
  *   normalize_q != 0 : L2-normalise the queries first (src/eval_utils.py:162)
  *   D [nq,k] fp32, I [nq,k] int64 (row ids offset by id_base, -1 if fewer than k rows)
  *   rows_out (nullable) [nq,k,dim] fp32 : gathered rows db[I]  (src/eval_utils.py:171-172,179-180)
- * Pipeline: bf16 MFMA scan with per-lane exact top-16 lists -> merge to 64 candidates ->
- * exact fp32 re-rank from `db` -> top-k.  `db` is the fp32 matrix given to keds_index_pack. */
+ * Pipeline: bf16 MFMA scan with per-lane exact top-16 lists -> merge to 64 (k > 16: 256) candidates -> exact fp32
+ * re-rank from `db` -> top-k -> CERTIFICATE per query: the k-th candidate's exact score minus a rigorous bound on the bf16
+ * scan error must beat the best score any non-candidate row can have; queries that fail it (near-duplicate clusters
+ * wider than the candidate list) are answered by an exact fp32 pass over all rows (IndexFlatL2 semantics in every case).
+ * `db` is the fp32 matrix given to keds_index_pack.  status (nullable, device int32[2]): += {queries certified from the
+ * candidates, queries answered by the exact pass}. */
+int keds_index_search_packed_ex(const void* packed, const float* db, int64_t n, int dim, int metric,
+                      const float* queries, int nq, int normalize_q, int k, int64_t id_base,
+                      float* D, int64_t* I, float* rows_out,
+                      void* workspace, size_t workspace_bytes, int32_t* status, void* stream);
 int keds_index_search_packed(const void* packed, const float* db, int64_t n, int dim, int metric,
                       const float* queries, int nq, int normalize_q, int k, int64_t id_base,
                       float* D, int64_t* I, float* rows_out,

@@ -17,14 +17,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 
 # ---- constants mirrored from keds_hip.h ------------------------------------------------------
-ABI_VERSION = 3
+ABI_VERSION = 4
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
 EPI_LN_BIAS_BF16_H, EPI_LN_QGELU_BF16_H = 10, 11
 FP8_EPI_BIAS_BF16, FP8_EPI_LN_BIAS_BF16, FP8_EPI_LN_QGELU_MX, FP8_EPI_RESID_STATS_MX, FP8_EPI_RESID_STATS_MX_H = range(5)
 PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
-SCAN_MAX_K = 16
+SCAN_MAX_K = 128
 
 vp, i32, i64, f32, sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 
@@ -107,13 +107,17 @@ SIGNATURES = {
     # ---- keds_hip.h (stateless) -----------------------------------------------------------------
     "keds_abi_version": (i32, []),
     "keds_last_error": (C.c_char_p, []),
+    "keds_numerics_guard_set": (i32, [vp]),
     "keds_prof_enable": (i32, [i32]),
     "keds_prof_reset": (i32, []),
     "keds_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(i64)]),
     "keds_scan_debug": (i32, [i32]),
     "keds_index_packed_bytes": (sz, [i64, i32]),
     "keds_index_pack": (i32, [vp, i64, i32, i32, vp, vp]),
+    "keds_index_pack_append": (i32, [vp, i64, i64, i32, i32, vp, vp]),
     "keds_index_search_workspace_bytes": (sz, [i32, i32]),
+    "keds_index_search_workspace_bytes_ex": (sz, [i32, i32, i64, i32]),
+    "keds_index_search_packed_ex": (i32, [vp, vp, i64, i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, sz, vp, vp]),
     "keds_index_search_packed": (i32, [vp, vp, i64, i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, sz, vp]),
     "keds_topk_merge_parts": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
     "keds_gather_rows": (i32, [vp, i32, vp, i64, vp, vp]),
@@ -248,15 +252,16 @@ _gemm_ws = {}
 
 
 def ensure_gemm_workspace(device=None) -> None:
-    """Register a 32 MiB split-K scratch buffer for the current device (idempotent)."""
+    """Register an 8 MiB split-K scratch buffer for `device` (idempotent; one registration per device).  Only direct
+    `ops.gemm_bt` calls use it (one stream at a time per device): towers and handles split K into their own workspace."""
     require_gpu()
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
     if key not in _gemm_ws:
-        buf = torch.empty(32 << 20, dtype=torch.uint8, device=dev)
-        _gemm_ws.clear()                      # one registration at a time (the library keeps a single pointer)
+        buf = torch.empty(8 << 20, dtype=torch.uint8, device=dev)
         _gemm_ws[key] = buf
-        check(load().keds_gemm_set_workspace(buf.data_ptr(), buf.numel()), "keds_gemm_set_workspace")
+        with torch.cuda.device(key):
+            check(load().keds_gemm_set_workspace(buf.data_ptr(), buf.numel()), "keds_gemm_set_workspace")
 
 
 def prof_enable(on, classes=None) -> None:

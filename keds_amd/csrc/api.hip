@@ -76,6 +76,97 @@ int keds_stream_order(hipStream_t from, hipEvent_t ev, hipStream_t to) {
     return KEDS_OK;
 }
 
+// ---- per-device launch state ---------------------------------------------------------------
+namespace {
+std::mutex g_dev_mu;
+struct FuncDev {
+    const void* f;
+    int dev;
+    int bytes;
+};
+std::vector<FuncDev> g_func_lds;
+int g_cus[64];
+struct DevScratch {
+    float* p;
+    size_t bytes;
+};
+DevScratch g_splitk_dev[64];
+thread_local float* tl_splitk_p = nullptr;
+thread_local size_t tl_splitk_bytes = 0;
+}  // namespace
+
+int keds_func_lds_once(const void* func, int bytes, const char* what) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    for (const FuncDev& e : g_func_lds)
+        if (e.f == func && e.dev == dev && e.bytes >= bytes) return KEDS_OK;
+    if (hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        keds_set_error("%s: cannot raise dynamic LDS to %d bytes on device %d", what, bytes, dev);
+        return KEDS_E_LAUNCH;
+    }
+    g_func_lds.push_back(FuncDev{func, dev, bytes});
+    return KEDS_OK;
+}
+
+int keds_device_cus() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    if (g_cus[dev] == 0) {
+        hipDeviceProp_t prop;
+        g_cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0
+                         ? prop.multiProcessorCount : 256;
+    }
+    return g_cus[dev];
+}
+
+KedsSplitKScope::KedsSplitKScope(void* p, size_t bytes) : prev_p(tl_splitk_p), prev_bytes(tl_splitk_bytes) {
+    tl_splitk_p = (float*)p;
+    tl_splitk_bytes = p ? bytes : 0;
+}
+KedsSplitKScope::~KedsSplitKScope() {
+    tl_splitk_p = prev_p;
+    tl_splitk_bytes = prev_bytes;
+}
+void keds_splitk_scratch(float** p, size_t* bytes) {
+    if (tl_splitk_p) {
+        *p = tl_splitk_p;
+        *bytes = tl_splitk_bytes;
+        return;
+    }
+    int dev = 0;
+    *p = nullptr;
+    *bytes = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    *p = g_splitk_dev[dev].p;
+    *bytes = g_splitk_dev[dev].bytes;
+}
+
+// Per-device fallback scratch for keds_gemm_bt* calls made outside a composite call (keds_common.h): the buffer must
+// live on the CURRENT device; nullptr unregisters.  One stream at a time may run split-K shapes against it.
+extern "C" int keds_gemm_set_workspace(void* ptr, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        keds_set_error("keds_gemm_set_workspace: no current device");
+        return KEDS_E_ARG;
+    }
+    std::lock_guard<std::mutex> g(g_dev_mu);
+    g_splitk_dev[dev].p = (float*)ptr;
+    g_splitk_dev[dev].bytes = ptr ? bytes : 0;
+    return KEDS_OK;
+}
+
+// ---- numerics guard ------------------------------------------------------------------------
+static thread_local int* tl_guard = nullptr;
+int* keds_numerics_guard() { return tl_guard; }
+extern "C" int keds_numerics_guard_set(int32_t* device_flag) {
+    tl_guard = device_flag;
+    return KEDS_OK;
+}
+
 // ---- profiling ---------------------------------------------------------------------------
 namespace {
 struct EvPair {

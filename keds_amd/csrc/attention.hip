@@ -272,15 +272,7 @@ template <int NKT, bool CAUSAL, int NFULL>
 int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit, void* q8, void* s8, int q8_rows,
                 hipStream_t st) {
     using C = AttnCfg<NKT>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attention_kernel<NKT, CAUSAL, NFULL>,
-                                hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS) != hipSuccess) {
-            keds_set_error("attention: cannot set dynamic LDS size %d", C::LDS);
-            return KEDS_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if (int rc = keds_func_lds_once((const void*)attention_kernel<NKT, CAUSAL, NFULL>, C::LDS, "attention_kernel")) return rc;
     KedsProfScope prof(KEDS_PROF_ATTN, st);
     if constexpr (NKT == 18 && !CAUSAL && NFULL == 16) {
         if (g_attn_debug) {

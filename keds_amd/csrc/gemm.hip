@@ -96,20 +96,33 @@ __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
 constexpr float LN_EPS = 1e-5f;
 
 // LayerNorm statistics of row m from {sum, sum of squares}: returns (rstd, -mean * rstd)
-__device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats_, int m, float invk, float& rstd, float& nmr) {
+// Numerics guard of the folded-LayerNorm flow (keds_hip.h, keds_numerics_guard): the GEMM multiplies UN-centred rows, so
+// operand rounding is amplified by |row mean| / row std = |nmr| (rel-L2 4.8e-3 at 20, 1.8e-2 at 100),
+// and an fp16 residual stream that overflowed shows up as non-finite statistics.  Either raises the caller's flag; the
+// host then re-runs the pass on the fp32-stream flow with stand-alone LayerNorm.
+constexpr float GUARD_MAX_MEAN_OVER_STD = 32.0f;
+__device__ __forceinline__ void guard_check(int* __restrict__ guard, float nmr) {
+    if (guard && !(fabsf(nmr) <= GUARD_MAX_MEAN_OVER_STD)) *guard = 1;       // NaN / inf fail the comparison too
+}
+
+__device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats_, int m, float invk, float& rstd, float& nmr,
+                                             int* __restrict__ guard = nullptr) {
     const keds_stat_t* stats = reinterpret_cast<const keds_stat_t*>(stats_);
     const float s = keds_stat_value(stats[2 * (size_t)m]), ss = keds_stat_value(stats[2 * (size_t)m + 1]);
     const float mean = s * invk;
     const float var = fmaxf(ss * invk - mean * mean, 0.f);
     rstd = rsqrtf(var + LN_EPS);
     nmr = -mean * rstd;
+    guard_check(guard, nmr);
 }
 
-__device__ __forceinline__ void ln_coeff_from(keds_stat_t s_fixed, keds_stat_t ss_fixed, float invk, float& rstd, float& nmr) {
+__device__ __forceinline__ void ln_coeff_from(keds_stat_t s_fixed, keds_stat_t ss_fixed, float invk, float& rstd, float& nmr,
+                                              int* __restrict__ guard = nullptr) {
     const float mean = keds_stat_value(s_fixed) * invk;
     const float var = fmaxf(keds_stat_value(ss_fixed) * invk - mean * mean, 0.f);
     rstd = rsqrtf(var + LN_EPS);
     nmr = -mean * rstd;
+    guard_check(guard, nmr);
 }
 
 __device__ __forceinline__ float sum8(f32x4 a, f32x4 b) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])); }
@@ -119,7 +132,8 @@ __device__ __forceinline__ float sum8(f32x4 a, f32x4 b) { return ((a[0] + a[1]) 
 template <int EPI, int MI, int DBG = 0>   // DBG (stamped diagnostic build only): 2 = no statistics loads, 3 = no stores
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* __restrict__ bias, void* __restrict__ out,
                                               int m_lane, int M, int n_lane, int N, int K, const float* __restrict__ aux,
-                                              int aux_i, void* __restrict__ aux2, long long ldc, bool zero_lane) {
+                                              int aux_i, void* __restrict__ aux2, long long ldc, bool zero_lane,
+                                              int* __restrict__ guard = nullptr) {
     if constexpr (epi_is_ln(EPI)) {
         const float invk = 1.0f / (float)K;
         float rstd[MI], nmr[MI];
@@ -131,7 +145,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
                 rstd[mi] = 1.0f + invk;
                 nmr[mi] = invk;
             } else
-                ln_row_coeff(aux, m < M ? m : M - 1, invk, rstd[mi], nmr[mi]);
+                ln_row_coeff(aux, m < M ? m : M - 1, invk, rstd[mi], nmr[mi], zero_lane ? guard : nullptr);
             if (zero && zero_lane && m < M) keds_stat_zero(zero + 2 * (size_t)m);
         }
 #pragma unroll
@@ -310,9 +324,13 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
 // KEDS_EPI_RESID_STATS_F16 in the 256^2 kernel: the same simplifications (every row valid, uniform tile base + 32-bit lane
 // offsets for the read-modify-write of the fp16 stream, bias slice from the LDS side area), all 16 loads of the lane issued
 // before the first is used.
+template <int DBG = 0>   // stamped diagnostic build only: 3 = no stores, 4 = no statistics atomics, 5 = neither (and no loads)
 __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const char* __restrict__ side, void* __restrict__ out,
                                                     int m0, int n0, int N, int wm, int wn, int g, int c,
-                                                    keds_stat_t* __restrict__ stats) {
+                                                    keds_stat_t* __restrict__ stats, char* __restrict__ red) {
+    // `red`: 8 KiB of LDS nobody reads any more (the operand buffer of the last but one K-tile): the four waves that share
+    // a row (wn = 0..3) leave their {sum, sum sq} of it there, and after one barrier threads 0-255 add ONE statistics pair
+    // per row of the tile -- a quarter of the 64-bit atomics (they cost 5-7 k of this epilogue's ~21 k cycles).
     const int r0 = 128 * wm + c;
     char* tile = reinterpret_cast<char*>(out) + ((size_t)m0 * N + n0) * 2;               // wave-uniform
     const int nl = 64 * wn + 8 * g;
@@ -321,14 +339,15 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
     for (int p = 0; p < 2; ++p)
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi)
-            r[p][mi] = *reinterpret_cast<const f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
+            r[p][mi] = DBG == 5 ? f16x8{0, 0, 0, 0, 0, 0, 0, 0}
+                                : *reinterpret_cast<const f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
     f32x4 b[2][2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         b[p][0] = *reinterpret_cast<const f32x4*>(side + 2048 + (nl + 32 * p) * 4);
         b[p][1] = *reinterpret_cast<const f32x4*>(side + 2048 + (nl + 32 * p) * 4 + 16);
     }
-    keds_stat_t* srow = stats ? stats + 2 * (size_t)(m0 + r0) : nullptr;
+    f32x2* rw = reinterpret_cast<f32x2*>(red) + wn * 256 + r0;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
         float s = 0.f, ss = 0.f;
@@ -337,14 +356,32 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
             const f16x8 q = r[p][mi];
             const f32x4 v0 = f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]} + (acc[2 * p][mi] + b[p][0]);
             const f32x4 v1 = f32x4{(float)q[4], (float)q[5], (float)q[6], (float)q[7]} + (acc[2 * p + 1][mi] + b[p][1]);
-            *reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u) =
-                f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+            if constexpr (DBG == 3 || DBG == 5) {
+                const f32x4 v = v0 + v1;
+                if (v[0] + v[1] + v[2] + v[3] == 12345.678f) reinterpret_cast<float*>(out)[0] = v[0];
+            } else
+                *reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u) =
+                    f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
             s += sum8(v0, v1);
             ss += sum8(v0 * v0, v1 * v1);
         }
         s = rows_sum(s);                 // the four lanes (g = 0..3) that share the row hold this wave's 64 columns of it
         ss = rows_sum(ss);
-        if (srow && g == 0) keds_stat_add(srow + 32 * mi, s, ss);
+        if constexpr (DBG == 4 || DBG == 5) {
+            if (s + ss == 12345.678f) reinterpret_cast<float*>(out)[1] = s;
+        } else if (stats && g == 0)
+            rw[16 * mi] = f32x2{s, ss};
+    }
+    if constexpr (DBG != 4 && DBG != 5) {
+        if (stats) {                                                    // kernel-uniform
+            __syncthreads();
+            const int t = threadIdx.x;
+            if (t < 256) {
+                const f32x2* rr = reinterpret_cast<const f32x2*>(red) + t;
+                const f32x2 a = rr[0], b = rr[256], c2 = rr[512], d = rr[768];
+                keds_stat_add(stats + 2 * (size_t)(m0 + t), (a[0] + b[0]) + (c2[0] + d[0]), (a[1] + b[1]) + (c2[1] + d[1]));
+            }
+        }
     }
 }
 
@@ -373,7 +410,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
                                                          int M, int N, int K, int n_tiles,
                                                          const float* __restrict__ aux, int aux_i,
                                                          float* __restrict__ part, int k_len, int tiles, int m_pad,
-                                                         long long lda, long long ldc, void* __restrict__ aux2) {
+                                                         long long lda, long long ldc, void* __restrict__ aux2,
+                                                         int* __restrict__ guard) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = part ? bid_all / tiles : 0;
@@ -508,7 +546,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     }
     // zero_lane: LN epilogues: the one wave column that clears the other stats buffer; RESID_STATS: the lane that adds
     const bool zl = epi_is_ln(EPI) ? (n0 == 0 && wn == 0 && g == 0) : (g == 0);
-    tile_epilogue<EPI, 4>(acc, bias, out, m0 + 64 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, ldc, zl);
+    tile_epilogue<EPI, 4>(acc, bias, out, m0 + 64 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, ldc, zl, guard);
 }
 
 // split-K reduce: add this thread's partial {sum, sum sq} of a row to its statistics.  Lanes that are known to sit in
@@ -535,7 +573,8 @@ template <int EPI>
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __restrict__ part, int splits, int m_pad,
                                                                  const float* __restrict__ bias, void* __restrict__ out,
                                                                  int M, int N, int K, const float* __restrict__ aux, int aux_i,
-                                                                 long long ldc, void* __restrict__ aux2) {
+                                                                 long long ldc, void* __restrict__ aux2,
+                                                                 int* __restrict__ guard) {
     const int per_row = N >> 3;
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= M * per_row) return;
@@ -553,7 +592,7 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
     }
     if constexpr (epi_is_ln(EPI)) {
         float rstd, nmr;
-        ln_row_coeff(aux, m, 1.0f / (float)K, rstd, nmr);
+        ln_row_coeff(aux, m, 1.0f / (float)K, rstd, nmr, n == 0 ? guard : nullptr);
         keds_stat_t* zero = reinterpret_cast<keds_stat_t*>(aux2);
         if (zero && n == 0) keds_stat_zero(zero + 2 * (size_t)m);
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(bias + N + n), c1 = *reinterpret_cast<const f32x4*>(bias + N + n + 4);
@@ -586,37 +625,30 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 // every DMA lane group fetch half cache lines, the texture-address path saturates, and the 256 x 256 x 64 kernel below
 // replaced it: +16 % DMA rate from full-line fetches.  profiles/r01_gemm_pmc_ring_kernel.txt keeps its counters.)
 
-float* g_ws = nullptr;      // caller-registered split-K workspace (keds_gemm_set_workspace)
-size_t g_ws_bytes = 0;
-
 template <int EPI, int NST>
 int launch_small_nst(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                      int aux_i, void* aux2, int splits, long long lda, long long ldc, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_bt_kernel<EPI, NST>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                NST * BUF_BYTES) != hipSuccess) {
-            keds_set_error("gemm: cannot set dynamic LDS size");
-            return KEDS_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if (int rc = keds_func_lds_once((const void*)gemm_bt_kernel<EPI, NST>, NST * BUF_BYTES, "gemm_bt_kernel")) return rc;
     const int m_tiles = (M + BM - 1) / BM, n_tiles = N / BN;
     const int tiles = m_tiles * n_tiles;
     if (splits > 1) {
+        float* g_ws = nullptr;
+        size_t g_ws_bytes = 0;
+        keds_splitk_scratch(&g_ws, &g_ws_bytes);
         const int m_pad = m_tiles * BM;
         gemm_bt_kernel<EPI, NST><<<tiles * splits, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
                                                                                M, N, K, n_tiles, aux, aux_i, g_ws,
-                                                                               K / splits, tiles, m_pad, lda, ldc, aux2);
+                                                                               K / splits, tiles, m_pad, lda, ldc, aux2, nullptr);
         int rc = keds_check_launch("gemm_bt_kernel(split-K)");
         if (rc) return rc;
         const int threads = M * (N / 8);
         gemm_splitk_reduce_kernel<EPI><<<(threads + 255) / 256, 256, 0, st>>>(g_ws, splits, m_pad, bias, out, M, N, K, aux,
-                                                                              aux_i, ldc, aux2);
+                                                                              aux_i, ldc, aux2, keds_numerics_guard());
         return keds_check_launch("gemm_splitk_reduce_kernel");
     }
     gemm_bt_kernel<EPI, NST><<<tiles, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0, lda, ldc, aux2);
+                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0, lda, ldc, aux2,
+                                                                  keds_numerics_guard());
     return keds_check_launch("gemm_bt_kernel");
 }
 
@@ -627,7 +659,10 @@ int launch_small(const void* A, const void* W, const float* bias, void* out, int
                  int aux_i, void* aux2, long long lda, long long ldc, hipStream_t st) {
     const long tiles = (long)((M + BM - 1) / BM) * (N / BN);
     // too few tiles to fill 256 CUs: split K so that ~128+ workgroups stream the weights in parallel
-    if (tiles <= 64 && K >= 2048 && !g_no_split && g_ws) {   // at K = 1024 the second launch costs what the split saves
+    float* g_ws = nullptr;
+    size_t g_ws_bytes = 0;
+    if (tiles <= 64 && K >= 2048 && !g_no_split) keds_splitk_scratch(&g_ws, &g_ws_bytes);
+    if (g_ws) {   // (tiles <= 64 && K >= 2048; at K = 1024 the second launch costs what the split saves)
         int splits = 1;
         while (splits < 16 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
         const size_t need = (size_t)splits * ((M + BM - 1) / BM * BM) * N * sizeof(float);
@@ -644,7 +679,8 @@ constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int OP_BYTES = 256 * 128;             // 32 KiB per operand per K-tile
 constexpr int PBUF_BYTES = 2 * OP_BYTES;        // X | W
 constexpr int SIDE_OFF = 2 * PBUF_BYTES;        // side area: float2 {rstd, -mean rstd}[256 rows] | bias'[256 cols] | colsum[256 cols]
-constexpr int LDS_BYTES = SIDE_OFF + 4096;      // 132 KiB
+constexpr int PF_OFF = SIDE_OFF + 4096;         // landing zone of the L2 prefetches: 256 B per wave, never read
+constexpr int LDS_BYTES = PF_OFF + 2048;        // 134 KiB
 }  // namespace pr
 
 // NOTE (measured, round 1): a persistent variant of this kernel (one workgroup per CU walking its tiles, next tile's
@@ -676,11 +712,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int M, int N, int K, int n_tiles,
                                                               const float* __restrict__ aux, int aux_i,
-                                                              void* __restrict__ aux2) {
+                                                              void* __restrict__ aux2, int* __restrict__ guard) {
     using namespace pr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t_entry = 0, vm_wait = 0, bar_wait = 0;
-    if constexpr (STAMP) t_entry = __builtin_amdgcn_s_memtime();
+    if constexpr (STAMP) {
+        // desynchronisation experiment (stamped build only): every other group of 8 first-round workgroups starts
+        // `aux_i` cycles late, so half of the CUs run half a tile out of phase with the other half
+        if (aux_i > 0 && blockIdx.x < 256 && (blockIdx.x & 8)) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)aux_i) __builtin_amdgcn_s_sleep(8);
+        }
+        t_entry = __builtin_amdgcn_s_memtime();
+    }
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     // The 32 workgroups that run together on one XCD take consecutive logical ids.  Map each run of 32 ids to a
     // block of 8 m-tiles x 4 n-tiles (12 distinct operand panels per K-tile in that XCD's L2 instead of up to 18
@@ -720,6 +764,36 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         char* dst = smem + (p & 1) * PBUF_BYTES + (q < 4 ? 0 : OP_BYTES) + (wave + 8 * i) * 1024;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    // L2 prefetch of the residual tile the epilogue reads-modifies-writes (RESID_STATS_F16): a 4-byte LDS-DMA per lane
+    // pulls one 128-byte line per lane towards this XCD's L2 (the bytes land in a dump area of LDS nobody reads: no VGPR
+    // destination).  The tile is 1024 lines = two wave-instructions per wave, SPREAD over the K-loop: wave w issues its
+    // j-th one behind the DMA pieces of K-tile pf_tile[j], so each K-tile carries ~9 KB of extra reads; the next K-tile's
+    // wait leaves it in flight (counted vmcnt) and the one after retires it, two K-tiles after its issue.  The epilogue's 16 dependent loads per lane
+    // then hit L2: they cost ~9 k of its ~21 k cycles when they go to HBM.  (Measured, round 2: all 1024 lines issued in
+    // the prologue stall it by 10 k cycles -- 128 KB per CU is an HBM-rate burst wherever it sits; a per-K-tile prefetch of
+    // the OPERANDS two tiles ahead made the K-loop 5 % slower on every shape, c_proj included.)
+    [[maybe_unused]] char* pf_dst = smem + PF_OFF + wave * 256;
+    [[maybe_unused]] const char* ct = reinterpret_cast<const char*>(out) + ((size_t)m0 * N + n0) * 2;
+    [[maybe_unused]] const int pf_span = K / TK > 2 ? K / TK - 2 : 1;          // K-tiles whose pieces are issued in the loop
+    [[maybe_unused]] const int pf_tile0 = 2 + (2 * wave) * pf_span / 16, pf_tile1 = 2 + (2 * wave + 1) * pf_span / 16;
+    // the wait that retires K-tile `prev + 1`'s pieces: a prefetch this wave issued behind the pieces of K-tile `prev` is
+    // the youngest operation in its queue and stays in flight (it is retired by the NEXT K-tile's wait, two K-tiles after
+    // its issue); `steady` = inside the loop (outside it everything is drained)
+    auto wait_tile = [&](int prev, bool steady) {
+        int young = 0;
+        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)
+            if (steady) young = (prev == pf_tile0 ? 1 : 0) + (prev == pf_tile1 ? 1 : 0);
+        if (young == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else if (young == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    auto prefetch_c = [&](int j) {
+        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+            const unsigned L = (unsigned)tid + 512u * j;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ct + ((L >> 2) * (unsigned)N * 2u + (L & 3) * 128u)),
+                                             (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
+        }
     };
     // ---- fragment offsets inside a buffer for K-step kk (0/1) of the tile
     const int f = (c >> 1) & 7;
@@ -773,7 +847,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
                 nm = 1.0f / (float)K;
             } else {
                 ln_coeff_from((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0]),
-                              (keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]), 1.0f / (float)K, rs, nm);
+                              (keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]), 1.0f / (float)K, rs, nm,
+                              n0 == 0 ? guard : nullptr);
             }
             *reinterpret_cast<f32x2*>(smem + SIDE_OFF + tid * 8) = f32x2{rs, nm};
         } else {
@@ -803,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if constexpr (SYNC && STAMP != 0) {                                                                    \
             const unsigned long long ta = __builtin_amdgcn_s_memtime();                                        \
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+            wait_tile((ip)-1, ISSUE);                                                                          \
             const unsigned long long tb = __builtin_amdgcn_s_memtime();                                        \
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                    \
             const unsigned long long tc = __builtin_amdgcn_s_memtime();                                        \
@@ -811,7 +886,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
             vm_wait += tb - ta;                                                                                \
             bar_wait += tc - tb;                                                                               \
         }                                                                                                      \
-        if constexpr (SYNC && STAMP == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        if constexpr (SYNC && STAMP == 0) {                                                                    \
+            wait_tile((ip)-1, ISSUE);                                                                          \
+            asm volatile("s_barrier" ::: "memory");                                                            \
+        }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) {                                                     \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
@@ -824,6 +902,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
                 xf[mi] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + mi * 2048);                  \
             }                                                                                                  \
             if constexpr (ISSUE) issue((ip), mi);                                                              \
+        }                                                                                                      \
+        if constexpr (ISSUE && EPI == KEDS_EPI_RESID_STATS_F16) {   /* behind the pieces: the youngest ops of the step */ \
+            if ((ip) == pf_tile0) prefetch_c(0);                                                               \
+            if ((ip) == pf_tile1) prefetch_c(1);                                                               \
         }                                                                                                      \
         if constexpr (PREFETCH) {                                                                              \
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
@@ -862,6 +944,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         const unsigned long long t_loop1 = __builtin_amdgcn_s_memtime();
         if constexpr (epi_is_ln(EPI))
             pair_ln_epilogue<EPI, STAMP>(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c, nullptr);
+        else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)
+            pair_resid_epilogue<STAMP>(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c,
+                                       reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)), smem + (np & 1) * PBUF_BYTES);
         else
             tile_epilogue<EPI, 8, STAMP>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, nullptr, N, zl);
         const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
@@ -886,7 +971,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         pair_ln_epilogue<EPI, 0>(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c, aux2);
     else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)
         pair_resid_epilogue(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c,
-                            reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)));
+                            reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)), smem + (np & 1) * PBUF_BYTES);
     else
         tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
@@ -912,55 +997,37 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // 256^2 kernel; 15 % behind before that): 50 % more DMA bytes per flop and two barriers per K-tile cost more than the
 // hidden fixed costs return.
 
-int device_cus_gemm() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
 int g_pair_stamp = 0;     // diagnostic: stamped build of the qkv instantiation (aux2 = stamp buffer)
 
 template <int EPI>
 int launch_big(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                int aux_i, void* aux2, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                pr::LDS_BYTES) != hipSuccess) {
-            keds_set_error("gemm: cannot set dynamic LDS size (big tile)");
-            return KEDS_E_LAUNCH;
-        }
-        attr_set = true;
-    }
-    if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H) {
+    if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
+    if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_RESID_STATS_F16) {
         if (g_pair_stamp) {
-            static bool set2 = false;
-            if (!set2) {
-                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, pr::LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, pr::LDS_BYTES);
-                (void)hipFuncSetAttribute((const void*)gemm_bt_pair_kernel<EPI, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, pr::LDS_BYTES);
-                set2 = true;
-            }
             const dim3 grid((M / pr::TM) * (N / pr::TN));
-            if (g_pair_stamp == 2)
-                gemm_bt_pair_kernel<EPI, 2><<<grid, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
-            else if (g_pair_stamp == 3)
-                gemm_bt_pair_kernel<EPI, 3><<<grid, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
-            else
-                gemm_bt_pair_kernel<EPI, 1><<<grid, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, N / pr::TN, aux, aux_i, aux2);
+#define KEDS_STAMP_LAUNCH(V)                                                                                       \
+    {                                                                                                             \
+        (void)keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI, V>, pr::LDS_BYTES, "gemm_bt_pair_kernel<stamp>"); \
+        gemm_bt_pair_kernel<EPI, V><<<grid, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, \
+                                                                       N / pr::TN, aux, aux_i, aux2, nullptr);      \
+    }
+            switch (g_pair_stamp) {
+                case 2: KEDS_STAMP_LAUNCH(2) break;
+                case 3: KEDS_STAMP_LAUNCH(3) break;
+                case 4: KEDS_STAMP_LAUNCH(4) break;
+                case 5: KEDS_STAMP_LAUNCH(5) break;
+                default: KEDS_STAMP_LAUNCH(1) break;
+            }
+#undef KEDS_STAMP_LAUNCH
             return keds_check_launch("gemm_bt_pair_kernel<stamp>");
         }
     }
     const int m_tiles = M / pr::TM, n_tiles = N / pr::TN;         // M is a multiple of 256 here
     gemm_bt_pair_kernel<EPI><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
-                                                                            M, N, K, n_tiles, aux, aux_i, aux2);
+                                                                            M, N, K, n_tiles, aux, aux_i, aux2,
+                                                                            keds_numerics_guard());
     return keds_check_launch("gemm_bt_pair_kernel");
 }
 
@@ -1005,22 +1072,15 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
 
 }  // namespace
 
-bool keds_gemm_workspace_registered() { return g_ws != nullptr; }
 // true when a dense [M,K] x [N,K]^T problem sends its full 256-row tiles to the 256^2 kernel (and M % 256 rows to a
 // second, small launch): the towers then run those remainder rows as their own chain on the side lane
 bool keds_gemm_splits_rows(int M, int N, int K) { return big_tiles_ok(M, N, K) && M % pr::TM != 0; }
-
-extern "C" int keds_gemm_set_workspace(void* ptr, size_t bytes) {
-    g_ws = (float*)ptr;
-    g_ws_bytes = ptr ? bytes : 0;
-    return KEDS_OK;
-}
 
 extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
-    g_pair_stamp = (on >> 12) & 3;      // bits 12-13: stamped diagnostic build of the qkv GEMM (2: no statistics loads, 3: no stores)
+    g_pair_stamp = (on >> 12) & 7;      // bits 12-14: stamped diagnostic build of the qkv / residual GEMMs (2: no statistics loads, 3: no stores, 4: no atomics, 5: no residual traffic at all)
     return KEDS_OK;
 }
 

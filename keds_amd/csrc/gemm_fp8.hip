@@ -445,15 +445,7 @@ namespace {
 template <int EPI, int DBG>
 int launch_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, const void* Ws, int n_pad, const float* bias,
                  void* out, int M, int N, int K, float* aux, float* aux2, void* qout, void* qscale, int q_pad, hipStream_t st) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)gemm_mxfp8_kernel<EPI, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess) {
-            keds_set_error("keds_gemm_mxfp8: cannot set dynamic LDS size");
-            return KEDS_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if (int rc = keds_func_lds_once((const void*)gemm_mxfp8_kernel<EPI, DBG>, LDS_BYTES, "gemm_mxfp8_kernel")) return rc;
     const int m_tiles = M / TM, n_tiles = N / TN;
     gemm_mxfp8_kernel<EPI, DBG><<<m_tiles * n_tiles, 512, LDS_BYTES, st>>>(
         (const unsigned char*)Aq, (const unsigned char*)As, (const unsigned char*)Wq, (const unsigned char*)Ws, bias, out, M, N, K,

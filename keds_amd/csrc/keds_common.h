@@ -52,6 +52,31 @@ int keds_stream_order(hipStream_t from, hipEvent_t ev, hipStream_t to);
 
 static inline size_t keds_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// ---- per-device launch state (host) --------------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute and the session API creates contexts on any
+// device from any thread: raise it once per (kernel, device), under a lock.  Returns KEDS_OK or KEDS_E_LAUNCH.
+int keds_func_lds_once(const void* func, int bytes, const char* what);
+// compute units of the CURRENT device (cached per device id)
+int keds_device_cus();
+
+// ---- split-K scratch of the small-M GEMMs (host) -------------------------------------------------------------------
+// A GEMM launch that splits K writes fp32 partial tiles to scratch memory and reduces them in a second launch.  Every
+// composite call (towers, read-out, knowledge path) carves KEDS_SPLITK_BYTES out of ITS OWN caller-supplied workspace
+// and makes it the scratch of the GEMMs it enqueues for the duration of the call (thread-local scope): two handles,
+// threads or streams never share partial sums.  Direct keds_gemm_bt* calls outside such a scope use the per-device
+// buffer registered with keds_gemm_set_workspace (one stream at a time per device), or do not split.
+#define KEDS_SPLITK_BYTES ((size_t)8 << 20)      /* splits * tiles <= 128 tiles of 128 x 128 fp32 */
+struct KedsSplitKScope {
+    float* prev_p;
+    size_t prev_bytes;
+    KedsSplitKScope(void* p, size_t bytes);
+    ~KedsSplitKScope();
+};
+void keds_splitk_scratch(float** p, size_t* bytes);   // innermost scope of this thread, else the device registration
+
+// ---- numerics guard (host): device int32 flag of the calling thread's current composite call, or nullptr -----------
+int* keds_numerics_guard();
+
 // ---- device helpers ----------------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);

@@ -245,15 +245,7 @@ extern "C" int keds_rank_gallery(const float* ref, int nq, const float* gallery,
     int rc = keds_check_launch("dist_kernel");
     if (rc) return rc;
     if (ng > SORT_CHUNK) {
-        static bool chunk_attr = false;
-        if (!chunk_attr) {
-            if (hipFuncSetAttribute((const void*)sort_chunk_keys_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) !=
-                hipSuccess) {
-                keds_set_error("keds_rank_gallery: cannot set dynamic LDS size");
-                return KEDS_E_LAUNCH;
-            }
-            chunk_attr = true;
-        }
+        if ((rc = keds_func_lds_once((const void*)sort_chunk_keys_kernel, 65536, "sort_chunk_keys_kernel"))) return rc;
         const size_t db = keds_align_up((size_t)nq * ng * sizeof(float), 256);
         const size_t kb = keds_align_up((size_t)nq * ng * sizeof(unsigned long long), 256);
         unsigned long long* ka = (unsigned long long*)((char*)workspace + db);
@@ -275,15 +267,7 @@ extern "C" int keds_rank_gallery(const float* ref, int nq, const float* gallery,
     }
     const int P = next_pow2(ng);
     const size_t lds = (size_t)P * 8;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)sort_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536) !=
-            hipSuccess) {
-            keds_set_error("keds_rank_gallery: cannot set dynamic LDS size");
-            return KEDS_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if ((rc = keds_func_lds_once((const void*)sort_rows_kernel, 65536, "sort_rows_kernel"))) return rc;
     sort_rows_kernel<<<nq, 256, lds, st>>>(dist, ng, P, order);
     return keds_check_launch("sort_rows_kernel");
 }

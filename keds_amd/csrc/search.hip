@@ -21,7 +21,15 @@ namespace {
 
 constexpr int STAGE_KEYS = KEDS_SCAN_STAGE_KEYS;  // 32
 constexpr int LISTK = KEDS_SCAN_LIST;             // 16
-constexpr int NCAND = KEDS_SCAN_CAND;             // 64
+constexpr int NCAND = KEDS_SCAN_CAND;             // 64 candidates re-ranked per query for k <= 16
+constexpr int NCAND_WIDE = 256;                   // ... and for 16 < k <= KEDS_SCAN_MAX_K
+constexpr int MAXK = KEDS_SCAN_MAX_K;             // 128
+constexpr int TRAILER = 128;                      // bytes behind the last stage: DbBounds
+// Bounds over the database rows that make the candidate selection CERTIFIABLE (see certify_and_select_kernel):
+// xt = max ||bf16(x)||, r = max ||x - bf16(x)||, x = max ||x||, written by the pack kernel with integer atomicMax.
+struct DbBounds {
+    float xt, r, x, pad;
+};
 constexpr int QBLOCK = KEDS_SCAN_MAX_QUERIES;     // 128
 constexpr int SCAN_THREADS = 512;
 
@@ -205,9 +213,10 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
 // pack: fp32 rows -> swizzled bf16 stage blobs + fp32 bias tail.  One 256-thread block per stage.
 template <int D>
 __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ db, long long n, int metric,
-                                                   char* __restrict__ packed) {
+                                                   char* __restrict__ packed, DbBounds* __restrict__ bounds,
+                                                   long long first_stage) {
     using C = ScanCfg<D>;
-    const long long stage = blockIdx.x;
+    const long long stage = first_stage + blockIdx.x;
     char* blob = packed + (size_t)stage * C::STAGEB;
     for (int id = threadIdx.x; id < STAGE_KEYS * C::CHUNKS; id += 256) {
         const int row = id / C::CHUNKS, ch = id % C::CHUNKS;
@@ -224,32 +233,51 @@ __global__ __launch_bounds__(256) void pack_kernel(const float* __restrict__ db,
         }
         *reinterpret_cast<bf16x8*>(blob + row * C::ROWB + swz_chunk(ch, row) * 16) = v;
     }
-    // bias tail: one wave per 8 rows
+    // bias tail + the rounding bounds of the certificate: one wave per 8 rows
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float m_xt = 0.f, m_r = 0.f, m_x = 0.f;
     for (int row = wave * 8; row < wave * 8 + 8; ++row) {
         const long long key = stage * STAGE_KEYS + row;
         float bias;
         if (key < n) {
-            float s = 0.f;
-            if (metric == KEDS_METRIC_L2) {
-                const float* p = db + (size_t)key * D;
-                for (int i = lane; i < D; i += 64) s += p[i] * p[i];
-                s = wave_sum(s);
+            float s = 0.f, st = 0.f, sr = 0.f;
+            const float* p = db + (size_t)key * D;
+            for (int i = lane; i < D; i += 64) {
+                const float v = p[i], vt = (float)(bf16_t)v;
+                s += v * v;
+                st += vt * vt;
+                sr += (v - vt) * (v - vt);
             }
-            bias = -0.5f * s;
+            s = wave_sum(s);
+            st = wave_sum(st);
+            sr = wave_sum(sr);
+            bias = metric == KEDS_METRIC_L2 ? -0.5f * s : 0.f;
+            m_xt = fmaxf(m_xt, st);
+            m_r = fmaxf(m_r, sr);
+            m_x = fmaxf(m_x, s);
         } else {
             bias = -INFINITY;
         }
         if (lane == 0) reinterpret_cast<float*>(blob + C::KEYB)[row] = bias;
     }
+    if (lane == 0) {      // non-negative floats order like their bit patterns; sqrt rounded up by one ulp-ish factor
+        int* b = reinterpret_cast<int*>(bounds);
+        atomicMax(b + 0, __float_as_int(sqrtf(m_xt) * 1.000001f));
+        atomicMax(b + 1, __float_as_int(sqrtf(m_r) * 1.000001f));
+        atomicMax(b + 2, __float_as_int(sqrtf(m_x) * 1.000001f));
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // qprep: one wave per query row (rows >= nq of the bf16 block are zeroed)
+// qstat[row] = {||q||^2, ||q - bf16(q)||, ||bf16(q)||, 0} of the query as searched (after the optional normalisation);
+// thread 0 also clears the per-launch-set counters {failed certificates, next fallback slot}.
 __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q, int nq, int dim, int normalize,
-                                                    float* __restrict__ qn, bf16_t* __restrict__ qb, int qb_rows) {
+                                                    float* __restrict__ qn, bf16_t* __restrict__ qb, int qb_rows,
+                                                    f32x4* __restrict__ qstat, int* __restrict__ counters) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = 0;
     if (row >= qb_rows) return;
     if (row >= nq) {
         for (int i = lane; i < dim; i += 64) qb[(size_t)row * dim + i] = (bf16_t)0.f;
@@ -260,11 +288,21 @@ __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q,
     for (int i = lane; i < dim; i += 64) s += p[i] * p[i];
     s = wave_sum(s);
     const float nrm = sqrtf(s);
+    float s2 = 0.f, st = 0.f, sr = 0.f;
     for (int i = lane; i < dim; i += 64) {
         const float v = normalize ? p[i] / nrm : p[i];
+        const bf16_t vb = (bf16_t)v;
+        const float vt = (float)vb;
         qn[(size_t)row * dim + i] = v;
-        qb[(size_t)row * dim + i] = (bf16_t)v;
+        qb[(size_t)row * dim + i] = vb;
+        s2 += v * v;
+        st += vt * vt;
+        sr += (v - vt) * (v - vt);
     }
+    s2 = wave_sum(s2);
+    st = wave_sum(st);
+    sr = wave_sum(sr);
+    if (lane == 0) qstat[row] = f32x4{s2, sqrtf(sr) * 1.000001f, sqrtf(st) * 1.000001f, 0.f};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -286,7 +324,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
                                                            int nlists, int listk, const float* __restrict__ xval,
                                                            const int* __restrict__ xidx, int nextra,
                                                            int* __restrict__ cand_idx, float* __restrict__ cand_val,
-                                                           float* __restrict__ thr_out) {
+                                                           float* __restrict__ thr_out, int ncand,
+                                                           const float* __restrict__ thr_in, float* __restrict__ sbound_out) {
     __shared__ unsigned hist[256];
     __shared__ unsigned ckeys[MERGE_WAVES][MERGE_DENSE];
     __shared__ unsigned s_out, s_eq;
@@ -300,6 +339,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
     unsigned key[MERGE_MAXE];
     int id[MERGE_MAXE];
     unsigned nvalid = 0;
+    unsigned lastkey = 0;      // largest key that sits in the LAST slot of a (therefore full) per-lane list
     {
         // unconditional (index-clamped) loads so that all of a thread's entries are in flight together; predicated
         // loads were being issued one round trip at a time
@@ -321,6 +361,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
             if (e >= total) id[i] = -1;
             key[i] = id[i] >= 0 ? ord_key(fv[i]) : 0u;      // 0 is below every real score's key
             nvalid += id[i] >= 0 ? 1u : 0u;
+            if (id[i] >= 0 && e < nmain && (e % listk) == listk - 1 && key[i] > lastkey) lastkey = key[i];
         }
     }
     // block-wide reductions through 4 LDS words (one per wave); no atomics on shared bins: the scores of one
@@ -353,10 +394,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
         s_eq = 0;
     }
     const unsigned V = block_sum(nvalid);
-    const unsigned want = V < (unsigned)NCAND ? V : (unsigned)NCAND;
+    const unsigned want = V < (unsigned)ncand ? V : (unsigned)ncand;
     unsigned T = 0;          // threshold key: entries with key > T are taken, `rem` of those with key == T
     unsigned rem = want;
-    if (V > (unsigned)NCAND) {
+    if (V > (unsigned)ncand) {
         // bits that differ between valid keys: skip the common leading bits
         unsigned kmax = 0, kxor = 0;
 #pragma unroll
@@ -435,10 +476,10 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
             const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
             f = __uint_as_float(u);
         }
-        if (V <= (unsigned)NCAND || k > T) {
+        if (V <= (unsigned)ncand || k > T) {
             const unsigned o = atomicAdd(&s_out, 1u);
-            cand_idx[q * NCAND + o] = id[i];
-            cand_val[q * NCAND + o] = f;
+            cand_idx[q * ncand + o] = id[i];
+            cand_val[q * ncand + o] = f;
         } else if (k == T) {
             const unsigned o = atomicAdd(&s_eq, 1u);
             if (o < 256) {
@@ -448,7 +489,7 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
         }
     }
     __syncthreads();
-    if (V > (unsigned)NCAND) {
+    if (V > (unsigned)ncand) {
         // ties at the threshold: take the `rem` smallest ids (rank by counting; ties are rare, <= 256 handled)
         const unsigned neq = s_eq < 256 ? s_eq : 256;
         const unsigned base = s_out;
@@ -457,26 +498,38 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
             unsigned rank = 0;
             for (unsigned j = 0; j < neq; ++j) rank += eq_idx[j] < my ? 1u : 0u;
             if (rank < rem) {
-                cand_idx[q * NCAND + base + rank] = my;
-                cand_val[q * NCAND + base + rank] = eq_val[tid];
+                cand_idx[q * ncand + base + rank] = my;
+                cand_val[q * ncand + base + rank] = eq_val[tid];
             }
         }
     }
     // fillers when fewer than NCAND valid entries
-    for (int o = (int)want + tid; o < NCAND; o += MERGE_THREADS) {
-        cand_idx[q * NCAND + o] = -1;
-        cand_val[q * NCAND + o] = -INFINITY;
+    for (int o = (int)want + tid; o < ncand; o += MERGE_THREADS) {
+        cand_idx[q * ncand + o] = -1;
+        cand_val[q * ncand + o] = -INFINITY;
     }
-    if (thr_out && tid == 0) {
-        float t = -INFINITY;
-        if (V >= (unsigned)NCAND) {
-            const unsigned k = V > (unsigned)NCAND ? T : 0u;
-            if (V > (unsigned)NCAND) {
-                const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-                t = __uint_as_float(u);
-            }
+    auto key_float = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); };
+    if (thr_out && tid == 0) thr_out[q] = V > (unsigned)ncand ? key_float(T) : -INFINITY;
+    if (sbound_out) {
+        // Upper bound on the bf16 score of every row that is NOT among the candidates.  Such a row was (a) in the union
+        // and cut: score <= T; (b) rejected by the insert threshold: score <= thr_in; (c) pushed out of a full per-lane
+        // list: score <= that list's last entry.  (a) only exists when V > ncand, and then T > thr_in.
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned other = __shfl_xor(lastkey, o, 64);
+            lastkey = other > lastkey ? other : lastkey;
         }
-        thr_out[q] = t;
+        __syncthreads();
+        if (lane == 0) hist[wv] = lastkey;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned lk = hist[0];
+#pragma unroll
+            for (int w = 1; w < MERGE_WAVES; ++w) lk = hist[w] > lk ? hist[w] : lk;
+            float b = V > (unsigned)ncand ? key_float(T) : (thr_in ? thr_in[q] : -INFINITY);
+            if (lk) b = fmaxf(b, key_float(lk));
+            sbound_out[q] = b;
+        }
     }
 }
 
@@ -484,11 +537,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
 // rerank: exact fp32 distance (L2: sum (q-x)^2; IP: q.x) of every candidate; one wave each.
 __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ db, int dim, int metric,
                                                      const float* __restrict__ qn, const int* __restrict__ cand_idx,
-                                                     float* __restrict__ cand_d, int total) {
+                                                     float* __restrict__ cand_d, int total, int ncand) {
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (w >= total) return;
-    const int q = w / NCAND;
+    const int q = w / ncand;
     const int id = cand_idx[w];
     if (id < 0) {
         if (lane == 0) cand_d[w] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
@@ -515,33 +568,223 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
     if (lane == 0) cand_d[w] = s;
 }
 
-// select: one wave per query; rank the NCAND (=64) candidates by (distance, id); write top-k.
-__global__ __launch_bounds__(64) void select_kernel(const int* __restrict__ cand_idx, const float* __restrict__ cand_d,
-                                                    int metric, int k, long long id_base, float* __restrict__ D,
-                                                    long long* __restrict__ I) {
-    const int q = blockIdx.x, lane = threadIdx.x;
-    const float d = cand_d[q * NCAND + lane];
-    const int id = cand_idx[q * NCAND + lane];
-    // key: smaller is better
-    const float key = metric == KEDS_METRIC_L2 ? d : -d;
-    int rank = 0;
-    for (int j = 0; j < NCAND; ++j) {
-        const float kj = __shfl(key, j, 64);
-        const int ij = __shfl(id, j, 64);
-        const bool valid_j = ij >= 0;
-        const bool before = valid_j && (id < 0 || kj < key || (kj == key && ij < id));
-        rank += (before && j != lane) ? 1 : 0;
+// select + certificate: one block of `ncand` threads (64 or 256) per query.  Ranks the candidates by (exact distance, id),
+// writes the top-k, and then PROVES that no row outside the candidate set can belong to the exact top-k:
+//   every such row has a bf16 scan score  s <= sbound[q]                         (merge_select_kernel)
+//   its exact score t = q.x - 0.5||x||^2 (L2) or q.x (IP) obeys  |t - s| <= eps(q)
+//       eps(q) = ||q - q~|| max||x~|| + ||q~|| max||x - x~|| + ||q - q~|| max||x - x~||  (Cauchy-Schwarz on
+//       q.x - q~.x~ = (q - q~).x~ + q~.(x - x~) + (q - q~).(x - x~); q~, x~ = the bf16 roundings the scan multiplies)
+//       + 2e-4 ||q~|| max||x~||  (fp32 accumulation of the MFMA chain: 768 adds x 2^-24 relative, 4x margin)
+//   so if the k-th best candidate's exact score t_k satisfies  t_k - eps(q) > sbound[q],  every outside row is strictly
+//   worse than k candidates: the result is the exact top-k, ties included.  Otherwise the query goes to the exact
+//   fallback (exact_chunk_kernel / exact_merge_kernel) with the pruning bound dk = the k-th candidate distance.
+// counters[0] = failed certificates of this launch set; status[0] / [1] += certified / fallback queries (nullable).
+__global__ __launch_bounds__(256) void certify_select_kernel(const int* __restrict__ cand_idx, const float* __restrict__ cand_d,
+                                                             int ncand, int metric, int k, long long id_base,
+                                                             float* __restrict__ D, long long* __restrict__ I,
+                                                             const f32x4* __restrict__ qstat, const float* __restrict__ sbound,
+                                                             const DbBounds* __restrict__ bounds, int* __restrict__ counters,
+                                                             int* __restrict__ fail_ids, int* __restrict__ fslot,
+                                                             float* __restrict__ dk, int* __restrict__ status,
+                                                             int force_fail) {
+    __shared__ float s_key[NCAND_WIDE];
+    __shared__ int s_id[NCAND_WIDE];
+    __shared__ int s_nvalid;
+    __shared__ float s_dk;
+    const int q = blockIdx.x, t = threadIdx.x;
+    const float d = cand_d[q * ncand + t];
+    const int id = cand_idx[q * ncand + t];
+    const float key = metric == KEDS_METRIC_L2 ? d : -d;           // smaller is better
+    s_key[t] = key;
+    s_id[t] = id;
+    if (t == 0) {
+        s_nvalid = 0;
+        s_dk = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
     }
-    if (id < 0) rank = NCAND + lane;  // never selected before a valid one
+    __syncthreads();
+    int rank = 0;
+    for (int j = 0; j < ncand; ++j) {
+        const float kj = s_key[j];
+        const int ij = s_id[j];
+        const bool before = ij >= 0 && (id < 0 || kj < key || (kj == key && ij < id));
+        rank += (before && j != t) ? 1 : 0;
+    }
+    if (id >= 0) atomicAdd(&s_nvalid, 1);
+    if (id < 0) rank = ncand + t;            // never selected before a valid one
     if (rank < k) {
         D[(size_t)q * k + rank] = d;
         I[(size_t)q * k + rank] = id + id_base;
     }
+    if (id >= 0 && rank == k - 1) s_dk = d;
+    __syncthreads();
+    const int nvalid = s_nvalid;
     // fewer than k valid candidates: (inf | -inf, -1) fillers like faiss
-    const int nvalid = __popcll(__ballot(id >= 0));
-    if (lane >= nvalid && lane < k) {
-        D[(size_t)q * k + lane] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
-        I[(size_t)q * k + lane] = -1;
+    if (t >= nvalid && t < k) {
+        D[(size_t)q * k + t] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+        I[(size_t)q * k + t] = -1;
+    }
+    if (t == 0) {
+        const float sb = sbound[q];
+        bool ok = sb == -INFINITY;           // nothing was ever left out of the candidate set
+        if (force_fail) ok = false;          // test hook (keds_scan_debug bit 5): every query takes the exact pass
+        else if (!ok && nvalid >= k) {
+            const f32x4 qs = qstat[q];
+            const float xt = bounds->xt, rm = bounds->r;
+            const float tk = metric == KEDS_METRIC_L2 ? 0.5f * (qs[0] - s_dk) : s_dk;
+            const float eps = (qs[1] * xt + qs[2] * rm + qs[1] * rm + 2e-4f * qs[2] * xt) * 1.01f +
+                              1e-6f * (fabsf(tk) + qs[0] + 1.0f);
+            ok = tk - eps > sb;
+        }
+        if (ok) {
+            fslot[q] = -1;
+            if (status) atomicAdd(status + 0, 1);
+        } else {
+            const int f = atomicAdd(counters, 1);
+            fail_ids[f] = q;
+            fslot[q] = f;
+            dk[q] = nvalid >= k ? s_dk : (metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY);
+            if (status) atomicAdd(status + 1, 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact fallback, pass 1.  Work item (chunk c of `chunk_rows` rows, failed query f): exact fp32 distances of the chunk's
+// rows from the fp32 matrix, keep the rows that are not worse than the pruning bound dk[q], rank them by (distance, id)
+// and write the best min(count, k) in order to plist[f][c][0..k).  Persistent blocks walk the items with the failed
+// queries fastest, so the blocks that run together stream the same rows (L2).  Exits at once when nothing failed.
+__device__ __forceinline__ unsigned long long exact_key(float d, int id, int metric) {
+    const float kf = metric == KEDS_METRIC_L2 ? d : -d;            // smaller is better
+    return ((unsigned long long)ord_key(kf) << 32) | (unsigned)id;
+}
+
+__global__ __launch_bounds__(256) void exact_chunk_kernel(const float* __restrict__ db, long long n, int dim, int metric,
+                                                          const float* __restrict__ qn, const int* __restrict__ counters,
+                                                          const int* __restrict__ fail_ids, const float* __restrict__ dk,
+                                                          int chunk_rows, int nchunks, int k,
+                                                          unsigned long long* __restrict__ plist, int* __restrict__ pcnt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nfail = counters[0];
+    if (nfail == 0) return;
+    float* sq = reinterpret_cast<float*>(smem);                                              // [dim]
+    unsigned long long* surv = reinterpret_cast<unsigned long long*>(smem + dim * 4);         // [chunk_rows]
+    __shared__ int s_cnt;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long items = (long long)nfail * nchunks;
+    for (long long w = blockIdx.x; w < items; w += gridDim.x) {
+        const int c = (int)(w / nfail), f = (int)(w - (long long)c * nfail);
+        const int q = fail_ids[f];
+        __syncthreads();                                   // previous item's LDS is no longer read
+        for (int i = tid; i < dim; i += 256) sq[i] = qn[(size_t)q * dim + i];
+        if (tid == 0) s_cnt = 0;
+        __syncthreads();
+        const float bound = dk[q];
+        const long long r0 = (long long)c * chunk_rows;
+        const int rows = (int)((n - r0 < chunk_rows) ? (n - r0) : chunk_rows);
+        for (int r = wave; r < rows; r += 4) {
+            const float* x = db + (size_t)(r0 + r) * dim;
+            float s = 0.f;
+            if (metric == KEDS_METRIC_L2) {
+                for (int i = lane * 4; i < dim; i += 256) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(sq + i);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(x + i);
+                    const f32x4 dd = a - b;
+                    s += dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2] + dd[3] * dd[3];
+                }
+            } else {
+                for (int i = lane * 4; i < dim; i += 256) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(sq + i);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(x + i);
+                    s += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+                }
+            }
+            s = wave_sum(s);                               // same summation order as rerank_kernel: identical bits
+            const bool keep = metric == KEDS_METRIC_L2 ? s <= bound : s >= bound;
+            if (lane == 0 && keep) surv[atomicAdd(&s_cnt, 1)] = exact_key(s, (int)(r0 + r), metric);
+        }
+        __syncthreads();
+        const int cnt = s_cnt;
+        unsigned long long* out = plist + ((size_t)f * nchunks + c) * k;
+        for (int i = tid; i < cnt; i += 256) {             // rank by counting: keys are unique (the id is part of them)
+            const unsigned long long me = surv[i];
+            int rank = 0;
+            for (int j = 0; j < cnt; ++j) rank += surv[j] < me ? 1 : 0;
+            if (rank < k) out[rank] = me;
+        }
+        if (tid == 0) pcnt[(size_t)f * nchunks + c] = cnt < k ? cnt : k;
+    }
+}
+
+// Exact fallback, pass 2: one block per query whose certificate failed merges its chunk lists (each sorted) into the
+// final top-k: thread t owns the lists t, t + 256, ... and the block pops the smallest head k times.
+__global__ __launch_bounds__(256) void exact_merge_kernel(const int* __restrict__ fslot, int nchunks, int k, int metric,
+                                                          long long id_base, const unsigned long long* __restrict__ plist,
+                                                          const int* __restrict__ pcnt, float* __restrict__ D,
+                                                          long long* __restrict__ I) {
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f = fslot[q];
+    if (f < 0) return;
+    constexpr int OWN = 8;                                 // lists per thread: nchunks <= 2048
+    __shared__ unsigned long long s_best[4];
+    __shared__ int s_who[4];
+    int pos[OWN], cnt[OWN];
+#pragma unroll
+    for (int o = 0; o < OWN; ++o) {
+        const int c = tid + 256 * o;
+        pos[o] = 0;
+        cnt[o] = c < nchunks ? pcnt[(size_t)f * nchunks + c] : 0;
+    }
+    const unsigned long long NONE = ~0ull;
+    for (int r = 0; r < k; ++r) {
+        unsigned long long best = NONE;
+        int bo = -1;
+#pragma unroll
+        for (int o = 0; o < OWN; ++o) {
+            if (pos[o] < cnt[o]) {
+                const unsigned long long h = plist[((size_t)f * nchunks + tid + 256 * o) * k + pos[o]];
+                if (h < best) {
+                    best = h;
+                    bo = o;
+                }
+            }
+        }
+        unsigned long long wbest = best;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned long long other = __shfl_xor(wbest, o, 64);
+            wbest = other < wbest ? other : wbest;
+        }
+        __syncthreads();
+        if (best == wbest && best != NONE) {               // keys are unique: at most one lane per wave matches
+            s_best[wave] = wbest;
+            s_who[wave] = tid;
+        }
+        if (lane == 0 && wbest == NONE) s_best[wave] = NONE;
+        __syncthreads();
+        unsigned long long bb = s_best[0];
+        int who = s_who[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_best[w] < bb) {
+                bb = s_best[w];
+                who = s_who[w];
+            }
+        if (bb == NONE) {
+            if (tid == 0) {
+                D[(size_t)q * k + r] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+                I[(size_t)q * k + r] = -1;
+            }
+            continue;
+        }
+        if (tid == who) {
+#pragma unroll
+            for (int o = 0; o < OWN; ++o)
+                if (o == bo) pos[o] += 1;
+            const unsigned ku = (unsigned)(bb >> 32);
+            const float kf = __uint_as_float((ku & 0x80000000u) ? (ku & 0x7FFFFFFFu) : ~ku);
+            D[(size_t)q * k + r] = metric == KEDS_METRIC_L2 ? kf : -kf;
+            I[(size_t)q * k + r] = (long long)(unsigned)(bb & 0xFFFFFFFFu) + id_base;
+        }
     }
 }
 
@@ -603,35 +846,45 @@ __global__ void merge_parts_kernel(const float* __restrict__ Dp, const long long
     }
 }
 
-int device_cus() {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
+int device_cus() { return keds_device_cus(); }
 
 constexpr int MAXQB = 8;   // query blocks searched per launch set (1024 queries)
+constexpr size_t EXACT_BUDGET = (size_t)256 << 20;   // bytes of chunk lists the exact fallback may use
+
+// rows per chunk of the exact fallback: at most 2048 chunks (exact_merge_kernel: 8 lists per thread), chunk lists for
+// every query of a launch set within EXACT_BUDGET, and a survivor list that fits LDS (16384 rows = 128 KiB); 0 = impossible
+int exact_chunk_rows(int64_t n, int nq_set, int k) {
+    for (int rows = 2048; rows <= 16384; rows *= 2) {
+        const int64_t chunks = (n + rows - 1) / rows;
+        if (chunks <= 2048 && (size_t)chunks * nq_set * k * 8 <= EXACT_BUDGET) return rows;
+    }
+    return 0;
+}
 
 struct SearchWs {
     float* qn;       // [nq_pad, dim]
-    bf16_t* qb;      // [128, dim]
+    bf16_t* qb;      // [1024, dim]
     float* lval;     // [128, nwg, 4, LISTK]
     int* lidx;
-    int* cidx;       // [128, NCAND]
+    int* cidx;       // [1024, ncand]
     float* cval;
     float* cdist;
-    int* aidx;       // [128, NCAND] phase-A candidates
+    int* aidx;       // [1024, ncand] phase-A candidates
     float* aval;
-    float* thr;      // [128] phase-B insert thresholds
+    float* thr;      // [1024] phase-B insert thresholds
+    float* sbound;   // [1024] bf16 score bound of everything outside the candidate set
+    f32x4* qstat;    // [1024] query norms for the certificate
+    float* dk;       // [1024] pruning bound of the exact fallback
+    int* fail_ids;   // [1024]
+    int* fslot;      // [1024]
+    int* counters;   // [4]
+    unsigned long long* plist;   // [nq_set, nchunks, k] exact fallback chunk lists
+    int* pcnt;       // [nq_set, nchunks]
+    int chunk_rows, nchunks;
     size_t bytes;
 };
 
-SearchWs carve(void* ws, int nq, int dim) {
+SearchWs carve(void* ws, int nq, int dim, int64_t n, int k) {
     SearchWs w;
     char* p = (char*)ws;
     const int nwg = 256;  // upper bound used for sizing
@@ -641,38 +894,44 @@ SearchWs carve(void* ws, int nq, int dim) {
         off += keds_align_up(b, 256);
         return r;
     };
+    const int ncand = k > LISTK ? NCAND_WIDE : NCAND;
     const size_t nq_pad = keds_align_up((size_t)nq, QBLOCK);
+    const size_t set = MAXQB * QBLOCK;
     w.qn = (float*)take(nq_pad * dim * sizeof(float));
-    w.qb = (bf16_t*)take((size_t)MAXQB * QBLOCK * dim * 2);
+    w.qb = (bf16_t*)take(set * dim * 2);
     w.lval = (float*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(float));
     w.lidx = (int*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(int));
-    w.cidx = (int*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(int));
-    w.cval = (float*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(float));
-    w.cdist = (float*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(float));
-    w.aidx = (int*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(int));
-    w.aval = (float*)take((size_t)MAXQB * QBLOCK * NCAND * sizeof(float));
-    w.thr = (float*)take((size_t)MAXQB * QBLOCK * sizeof(float));
+    w.cidx = (int*)take(set * ncand * sizeof(int));
+    w.cval = (float*)take(set * ncand * sizeof(float));
+    w.cdist = (float*)take(set * ncand * sizeof(float));
+    w.aidx = (int*)take(set * ncand * sizeof(int));
+    w.aval = (float*)take(set * ncand * sizeof(float));
+    w.thr = (float*)take(set * sizeof(float));
+    w.sbound = (float*)take(set * sizeof(float));
+    w.qstat = (f32x4*)take(set * sizeof(f32x4));
+    w.dk = (float*)take(set * sizeof(float));
+    w.fail_ids = (int*)take(set * sizeof(int));
+    w.fslot = (int*)take(set * sizeof(int));
+    w.counters = (int*)take(256);
+    const int nq_set = nq < (int)set ? nq : (int)set;
+    w.chunk_rows = exact_chunk_rows(n, nq_set, k);
+    w.nchunks = w.chunk_rows ? (int)((n + w.chunk_rows - 1) / w.chunk_rows) : 0;
+    w.plist = (unsigned long long*)take((size_t)nq_set * w.nchunks * k * 8);
+    w.pcnt = (int*)take((size_t)nq_set * w.nchunks * sizeof(int));
     w.bytes = off;
     return w;
 }
 
 int g_scan_debug = 0;   // timing-only ablations of the D=768 scan kernel
 int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresholds)
+int g_force_exact = 0;  // test hook: 1 sends every query through the exact fallback
 
 template <int D, int L>
 int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr, float* lval,
                 int* lidx, int nwg, int nqb, hipStream_t st) {
     using C = ScanCfg<D>;
     const size_t lds = (size_t)C::NST * C::LDS_STAGE;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)scan_topk_kernel<D, L>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess) {
-            keds_set_error("scan: cannot raise dynamic LDS to %zu bytes", lds);
-            return KEDS_E_LAUNCH;
-        }
-        attr_set = true;
-    }
+    if (int rc = keds_func_lds_once((const void*)scan_topk_kernel<D, L>, (int)lds, "scan_topk_kernel")) return rc;
     KedsProfScope prof(KEDS_PROF_SCAN, st);
     if constexpr (D == 768 && L == LISTK) {
         if (g_scan_debug) {
@@ -697,10 +956,24 @@ int launch_scan(const void* packed, int stage_begin, int total_stages, const bf1
     return keds_check_launch("scan_topk_kernel");
 }
 
+// pack the stages that hold rows >= old_n (a partly filled last stage is re-packed); the bounds of the rows before
+// old_n are carried over from where the trailer sat when the image ended at old_n
 template <int D>
-int launch_pack(const float* db, int64_t n, int metric, void* packed, hipStream_t st) {
+int launch_pack(const float* db, int64_t old_n, int64_t n, int metric, void* packed, hipStream_t st) {
+    using C = ScanCfg<D>;
     const int64_t stages = (n + STAGE_KEYS - 1) / STAGE_KEYS;
-    pack_kernel<D><<<(unsigned)stages, 256, 0, st>>>(db, n, metric, (char*)packed);
+    const int64_t old_stages = (old_n + STAGE_KEYS - 1) / STAGE_KEYS, first = old_n / STAGE_KEYS;
+    DbBounds* bounds = (DbBounds*)((char*)packed + (size_t)stages * C::STAGEB);
+    hipError_t e = hipSuccess;
+    if (old_n == 0)
+        e = hipMemsetAsync(bounds, 0, TRAILER, st);
+    else if (old_stages != stages)
+        e = hipMemcpyAsync(bounds, (char*)packed + (size_t)old_stages * C::STAGEB, TRAILER, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+        keds_set_error("keds_index_pack: trailer set-up failed");
+        return KEDS_E_LAUNCH;
+    }
+    pack_kernel<D><<<(unsigned)(stages - first), 256, 0, st>>>(db, n, metric, (char*)packed, bounds, first);
     return keds_check_launch("pack_kernel");
 }
 
@@ -713,56 +986,73 @@ size_t stage_bytes(int dim) { return (size_t)STAGE_KEYS * dim * 2 + 128; }
 extern "C" int keds_scan_debug(int variant) {
     g_scan_debug = variant & 15;          // bits 0-3: timing-only ablation
     g_scan_phases = (variant >> 4) & 1;   // bit 4: force the single-phase scan (exact as well; for A/B tests)
+    g_force_exact = (variant >> 5) & 1;   // bit 5: fail every certificate (tests of the exact fallback)
     return KEDS_OK;
 }
 
 extern "C" size_t keds_index_packed_bytes(int64_t n, int dim) {
     if (n < 0 || !dim_supported(dim)) return 0;
     const int64_t stages = (n + STAGE_KEYS - 1) / STAGE_KEYS;
-    return (size_t)stages * stage_bytes(dim);
+    return (size_t)stages * stage_bytes(dim) + TRAILER;      // + DbBounds (the certificate's rounding bounds)
 }
 
-extern "C" int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream) {
+extern "C" int keds_index_pack_append(const float* db, int64_t old_n, int64_t n, int dim, int metric, void* packed,
+                                      void* stream) {
     KEDS_REQUIRE(db && packed && n > 0, "keds_index_pack: null pointer or empty database");
+    KEDS_REQUIRE(old_n >= 0 && old_n < n, "keds_index_pack_append: old_n must be in [0, n)");
     KEDS_REQUIRE(dim_supported(dim), "keds_index_pack: dim %d unsupported (128,256,512,768,1024)", dim);
     KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "keds_index_pack: bad metric");
     KEDS_REQUIRE(n < (1LL << 31) - 64, "keds_index_pack: at most 2^31 rows per shard");
     hipStream_t st = (hipStream_t)stream;
     switch (dim) {
-        case 128: return launch_pack<128>(db, n, metric, packed, st);
-        case 256: return launch_pack<256>(db, n, metric, packed, st);
-        case 512: return launch_pack<512>(db, n, metric, packed, st);
-        case 768: return launch_pack<768>(db, n, metric, packed, st);
-        default: return launch_pack<1024>(db, n, metric, packed, st);
+        case 128: return launch_pack<128>(db, old_n, n, metric, packed, st);
+        case 256: return launch_pack<256>(db, old_n, n, metric, packed, st);
+        case 512: return launch_pack<512>(db, old_n, n, metric, packed, st);
+        case 768: return launch_pack<768>(db, old_n, n, metric, packed, st);
+        default: return launch_pack<1024>(db, old_n, n, metric, packed, st);
     }
 }
 
-extern "C" size_t keds_index_search_workspace_bytes(int nq, int dim) {
-    if (nq <= 0 || dim <= 0) return 0;
-    return carve(nullptr, nq, dim).bytes;
+extern "C" int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream) {
+    return keds_index_pack_append(db, 0, n, dim, metric, packed, stream);
 }
 
-extern "C" int keds_index_search_packed(const void* packed, const float* db, int64_t n, int dim, int metric,
-                                 const float* queries, int nq, int normalize_q, int k, int64_t id_base, float* D,
-                                 int64_t* I, float* rows_out, void* workspace, size_t workspace_bytes,
-                                 void* stream) {
+extern "C" size_t keds_index_search_workspace_bytes_ex(int nq, int dim, int64_t n, int k) {
+    if (nq <= 0 || dim <= 0 || n <= 0 || k < 1 || k > MAXK) return 0;
+    return carve(nullptr, nq, dim, n, k).bytes;
+}
+
+// (sized for k <= 16 over at most 4 M rows; use the _ex form for anything else)
+extern "C" size_t keds_index_search_workspace_bytes(int nq, int dim) {
+    return keds_index_search_workspace_bytes_ex(nq, dim, (int64_t)1 << 22, LISTK);
+}
+
+extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, int64_t n, int dim, int metric,
+                                           const float* queries, int nq, int normalize_q, int k, int64_t id_base, float* D,
+                                           int64_t* I, float* rows_out, void* workspace, size_t workspace_bytes,
+                                           int32_t* status, void* stream) {
     KEDS_REQUIRE(packed && db && queries && D && I && workspace, "keds_index_search_packed: null pointer");
     KEDS_REQUIRE(dim_supported(dim), "keds_index_search_packed: dim %d unsupported", dim);
     KEDS_REQUIRE(n > 0 && nq > 0, "keds_index_search_packed: empty database or query set");
-    KEDS_REQUIRE(k >= 1 && k <= LISTK, "keds_index_search_packed: k must be in [1,%d] (got %d)", LISTK, k);
+    KEDS_REQUIRE(k >= 1 && k <= MAXK, "keds_index_search_packed: k must be in [1,%d] (got %d)", MAXK, k);
     KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "keds_index_search_packed: bad metric");
-    SearchWs w = carve(workspace, nq, dim);
+    SearchWs w = carve(workspace, nq, dim, n, k);
+    KEDS_REQUIRE(w.chunk_rows > 0, "keds_index_search_packed: %lld rows x %d queries x k=%d exceed the exact-fallback budget; "
+                 "search fewer queries per call", (long long)n, nq, k);
     if (workspace_bytes < w.bytes) {
-        keds_set_error("keds_index_search_packed: workspace %zu < %zu bytes", workspace_bytes, w.bytes);
+        keds_set_error("keds_index_search_packed: workspace %zu < %zu bytes (keds_index_search_workspace_bytes_ex)",
+                       workspace_bytes, w.bytes);
         return KEDS_E_WORKSPACE;
     }
     hipStream_t st = (hipStream_t)stream;
     const int total_stages = (int)((n + STAGE_KEYS - 1) / STAGE_KEYS);
+    const DbBounds* bounds = (const DbBounds*)((const char*)packed + (size_t)total_stages * stage_bytes(dim));
+    const int ncand = k > LISTK ? NCAND_WIDE : NCAND;
     int cus = device_cus();
     if (cus > 256) cus = 256;
     // Two phases so that list inserts are rare for ANY data: phase A scans the first 1/16 of the stages with empty
     // lists (every lane fills its list: insert-heavy, but on 6 % of the bytes), the merge of phase A yields the
-    // 64th best score per query, and phase B scans the rest accepting only scores above that threshold
+    // ncand-th best score per query, and phase B scans everything accepting only scores above that threshold
     // (expected accept rate 64 / rows(A): ~0.2 % at 0.5 M rows).  Small databases use one phase.
     const bool two_phase = g_scan_phases != 1 && total_stages >= 16 * 64;
     const int stagesA = total_stages / 16;                         // threshold pass: first 1/16 of the rows
@@ -780,7 +1070,7 @@ extern "C" int keds_index_search_packed(const void* packed, const float* db, int
         const int nwgB = total_stages < per ? total_stages : per;
         float* qn = w.qn + (size_t)q0 * dim;
         qprep_kernel<<<nqb * QBLOCK / 4, 256, 0, st>>>(queries + (size_t)q0 * dim, nb, dim, normalize_q, qn, w.qb,
-                                                      nqb * QBLOCK);
+                                                      nqb * QBLOCK, w.qstat, w.counters);
         if ((rc = keds_check_launch("qprep_kernel"))) return rc;
         auto scan_thr = [&]() -> int {                             // depth-4 lists, no threshold
             switch (dim) {
@@ -802,24 +1092,37 @@ extern "C" int keds_index_search_packed(const void* packed, const float* db, int
         };
         if (two_phase) {
             // Threshold pass: every lane keeps the best 4 scores of its share of the first 1/16 of the rows; the
-            // 64th best of their union is a score that 64 real rows reach, so the final 64 candidates all beat or
-            // equal it.  The candidate pass then rescans everything, inserting only above that threshold
-            // (expected accept rate 64 / rows(A): 0.2 % at 0.5 M rows), so list inserts are rare for ANY data.
+            // ncand-th best of their union is a score that ncand real rows reach, so the final candidates all beat or
+            // equal it.  The candidate pass then rescans everything, inserting only above that threshold, so list
+            // inserts are rare for ANY data.
             if ((rc = scan_thr())) return rc;
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgA * 4, 4, nullptr, nullptr, 0, w.aidx, w.aval, w.thr);
+            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgA * 4, 4, nullptr, nullptr, 0, w.aidx, w.aval,
+                                                              w.thr, ncand, nullptr, nullptr);
             if ((rc = keds_check_launch("merge_select_kernel(thr)"))) return rc;
         }
         if ((rc = scan_all(two_phase ? w.thr : nullptr))) return rc;
         {
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgB * 4, LISTK, nullptr, nullptr, 0, w.cidx, w.cval, nullptr);
+            float* Dq = D + (size_t)q0 * k;
+            long long* Iq = (long long*)I + (size_t)q0 * k;
+            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgB * 4, LISTK, nullptr, nullptr, 0, w.cidx, w.cval,
+                                                              nullptr, ncand, two_phase ? w.thr : nullptr, w.sbound);
             if ((rc = keds_check_launch("merge_select_kernel"))) return rc;
-            rerank_kernel<<<(nb * NCAND + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * NCAND);
+            rerank_kernel<<<(nb * ncand + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * ncand, ncand);
             if ((rc = keds_check_launch("rerank_kernel"))) return rc;
-            select_kernel<<<nb, 64, 0, st>>>(w.cidx, w.cdist, metric, k, (long long)id_base, D + (size_t)q0 * k,
-                                             (long long*)I + (size_t)q0 * k);
-            if ((rc = keds_check_launch("select_kernel"))) return rc;
+            certify_select_kernel<<<nb, ncand, 0, st>>>(w.cidx, w.cdist, ncand, metric, k, (long long)id_base, Dq, Iq, w.qstat,
+                                                        w.sbound, bounds, w.counters, w.fail_ids, w.fslot, w.dk, status,
+                                                        g_force_exact);
+            if ((rc = keds_check_launch("certify_select_kernel"))) return rc;
+            // exact fallback for the queries whose certificate failed (both kernels return at once when none did)
+            const size_t lds = (size_t)dim * 4 + (size_t)w.chunk_rows * 8;
+            if ((rc = keds_func_lds_once((const void*)exact_chunk_kernel, (int)lds, "exact_chunk_kernel"))) return rc;
+            exact_chunk_kernel<<<4 * cus, 256, lds, st>>>(db, n, dim, metric, qn, w.counters, w.fail_ids, w.dk, w.chunk_rows,
+                                                         w.nchunks, k, w.plist, w.pcnt);
+            if ((rc = keds_check_launch("exact_chunk_kernel"))) return rc;
+            exact_merge_kernel<<<nb, 256, 0, st>>>(w.fslot, w.nchunks, k, metric, (long long)id_base, w.plist, w.pcnt, Dq, Iq);
+            if ((rc = keds_check_launch("exact_merge_kernel"))) return rc;
         }
     }
     if (rows_out) {
@@ -829,6 +1132,14 @@ extern "C" int keds_index_search_packed(const void* packed, const float* db, int
         if ((rc = keds_check_launch("gather_rows_kernel"))) return rc;
     }
     return KEDS_OK;
+}
+
+extern "C" int keds_index_search_packed(const void* packed, const float* db, int64_t n, int dim, int metric,
+                                 const float* queries, int nq, int normalize_q, int k, int64_t id_base, float* D,
+                                 int64_t* I, float* rows_out, void* workspace, size_t workspace_bytes,
+                                 void* stream) {
+    return keds_index_search_packed_ex(packed, db, n, dim, metric, queries, nq, normalize_q, k, id_base, D, I, rows_out,
+                                       workspace, workspace_bytes, nullptr, stream);
 }
 
 extern "C" int keds_topk_merge_parts(const float* D_parts, const int64_t* I_parts, int parts, int nq, int k,

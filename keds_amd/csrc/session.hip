@@ -13,7 +13,6 @@
 #include <string>
 #include <vector>
 
-bool keds_gemm_workspace_registered();   // gemm.hip
 
 #define HIP_TRY(call, what)                                                    \
     do {                                                                       \
@@ -297,7 +296,6 @@ int rccl_check(int rc, const char* what) {
 // ---- handles ----------------------------------------------------------------------------------------
 struct keds_ctx {
     int device = 0;
-    void* splitk = nullptr;       // registered with keds_gemm_set_workspace when nobody else has
     void* comm = nullptr;
     int rank = 0, world = 1;
 };
@@ -357,10 +355,7 @@ extern "C" int keds_ctx_create(int device, keds_ctx** out) {
                  device, prop.gcnArchName);
     keds_ctx* c = new keds_ctx();
     c->device = device;
-    if (!keds_gemm_workspace_registered()) {
-        const size_t bytes = 32u << 20;
-        if (hipMalloc(&c->splitk, bytes) == hipSuccess) keds_gemm_set_workspace(c->splitk, bytes);
-    }
+    // (split-K scratch of the small-M GEMMs lives inside every handle's own workspace: keds_common.h, KedsSplitKScope)
     *out = c;
     return KEDS_OK;
 }
@@ -368,10 +363,6 @@ extern "C" int keds_ctx_create(int device, keds_ctx** out) {
 extern "C" int keds_ctx_destroy(keds_ctx* ctx) {
     if (!ctx) return KEDS_OK;
     if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
-    if (ctx->splitk) {
-        keds_gemm_set_workspace(nullptr, 0);
-        (void)hipFree(ctx->splitk);
-    }
     delete ctx;
     return KEDS_OK;
 }
@@ -757,7 +748,8 @@ extern "C" int keds_index_add(keds_index* idx, const float* rows, int64_t n) {
 static int index_search_local(keds_index* idx, const float* q, int nq, int k, float* D, int64_t* I, float* rows_out,
                               hipStream_t st, const char* what) {
     KEDS_REQUIRE(idx->n > 0, "%s: the index is empty", what);
-    const size_t need = keds_index_search_workspace_bytes(nq, idx->dim);
+    KEDS_REQUIRE(k >= 1 && k <= KEDS_SCAN_MAX_K, "%s: k must be in [1,%d] (got %d)", what, KEDS_SCAN_MAX_K, k);
+    const size_t need = keds_index_search_workspace_bytes_ex(nq, idx->dim, idx->n, k);
     int rc = idx->ws.reserve(need, st, what);
     if (rc) return rc;
     return keds_index_search_packed(idx->packed, idx->rows, idx->n, idx->dim, idx->metric, q, nq, 0, k, idx->row0, D, I,

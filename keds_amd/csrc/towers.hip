@@ -28,6 +28,7 @@ struct TowerWs {
     keds_stat_t *st1, *st2;
     // MXFP8 operands of the full 256-row tiles (fp8 towers): residual copy, attention output, MLP hidden (+ scale dwords)
     unsigned char *xq, *xs, *aq, *as, *hq, *hs;
+    char* splitk;          // fp32 partial tiles of the split-K launches of THIS call (remainder rows, CLS tail)
     size_t bytes;
 };
 
@@ -55,6 +56,7 @@ TowerWs carve_tower(void* ws, int width, int seq, int B) {
     t.as = (unsigned char*)take(s1);
     t.hq = (unsigned char*)take(4 * q1);
     t.hs = (unsigned char*)take(4 * s1);
+    t.splitk = take(KEDS_SPLITK_BYTES);
     t.bytes = off;
     return t;
 }
@@ -184,6 +186,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
     const int w = p->width, S = p->seq;
     const int M = B * S;
     TowerWs t = carve_tower(ws, w, S, B);
+    KedsSplitKScope splitk(t.splitk, KEDS_SPLITK_BYTES);   // this call's GEMMs split K into this call's scratch only
     int rc;
     // LayerNorm folded into the GEMMs (keds_hip.h, KEDS_EPI_LN_*): t.h holds the bf16 copy of the residual stream,
     // st1 / st2 the {sum, sum sq} of its rows as seen by ln_1 / ln_2.  Each LN-consuming GEMM also clears the

@@ -42,7 +42,10 @@ class FlatIndex:
         self.row0 = int(row0)            # global id of local row 0 (sharding)
         self.rows: Optional[torch.Tensor] = None      # fp32 [n, d] on device (re-rank + gather source)
         self.packed: Optional[torch.Tensor] = None    # bf16 scan image
+        self._rows_buf: Optional[torch.Tensor] = None     # capacity buffers behind rows / packed (chunked add)
+        self._packed_buf: Optional[torch.Tensor] = None
         self._ws = _lib.Workspace()
+        self._status: Optional[torch.Tensor] = None   # device int32[2]: queries certified from the candidates / by the exact pass
 
     # ---- faiss-like surface -------------------------------------------------------------------
     @property
@@ -56,22 +59,39 @@ class FlatIndex:
         return self.device
 
     def add(self, x: ArrayLike) -> None:
-        """Append rows and (re)build the bf16 scan image.  x: float32 [n, d]."""
+        """Append rows and extend the bf16 scan image.  x: float32 [n, d].  Chunked adds pack only the new stages into
+        buffers that grow geometrically (amortised O(rows added), not a re-pack of the whole database per call)."""
         t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)) if isinstance(x, np.ndarray) else x
         if t.dim() != 2 or t.shape[1] != self.d:
             raise ValueError(f"expected [n, {self.d}] rows, got {tuple(t.shape)}")
+        if t.shape[0] == 0:
+            return
         t = t.to(self._dev(), dtype=torch.float32).contiguous()
-        self.rows = t if self.rows is None else torch.cat([self.rows, t]).contiguous()
         lib = load()
-        n = self.rows.shape[0]
-        nbytes = lib.keds_index_packed_bytes(n, self.d)
-        self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-        check(lib.keds_index_pack(ptr(self.rows), n, self.d, self.metric, ptr(self.packed), stream()),
-              "keds_index_pack")
+        old_n = self.ntotal
+        n = old_n + t.shape[0]
+        if old_n == 0:
+            self._rows_buf, self._packed_buf = t, torch.empty(lib.keds_index_packed_bytes(n, self.d), dtype=torch.uint8,
+                                                              device=self.device)
+        else:
+            if n > self._rows_buf.shape[0]:
+                cap = max(n, 2 * self._rows_buf.shape[0])
+                rows_buf = torch.empty((cap, self.d), dtype=torch.float32, device=self.device)
+                rows_buf[:old_n] = self.rows
+                packed_buf = torch.empty(lib.keds_index_packed_bytes(cap, self.d), dtype=torch.uint8, device=self.device)
+                old_bytes = lib.keds_index_packed_bytes(old_n, self.d)
+                packed_buf[:old_bytes] = self.packed[:old_bytes]
+                self._rows_buf, self._packed_buf = rows_buf, packed_buf
+            self._rows_buf[old_n:n] = t
+        self.rows = self._rows_buf[:n]
+        self.packed = self._packed_buf[:lib.keds_index_packed_bytes(n, self.d)]
+        check(lib.keds_index_pack_append(ptr(self.rows), old_n, n, self.d, self.metric, ptr(self.packed), stream()),
+              "keds_index_pack_append")
 
     def reset(self) -> None:
         self.rows = None
         self.packed = None
+        self._rows_buf = self._packed_buf = None
 
     # ---- on-disk form (SURVEY 8f rank 2: the database is built once and reloaded by every eval run) ----------------
     MAGIC = "keds-flat-index-v1"
@@ -83,7 +103,7 @@ class FlatIndex:
         if self.rows is None:
             raise RuntimeError("save of an empty index")
         torch.save({"magic": self.MAGIC, "abi": _lib.ABI_VERSION, "d": self.d, "metric": self.metric, "row0": self.row0,
-                    "rows": self.rows.cpu(), "packed": self.packed.cpu()}, path)
+                    "rows": self.rows.cpu().clone(), "packed": self.packed.cpu().clone()}, path)
 
     @classmethod
     def load(cls, path: str, device=None) -> "FlatIndex":
@@ -101,8 +121,8 @@ class FlatIndex:
         dev = idx._dev()
         expect = load().keds_index_packed_bytes(blob["rows"].shape[0], idx.d)
         if int(blob["abi"]) == _lib.ABI_VERSION and blob["packed"].numel() == expect:
-            idx.rows = blob["rows"].to(dev, dtype=torch.float32).contiguous()
-            idx.packed = blob["packed"].to(dev).contiguous()
+            idx.rows = idx._rows_buf = blob["rows"].to(dev, dtype=torch.float32).contiguous()
+            idx.packed = idx._packed_buf = blob["packed"].to(dev).contiguous()
         else:
             idx.add(blob["rows"])
         return idx
@@ -120,15 +140,30 @@ class FlatIndex:
         q = q.to(self.device, dtype=torch.float32).contiguous()
         B = q.shape[0]
         lib = load()
-        nbytes = lib.keds_index_search_workspace_bytes(B, self.d)
+        nbytes = lib.keds_index_search_workspace_bytes_ex(B, self.d, self.rows.shape[0], k)
+        if nbytes == 0:
+            raise ValueError(f"search of {B} queries x k={k} over {self.rows.shape[0]} rows is not supported in one call")
         ws = self._ws.get(nbytes, self.device)
+        if self._status is None or self._status.device != self.device:
+            self._status = torch.zeros(2, dtype=torch.int32, device=self.device)
         D = torch.empty((B, k), dtype=torch.float32, device=self.device)
         I = torch.empty((B, k), dtype=torch.int64, device=self.device)
         rows = torch.empty((B, k, self.d), dtype=torch.float32, device=self.device) if gather else None
-        check(lib.keds_index_search_packed(ptr(self.packed), ptr(self.rows), self.rows.shape[0], self.d, self.metric,
-                                    ptr(q), B, 1 if normalize else 0, k, self.row0, ptr(D), ptr(I), ptr(rows),
-                                    ptr(ws), ws.numel(), stream()), "keds_index_search_packed")
+        check(lib.keds_index_search_packed_ex(ptr(self.packed), ptr(self.rows), self.rows.shape[0], self.d, self.metric,
+                                              ptr(q), B, 1 if normalize else 0, k, self.row0, ptr(D), ptr(I), ptr(rows),
+                                              ptr(ws), ws.numel(), ptr(self._status), stream()), "keds_index_search_packed")
         return D, I, rows
+
+    def certificate_counts(self, reset: bool = False) -> Tuple[int, int]:
+        """(queries whose top-k was PROVEN exact from the re-ranked candidates, queries answered by the exact fp32 pass over
+        all rows) since the last reset.  Every result is exact either way (IndexFlatL2 semantics); the second number says how
+        often the candidate list was too narrow to certify (near-duplicate clusters).  Synchronises."""
+        if self._status is None:
+            return 0, 0
+        a, b = (int(v) for v in self._status.cpu())
+        if reset:
+            self._status.zero_()
+        return a, b
 
     def search(self, q: ArrayLike, k: int):
         """Faiss call shape: numpy in -> numpy out; device tensor in -> device tensors out."""

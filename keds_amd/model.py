@@ -81,7 +81,7 @@ class VisualTransformer(nn.Module):
 
 
 def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: bool = False,
-                fp8: bool = False) -> _lib.TowerParams:
+                fp8: bool = False, folded: bool = True) -> _lib.TowerParams:
     blocks = (_lib.BlockParams * tr.layers)()
     for i, blk in enumerate(tr.resblocks):
         t = dict(
@@ -96,7 +96,7 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
         lib = load()
         folds = (("qkv", blk.attn.in_proj_weight, t["qkv_b"], ("ln1_g", "ln1_b")),
                  ("fc", blk.mlp.c_fc.weight, t["fc_b"], ("ln2_g", "ln2_b")))
-        if os.environ.get("KEDS_DETERMINISTIC", "0") == "1":
+        if not folded:
             folds = ()
         for name, lin_w, lin_b, ln in folds:
             w32 = _f32(lin_w)
@@ -135,8 +135,9 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
 class _Packed:
     """bf16/fp32 device copies of the weights in the layout the kernels want + the ABI structs."""
 
-    def __init__(self, clip: "CLIP"):
+    def __init__(self, clip: "CLIP", folded: bool = True):
         self.keep: list = []
+        self.folded = folded
         v = clip.visual
         width = v.conv1.weight.shape[0]
         P = v.patch_size
@@ -150,7 +151,7 @@ class _Packed:
                  ln_post_b=_f32(v.ln_post.bias), proj_t=_bf16(v.proj.detach().t()))
         self.keep.append(t)
         fp8 = getattr(clip, "precision", "bf16") == "fp8"
-        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep, cls_only=True, fp8=fp8),
+        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep, cls_only=True, fp8=fp8, folded=folded),
                                   v.input_resolution, P,
                                   self.kpad, v.output_dim, *[ptr(t[k]) for k in (
                                       "conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
@@ -160,7 +161,7 @@ class _Packed:
                   proj_t=_bf16(clip.text_projection.detach().t()))
         self.keep.append(tt)
         self.text = _lib.TextParams(_pack_tower(clip.transformer, clip.context_length, True, self.keep,
-                                                fp8=fp8 and clip.transformer.width % 256 == 0),
+                                                fp8=fp8 and clip.transformer.width % 256 == 0, folded=folded),
                                     clip.vocab_size, clip.embed_dim,
                                     *[ptr(tt[k]) for k in ("token_emb", "pos_emb", "ln_final_g", "ln_final_b", "proj_t")])
         self.device = conv.device
@@ -194,6 +195,13 @@ class CLIP(nn.Module):
         self._packed: Optional[_Packed] = None
         self._ws = _lib.Workspace()
         self.precision = os.environ.get("KEDS_PRECISION", "bf16")
+        # "auto": the fast tower flow (fp16 residual stream, LayerNorm folded into the GEMMs) guarded by a device flag --
+        # a row with |mean|/std > 32 or non-finite statistics re-runs the pass on the fp32-stream flow with stand-alone
+        # LayerNorm and keeps the model there (keds_hip.h, keds_numerics_guard_set); "fast": no guard; "safe": always the
+        # fp32-stream flow (what KEDS_DETERMINISTIC=1 selected before).
+        self.numerics = "safe" if os.environ.get("KEDS_DETERMINISTIC", "0") == "1" else os.environ.get("KEDS_NUMERICS", "auto")
+        self.numerics_tripped = False
+        self._guard: Optional[torch.Tensor] = None
 
     # ---- init (same distributions as model.py:511-541) ------------------------------------------
     def initialize_parameters(self):
@@ -234,7 +242,7 @@ class CLIP(nn.Module):
         a multiple of 256 too, e.g. 768)."""
         if precision not in ("bf16", "fp8"):
             raise ValueError("precision must be 'bf16' or 'fp8'")
-        if precision == "fp8" and (self.visual.transformer.width % 256 != 0 or os.environ.get("KEDS_DETERMINISTIC", "0") == "1"):
+        if precision == "fp8" and (self.visual.transformer.width % 256 != 0 or self.numerics == "safe"):
             raise ValueError("fp8 needs a vision width that is a multiple of 256 and the folded LayerNorm path")
         self.precision = precision
         self._packed = None
@@ -245,10 +253,41 @@ class CLIP(nn.Module):
         load()
         if not self.visual.conv1.weight.is_cuda:
             raise RuntimeError("keds_amd.CLIP: move the model to the GPU first (model.cuda()); no CPU path exists")
-        if self._packed is None:
-            self._packed = _Packed(self)
+        folded = self.numerics != "safe" and not self.numerics_tripped
+        if self._packed is None or self._packed.folded != folded:
+            self._packed = _Packed(self, folded=folded)
         _lib.ensure_gemm_workspace(self._packed.device)
         return self._packed
+
+    def set_numerics(self, mode: str = "auto"):
+        if mode not in ("auto", "fast", "safe"):
+            raise ValueError("numerics must be 'auto', 'fast' or 'safe'")
+        if mode == "safe" and self.precision == "fp8":
+            raise ValueError("fp8 needs the folded LayerNorm path")
+        self.numerics, self.numerics_tripped = mode, False
+        return self
+
+    def _guarded(self, run):
+        """Run one tower pass (`run(engine)` enqueues it and returns the output tensor) under the numerics guard."""
+        eng = self._engine()
+        if self.numerics != "auto" or not eng.folded or self.precision == "fp8":
+            return run(eng)
+        if self._guard is None or self._guard.device != eng.device:
+            self._guard = torch.zeros(1, dtype=torch.int32, device=eng.device)
+        lib = load()
+        check(lib.keds_numerics_guard_set(ptr(self._guard)), "keds_numerics_guard_set")
+        try:
+            out = run(eng)
+        finally:
+            check(lib.keds_numerics_guard_set(None), "keds_numerics_guard_set")
+        if int(self._guard.item()) == 0:
+            return out
+        import warnings
+        warnings.warn("keds_amd.CLIP: activations left the range the fast tower flow is accurate in (|row mean|/std > 32 or a "
+                      "non-finite fp16 residual); re-running on the fp32-stream flow and staying there", RuntimeWarning)
+        self._guard.zero_()
+        self.numerics_tripped = True
+        return run(self._engine())
 
     # ---- encoders ------------------------------------------------------------------------------------
     def encode_image(self, image, mid_feature=False, mask_token=False, normalize: bool = False):
@@ -265,12 +304,15 @@ class CLIP(nn.Module):
         if B == 0:                                    # an empty last batch of a loader: the reference returns [0, embed_dim]
             return torch.empty((0, self.embed_dim), dtype=self.dtype, device=eng.device)
         lib = load()
-        nbytes = lib.keds_vit_workspace_bytes(C.byref(eng.vit), B)
-        ws = self._ws.get(nbytes, eng.device)
-        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
-        check(lib.keds_vit_run(C.byref(eng.vit), ptr(img), B, ptr(out), 1 if normalize else 0, ptr(ws), ws.numel(),
+
+        def run(eng):
+            nbytes = lib.keds_vit_workspace_bytes(C.byref(eng.vit), B)
+            ws = self._ws.get(nbytes, eng.device)
+            out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
+            check(lib.keds_vit_run(C.byref(eng.vit), ptr(img), B, ptr(out), 1 if normalize else 0, ptr(ws), ws.numel(),
                                    stream()), "keds_vit_run")
-        return out.to(self.dtype)
+            return out
+        return self._guarded(run).to(self.dtype)
 
     def _eot_columns(self, text: torch.Tensor) -> torch.Tensor:
         hits = text == self.end_id
@@ -289,12 +331,15 @@ class CLIP(nn.Module):
         ro = readout.to(eng.device, dtype=torch.int32).contiguous()
         it = None if img_tokens is None else img_tokens.to(eng.device, dtype=torch.float32).contiguous()
         n_tok = 0 if it is None else it.shape[1]
-        nbytes = lib.keds_text_workspace_bytes(C.byref(eng.text), B)
-        ws = self._ws.get(nbytes, eng.device)
-        out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
-        check(lib.keds_text_run(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, ptr(out),
+
+        def run(eng):
+            nbytes = lib.keds_text_workspace_bytes(C.byref(eng.text), B)
+            ws = self._ws.get(nbytes, eng.device)
+            out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
+            check(lib.keds_text_run(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, ptr(out),
                                     1 if normalize else 0, ptr(ws), ws.numel(), stream()), "keds_text_run")
-        return out.to(self.dtype)
+            return out
+        return self._guarded(run).to(self.dtype)
 
     def encode_text(self, text, normalize: bool = False):
         """model.py:577-590.  text int [B, L] -> [B, embed_dim]; read-out at the EOT column."""

@@ -147,6 +147,37 @@ def get_metrics_cirr(image_features: torch.Tensor, ref_features: torch.Tensor, r
     return {f"recall_R@{k}": float((rank < k).sum().item()) / n * 100.0 for k in (1, 5, 10, 50, 100)}
 
 
+def get_metrics_cirr_topk(gallery_index, ref_features: torch.Tensor, reference_names, index_names, target_names,
+                          depth: int = 101) -> Dict[str, float]:
+    """get_metrics_cirr (eval_utils.py:1040-1067) from the best `depth` gallery rows only -- the sharded form SURVEY 8e
+    prescribes ("gallery sharded like the DB, K = 101"): `gallery_index` is an inner-product FlatIndex / ShardedFlatIndex
+    over the L2-normalised gallery features (rank r owns its rows; the partial top-101 lists are merged keyed on
+    (score, id), so the ranking is the reference's stable ascending sort of 1 - ref.gallery^T truncated at 101).
+    Removing the reference image can move the target up by one place, so Recall@100 needs the best 101.
+    The full [Q, G] distance matrix and its sort are never built."""
+    table: Dict[str, int] = {}
+    gal = _intern(index_names, table)
+    ref = _intern(reference_names, table)
+    tgt = _intern(target_names, table)
+    if len(set(gal.tolist())) != len(gal):
+        raise AssertionError("gallery names must be unique")            # eval_utils.py:1063 (exactly one hit per row)
+    n = gallery_index.ntotal if hasattr(gallery_index, "ntotal") else gallery_index.n_global
+    depth = min(int(depth), int(n))
+    got = gallery_index.search(ref_features, depth)
+    I = got[1]
+    dev = I.device
+    names = torch.from_numpy(gal).to(dev)[I.clamp(min=0)]              # [Q, depth] interned gallery names
+    names = torch.where(I >= 0, names, torch.full_like(names, -1))
+    is_ref = names == torch.from_numpy(ref).to(dev)[:, None]
+    is_tgt = names == torch.from_numpy(tgt).to(dev)[:, None]
+    slots = torch.arange(depth, device=dev)[None, :]
+    pos = torch.where(is_tgt, slots, torch.full_like(slots, depth)).amin(dim=1)          # first (only) hit or `depth`
+    rank = pos - (is_ref & (slots < pos[:, None])).sum(dim=1)
+    rank = torch.where(pos < depth, rank, torch.full_like(rank, 1 << 30)).cpu()
+    q = rank.shape[0]
+    return {f"recall_R@{k}": float((rank < k).sum().item()) / q * 100.0 for k in (1, 5, 10, 50, 100)}
+
+
 def _intern_whole(names: Sequence[str], table: Dict[str, int]) -> np.ndarray:
     return np.fromiter((table.setdefault(str(n), len(table)) for n in names), dtype=np.int32, count=len(names))
 

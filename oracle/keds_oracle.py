@@ -589,3 +589,79 @@ def synth_tokens(batch: int, context_length: int = 77, seed: int = 4004,
         row = [sot, 320, 1125, 539, star, 267] + list(rs.randint(300, 40000, size=e - 6)) + [eot]
         out[b, :len(row)] = row
     return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------
+# weight / input variants for the full-size parity fixtures (tools/mint_golden.py, tests/test_gpu_fullsize.py)
+# ----------------------------------------------------------------------------
+def sharpen_clip(sd: Mapping[str, Tensor], qk: float = 3.0, resid: float = 4.0) -> Dict[str, Tensor]:
+    """Random-init towers average their tokens almost uniformly, so every input lands on nearly the same embedding
+    (cosine 0.995 between unrelated images) and a ranking over such features is decided by rounding noise.  Scaling the
+    q/k projections (peaky attention) and the residual-branch output projections of the VISUAL tower gives embeddings with
+    cosine ~0.4 between unrelated images: a retrieval problem whose margins are far above the stated fp tolerance."""
+    out = dict(sd)
+    w = sd["visual.conv1.weight"].shape[0]
+    i = 0
+    while f"visual.transformer.resblocks.{i}.attn.in_proj_weight" in sd:
+        p = f"visual.transformer.resblocks.{i}."
+        a = sd[p + "attn.in_proj_weight"].clone()
+        a[:2 * w] *= qk
+        out[p + "attn.in_proj_weight"] = a
+        out[p + "attn.out_proj.weight"] = sd[p + "attn.out_proj.weight"] * resid
+        out[p + "mlp.c_proj.weight"] = sd[p + "mlp.c_proj.weight"] * resid
+        i += 1
+    return out
+
+
+def make_heavy_tailed(sd: Mapping[str, Tensor]) -> Dict[str, Tensor]:
+    """Massive activations as real CLIP checkpoints have them: from block 3 (visual) / block 2 (text) on, three channels of
+    the residual stream carry offsets of +120 / -80 / +50 (about 50-100 x the std of the other channels) that vary per
+    token, and later LayerNorm gains damp (x0.3) or amplify (x2) exactly those channels."""
+    out = dict(sd)
+    for pfx, blk, chans in (("visual.transformer.", 3, (17, 389, 700)), ("transformer.", 2, (5, 300, 611))):
+        p = pfx + f"resblocks.{blk}."
+        b = sd[p + "mlp.c_proj.bias"].clone()
+        wgt = sd[p + "mlp.c_proj.weight"].clone()
+        for c, v in zip(chans, (120.0, -80.0, 50.0)):
+            b[c] += v
+            wgt[c] *= 20.0
+        out[p + "mlp.c_proj.bias"], out[p + "mlp.c_proj.weight"] = b, wgt
+        i = blk + 1
+        while pfx + f"resblocks.{i}.ln_1.weight" in sd:
+            for ln in ("ln_1", "ln_2"):
+                g = sd[pfx + f"resblocks.{i}.{ln}.weight"].clone()
+                g[chans[0]] *= 0.3
+                g[chans[1]] *= 2.0
+                g[chans[2]] *= 0.3
+                out[pfx + f"resblocks.{i}.{ln}.weight"] = g
+            i += 1
+    return out
+
+
+def synth_gallery_images(n: int, start: int = 0, res: int = 224) -> Tensor:
+    """Image i of the synthetic gallery: RandomState(50000 + i) (chunkable: any slice is reproducible on its own)."""
+    out = np.empty((n, 3, res, res), dtype=np.float32)
+    for i in range(n):
+        out[i] = np.random.RandomState(50000 + start + i).standard_normal((3, res, res)).astype(np.float32)
+    return torch.from_numpy(out)
+
+
+def synth_recall_plan(n_gallery: int, n_query: int, seed: int = 6006):
+    """(target index, reference index, noise level) of every query: noise levels graded geometrically 0.1 .. 3."""
+    rs = np.random.RandomState(seed)
+    tgt = rs.randint(0, n_gallery, size=n_query)
+    ref = (tgt + 1 + rs.randint(0, n_gallery - 1, size=n_query)) % n_gallery
+    sigma = (0.1 * 30.0 ** (np.arange(n_query) / max(n_query - 1, 1))).astype(np.float32)
+    return tgt.astype(np.int64), ref.astype(np.int64), sigma
+
+
+def synth_recall_queries(tgt: np.ndarray, sigma: np.ndarray, start: int = 0, count: Optional[int] = None,
+                         res: int = 224) -> Tensor:
+    """Query j = gallery image tgt[j] + sigma[j] * RandomState(70000 + j) noise (chunkable)."""
+    count = len(tgt) - start if count is None else count
+    out = np.empty((count, 3, res, res), dtype=np.float32)
+    for j in range(start, start + count):
+        g = np.random.RandomState(50000 + int(tgt[j])).standard_normal((3, res, res)).astype(np.float32)
+        n = np.random.RandomState(70000 + j).standard_normal((3, res, res)).astype(np.float32)
+        out[j - start] = g + float(sigma[j]) * n
+    return torch.from_numpy(out)

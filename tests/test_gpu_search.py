@@ -105,7 +105,7 @@ def test_search_edge_cases():
     D, I, _ = idx2.search_device(db[:7].cuda(), 2)
     assert torch.equal(I.cpu()[:, 0], torch.arange(7)) and torch.equal(I.cpu()[:, 1], torch.arange(40, 47))
     with pytest.raises(ValueError):
-        idx.search_device(q.cuda(), 17)
+        idx.search_device(q.cuda(), 129)
     with pytest.raises(ValueError):
         keds_amd.IndexFlatL2(100)
     with pytest.raises(RuntimeError):

@@ -54,12 +54,17 @@ def test_session_abi_fails_loudly_without_a_gpu():
 def test_size_queries_need_no_gpu():
     lib = _lib.load()
     # 500k x 768: 15625 stages of (32*768*2 + 128) bytes
-    assert lib.keds_index_packed_bytes(500000, 768) == 15625 * (32 * 768 * 2 + 128)
-    assert lib.keds_index_packed_bytes(33, 128) == 2 * (32 * 128 * 2 + 128)
+    # (+ a 128-byte trailer: the rounding bounds of the search certificate)
+    assert lib.keds_index_packed_bytes(500000, 768) == 15625 * (32 * 768 * 2 + 128) + 128
+    assert lib.keds_index_packed_bytes(33, 128) == 2 * (32 * 128 * 2 + 128) + 128
     assert lib.keds_index_packed_bytes(10, 100) == 0               # unsupported dim
     assert lib.keds_index_search_workspace_bytes(128, 768) > 16 * 1024 * 1024
+    # k up to 128 (256 candidates per query) and the chunk lists of the exact fallback grow the workspace
+    assert lib.keds_index_search_workspace_bytes_ex(128, 768, 500000, 101) > lib.keds_index_search_workspace_bytes_ex(128, 768, 500000, 16)
+    assert lib.keds_index_search_workspace_bytes_ex(128, 768, 500000, 129) == 0
     assert lib.keds_tower_workspace_bytes(1024, 257, 128) == (32896 * 1024 * 2 + 2 * 32896 * 4096 * 2 + 2 * 32896 * 16
-                                                              + 6 * (32768 * 1024 + 32768 * 32))       # + MXFP8 operands
+                                                              + 6 * (32768 * 1024 + 32768 * 32)        # + MXFP8 operands
+                                                              + (8 << 20))                             # + this call's split-K scratch
     # remainder rows of a tower pass run beside the full tiles (side lane): 128 of 32,896 at B = 128, none for a text tower
     assert lib.keds_tower_side_rows(1024, 257, 128, 0) in (0, 128)      # 0 with KEDS_SIDE_STREAM=0
     assert lib.keds_tower_side_rows(768, 77, 128, 0) == 0
@@ -69,7 +74,7 @@ def test_argument_errors_are_reported():
     lib = _lib.load()
     rc = lib.keds_gemm_bt(None, None, None, None, 1, 1, 1, 0, None, 0, None)
     assert rc == -1 and "null" in _lib.last_error()
-    rc = lib.keds_index_search_packed(1, 1, 10, 768, 0, 1, 4, 0, 17, 0, 1, 1, None, 1, 0, None)   # k > 16
+    rc = lib.keds_index_search_packed(1, 1, 10, 768, 0, 1, 4, 0, 129, 0, 1, 1, None, 1, 0, None)   # k > 128
     assert rc == -1 and "k must be" in _lib.last_error()
     rc = lib.keds_attention(1, 1, 1, 400, 16, 0, None)
     assert rc == -1 and "unsupported" in _lib.last_error()

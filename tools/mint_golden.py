@@ -328,6 +328,135 @@ def mint_keys():
     print("keys:", {k: len(v) for k, v in out.items()})
 
 
+
+def _load_vitl(sd):
+    model = CLIP(VITL["embed_dim"], VITL["image_resolution"], VITL["vision_layers"], VITL["vision_width"],
+                 VITL["vision_patch_size"], VITL["context_length"], VITL["vocab_size"], VITL["transformer_width"],
+                 VITL["transformer_width"] // 64, VITL["transformer_layers"]).eval().float()
+    model.load_state_dict(sd, strict=True)
+    return model
+
+
+def mint_dual_full(batch=8, n_db=500000):
+    """BASELINE config 4 at FULL size: ViT-L/14, d = 768, two seeded 0.5 M x 768 databases, two stream checkpoints;
+    the per-batch body of evaluate_cirr (eval_utils.py:652-714) statement for statement on the reference's objects,
+    with the reference's own get_retrieved_features (eval_utils.py:153-186) over an exact float64 flat index."""
+    dim, middle, star = 768, 512, 265
+    sd = O.synth_clip_state_dict(**VITL, seed=7)
+    m = _load_vitl(sd)
+    ns = {"torch": torch, "np": np}
+    grf = extract_function(os.path.join(REF, "eval_utils.py"), "get_retrieved_features", ns)
+    image_base = O.synth_database(n_db, dim, seed=2002)
+    text_base = O.synth_database(n_db, dim, seed=2003, clustered=True)
+    ii, ti = FakeFlatL2(), FakeFlatL2()
+    ii.add(image_base.numpy())
+    ti.add(text_base.numpy())
+    database = [image_base, text_base, None, ii, ti]
+
+    def stream(seed):
+        sds = (O.synth_im2text_state_dict(dim, middle, dim, 2, seed=seed, tag="i2t"),
+               O.synth_crossformer_state_dict(dim, 3, seed=seed, tag="fuse"),
+               O.synth_crossformer_state_dict(dim, 3, seed=seed, tag="cond"))
+        a = IM2TEXT(embed_dim=dim, middle_dim=middle, output_dim=dim, n_layer=2).eval()
+        b = CrossFormer(q_dim=dim, k_dim=dim, v_dim=dim, num_layers=3).eval()
+        c = CrossFormer(q_dim=dim, k_dim=dim, v_dim=dim, num_layers=3).eval()
+        a.load_state_dict(sds[0]); b.load_state_dict(sds[1]); c.load_state_dict(sds[2])
+        return a, b, c
+
+    img2text, retrieval_fuse, text_condition = stream(21)
+    img2text_tb, retrieval_fuse_tb, text_condition_tb = stream(22)
+    rs = np.random.RandomState(1001)
+    timg = torch.from_numpy(rs.standard_normal((batch, 3, 224, 224)).astype(np.float32))
+    ttxt = O.synth_tokens(batch, seed=4004)
+    # ---- eval_utils.py:654-695 ----
+    query_image_features = m.encode_image(timg)
+    qfeat = query_image_features.clone()
+    torch.manual_seed(1234)                      # the reference shuffles the K axis with randperm (eval_utils.py:174)
+    topk_image, topk_text = grf(query_image_features, database, None)
+    mapped_features = img2text(query_image_features)
+    topk_image_features = img2text(topk_image)
+    topk_text_features = img2text(topk_text)
+    fused_features = retrieval_fuse(mapped_features.unsqueeze(1), topk_image_features, topk_image_features)
+    text_conditioned = text_condition(mapped_features.unsqueeze(1), topk_text_features, topk_text_features)
+    fused_features = torch.cat([fused_features, text_conditioned, mapped_features.unsqueeze(1)], dim=1)
+    composed_feature = m.encode_text_img_retrieval(ttxt, fused_features, split_ind=star, repeat=False)
+    mapped_features_tb = img2text_tb(query_image_features)
+    topk_image_features_tb = img2text_tb(topk_image)
+    topk_text_features_tb = img2text_tb(topk_text)
+    fused_features_tb = retrieval_fuse_tb(mapped_features_tb.unsqueeze(1), topk_image_features_tb, topk_image_features_tb)
+    text_conditioned_tb = text_condition_tb(mapped_features_tb.unsqueeze(1), topk_text_features_tb, topk_text_features_tb)
+    fused_features_tb = torch.cat([fused_features_tb, text_conditioned_tb, mapped_features_tb.unsqueeze(1)], dim=1)
+    composed_feature_tb = m.encode_text_img_retrieval(ttxt, fused_features_tb, split_ind=star, repeat=False)
+    # ---- eval_utils.py:698-710 ----
+    query_image_features = composed_feature_tb
+    query_image_features = query_image_features / query_image_features.norm(dim=-1, keepdim=True)
+    composed_feature = composed_feature / composed_feature.norm(dim=-1, keepdim=True)
+    mixture_features = 0.5 * query_image_features + 0.5 * composed_feature
+    mixture_features = mixture_features / mixture_features.norm(dim=-1, keepdim=True)
+    qn = (qfeat / qfeat.norm(dim=-1, keepdim=True)).numpy()
+    Di, Ii = ii.search(qn, 17)
+    Dt, It = ti.search(qn, 17)
+    np.savez_compressed(os.path.join(OUT, "dual_vitl14_full.npz"),
+                        composed=composed_feature.numpy(), image=query_image_features.numpy(),
+                        mixture=mixture_features.numpy(), query_image_features=qfeat.numpy(),
+                        tokens_image_stream=fused_features.numpy(), tokens_text_stream=fused_features_tb.numpy(),
+                        I_image=Ii, I_text=It, D_image=Di, D_text=Dt, n_db=np.int64(n_db), batch=np.int64(batch),
+                        weights_checksum=np.float64(checksum(sd)))
+    print("dual_vitl14_full: ok; top-16/17 gaps image", (Di[:, 16] - Di[:, 15]).min(), "text", (Dt[:, 16] - Dt[:, 15]).min())
+
+
+def mint_heavy_tail(batch=2):
+    """ViT-L/14 + text tower with heavy-tailed activations (massive channels of 50-200 sigma in the residual stream,
+    as real CLIP checkpoints have): the reference's fp32 outputs and per-block CLS rows."""
+    sd = O.make_heavy_tailed(O.synth_clip_state_dict(**VITL, seed=7))
+    m = _load_vitl(sd)
+    rs = np.random.RandomState(1001)
+    image = rs.standard_normal((batch, 3, 224, 224)).astype(np.float32)
+    text = O.synth_tokens(batch, seed=4004).numpy()
+    feat, mids = m.encode_image(torch.from_numpy(image), mid_feature=True)
+    mids = [x.float() for x in mids]
+    stats = np.stack([np.array([float((x.mean(-1).abs() / x.std(-1)).max()), float(x.abs().max()),
+                                float((x.abs().amax(-1) / x.std(-1)).max())]) for x in mids])
+    tfeat = m.encode_text(torch.from_numpy(text))
+    np.savez_compressed(os.path.join(OUT, "clip_vitl14_heavy.npz"), encode_image=feat.numpy(),
+                        block_cls=np.stack([x[:, 0, :].numpy() for x in mids]), encode_text=tfeat.numpy(),
+                        block_stats=stats, weights_checksum=np.float64(checksum(sd)))
+    print("heavy tail: per-block [max |mean|/std, max |x|, max |x|/std]:\n", np.round(stats, 2))
+
+
+def mint_recall_vitl(n_gallery=1000, n_query=256, chunk=8):
+    """BASELINE config 1 at its stated size: ViT-L/14 features of a 1 k-image gallery and 256 queries (noisy copies of
+    gallery images at graded noise levels), ranked by the reference's own get_metrics_cirr (eval_utils.py:1040-1067).
+    Weights: the seeded ViT-L/14 with sharpened attention / residual branches (oracle.sharpen_clip: unrelated images at
+    cosine ~0.4 instead of the 0.995 of plain random init, so the ranking is decided by the features, not by rounding)."""
+    sd = O.sharpen_clip(O.synth_clip_state_dict(**VITL, seed=7))
+    m = _load_vitl(sd)
+    tgt_idx, ref_idx, sigma = O.synth_recall_plan(n_gallery, n_query)
+
+    def enc(make, n):
+        out = []
+        for i in range(0, n, chunk):
+            out.append(m.encode_image(make(i, min(chunk, n - i))))
+            if (i // chunk) % 8 == 0:
+                print("  encoded", i + chunk, "/", n, flush=True)
+        f = torch.cat(out)
+        return f / f.norm(dim=-1, keepdim=True)
+
+    gal = enc(lambda i, c: O.synth_gallery_images(c, start=i), n_gallery)
+    qf = enc(lambda i, c: O.synth_recall_queries(tgt_idx, sigma, start=i, count=c), n_query)
+    ns = {"torch": torch, "np": np, "os": os}
+    gm = extract_function(os.path.join(REF, "eval_utils.py"), "get_metrics_cirr", ns)
+    index_names = [f"/data/cirr/dev/img_{i:05d}.png" for i in range(n_gallery)]
+    reference_names = [os.path.basename(index_names[i]) for i in ref_idx]
+    target_names = [os.path.basename(index_names[i]) for i in tgt_idx]
+    metrics = gm(gal, qf, np.array(reference_names), np.array(index_names), np.array(target_names))
+    np.savez_compressed(os.path.join(OUT, "recall_vitl14.npz"), gallery=gal.numpy().astype(np.float32),
+                        query=qf.numpy().astype(np.float32), ref_idx=ref_idx, tgt_idx=tgt_idx, sigma=sigma,
+                        weights_checksum=np.float64(checksum(sd)),
+                        **{k.replace("@", "_at_"): np.float64(v) for k, v in metrics.items()})
+    print("recall_vitl14:", metrics)
+
+
 TINY = dict(embed_dim=128, image_resolution=56, vision_layers=2, vision_width=128, vision_patch_size=14,
             context_length=77, vocab_size=512, transformer_width=128, transformer_layers=2)
 VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
@@ -355,3 +484,10 @@ if __name__ == "__main__":
         mint_metrics()
     if "vitl" in which:
         mint_clip("vitl14", VITL, batch=2, star=265)
+    # full-size fixtures (minutes of CPU each; not in the default list)
+    if "heavy" in which:
+        mint_heavy_tail()
+    if "dual_full" in which:
+        mint_dual_full()
+    if "recall_vitl" in which:
+        mint_recall_vitl()

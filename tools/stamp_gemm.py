@@ -7,27 +7,56 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from keds_amd import _lib
 from keds_amd._lib import ptr, check, stream
 lib = _lib.load()
-M, N, K = 32768, 3072, 1024
-a = torch.randn(M, K, device="cuda").half()
-w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
-bias = torch.randn(2 * N, device="cuda")
-out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-stats = torch.zeros(M, 2, device="cuda", dtype=torch.int64); stats[:, 1] = (1 << 28) * K
+SHAPE = os.environ.get("SHAPE", "qkv")          # qkv (LN-folded epilogue) | out | proj (fp16-residual epilogue)
+M, N, K = {"qkv": (32768, 3072, 1024), "out": (32768, 1024, 1024), "proj": (32768, 1024, 4096)}[SHAPE]
+RESID = SHAPE != "qkv"
+if RESID:
+    a = torch.randn(M, K, device="cuda").bfloat16()
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).bfloat16()
+    bias = torch.randn(N, device="cuda")
+    out = torch.randn(M, N, device="cuda").half()
+    stats = torch.zeros(M, 2, device="cuda", dtype=torch.int64)
+    EPI = _lib.EPI_RESID_STATS_F16
+else:
+    a = torch.randn(M, K, device="cuda").half()
+    w = (torch.randn(N, K, device="cuda") * K ** -0.5).half()
+    bias = torch.randn(2 * N, device="cuda")
+    out = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    stats = torch.zeros(M, 2, device="cuda", dtype=torch.int64); stats[:, 1] = (1 << 28) * K
+    EPI = _lib.EPI_LN_BIAS_BF16_H
 tiles = (M // 256) * (N // 256)
 buf = torch.zeros(tiles * 8 * 8 + tiles * 8, device="cuda", dtype=torch.int64)
 _lib.ensure_gemm_workspace(torch.device("cuda"))
 def run(aux2):
-    check(lib.keds_gemm_bt_ex2(ptr(a), K, ptr(w), ptr(bias), ptr(out), N, M, N, K, _lib.EPI_LN_BIAS_BF16_H, ptr(stats), 0, ptr(aux2), stream()), "gemm")
-other = torch.zeros(M, 2, device="cuda", dtype=torch.int64)
+    if RESID:
+        out.normal_()           # keep the fp16 stream bounded over repeated accumulation
+        stats.zero_()
+    check(lib.keds_gemm_bt_ex2(ptr(a), K, ptr(w), ptr(bias), ptr(out), N, M, N, K, EPI, ptr(stats), 0, ptr(aux2) if aux2 is not None else None, stream()), "gemm")
+other = None if RESID else torch.zeros(M, 2, device="cuda", dtype=torch.int64)
 for _ in range(20):
     run(other)
 torch.cuda.synchronize()
-for variant, what in ((1, "product epilogue"), (2, "no statistics loads"), (3, "no stores"), (1, "product epilogue again")):
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+DELAY = 0
+def gemm(aux2):
+    check(lib.keds_gemm_bt_ex2(ptr(a), K, ptr(w), ptr(bias), ptr(out), N, M, N, K, EPI, ptr(stats), DELAY, ptr(aux2) if aux2 is not None else None, stream()), "gemm")
+run(other); torch.cuda.synchronize()
+e0.record(); gemm(other); e1.record(); torch.cuda.synchronize()
+print(f"== SHAPE={SHAPE} {M}x{N}x{K}: product launch (unstamped) {e0.elapsed_time(e1) * 1e3:.1f} us")
+VARIANTS = (((1, "product epilogue", 0), (3, "no stores", 0), (4, "no statistics atomics", 0), (5, "no residual loads / stores / atomics", 0),
+             (1, "product epilogue, half of the CUs 25k cycles late", 25000), (1, "product epilogue again", 0))
+            if RESID else ((1, "product epilogue", 0), (2, "no statistics loads", 0), (3, "no stores", 0),
+                           (1, "product epilogue, half of the CUs 25k cycles late", 25000), (1, "product epilogue again", 0)))
+for variant, what, DELAY in VARIANTS:
     lib.keds_gemm_force_small(variant << 12)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
         run(buf)
-    e0.record(); run(buf); e1.record()
+    if RESID:
+        out.normal_(); stats.zero_()
+    gemm(buf)
+    torch.cuda.synchronize()
+    e0.record(); gemm(buf); e1.record()
     torch.cuda.synchronize()
     lib.keds_gemm_force_small(0)
     t = buf[:tiles * 64].view(tiles, 8, 8).double().cpu()
