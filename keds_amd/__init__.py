@@ -6,7 +6,7 @@ Python here is the host side only (parameter containers, argument checks, torch 
 torch.distributed); all compute runs in hand-written gfx950 kernels in csrc/libkeds_hip.so.
 """
 from ._lib import LIB_PATH, build as build_library, load as load_library   # noqa: F401
-from .index import (FlatIndex, IndexFlatIP, IndexFlatL2, ShardedFlatIndex, exchange_merge_gather,   # noqa: F401
+from .index import (FlatIndex, IndexFlatIP, IndexFlatL2, PackedExchange, ShardedFlatIndex, exchange_merge_gather,   # noqa: F401
                     index_cpu_to_all_gpus, merge_partials, shard_bounds)
 from .model import (CLIP, CrossAttention, CrossFormer, IM2TEXT, KnowledgeStream, LayerNorm, QuickGELU,   # noqa: F401
                     ResidualAttentionBlock, Transformer, VisualTransformer, build_model,

@@ -45,10 +45,14 @@ struct AttnCtx {
     unsigned char* q8;    // element (row, col) at q8[row*d + col]; nullptr = bf16 everywhere
     unsigned char* s8;    // scale dwords [d/128][q8_rows]
     int q8_rows, row0, col0;   // first global row of this sample, first column of this head
+    const char* tail;          // TAIL kernels: [K row of the last key: 64 bf16, unswizzled][its V row: 64 bf16]
 };
 
 // NQ consecutive 16-query tiles starting at tile qt0, for one wave.
-template <int NKT, bool CAUSAL, int NFULL, int DBG, int NQ>
+// TAIL: the sequence is 16*NKT + 1 keys; the MFMA tiles cover the first 16*NKT and the last key is a rank-1 VALU update
+// (its score from the lane's 16 query dims + a reduction over the four lanes of the query, its P.V term 16 FMAs per tile)
+// instead of two more key tiles of which 31 of 32 columns would be padding.
+template <int NKT, bool CAUSAL, int NFULL, int DBG, int NQ, bool TAIL = false>
 __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
     using C = AttnCfg<NKT>;
     const int g = cx.g, c = cx.c, S = cx.S;
@@ -85,8 +89,22 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
         }
         if (kt % 3 == 2) __builtin_amdgcn_sched_barrier(0);   // bound how far LDS reads are hoisted (VGPR pressure)
     }
+    // ---- TAIL: score of the last key for the lane's query (replicated over the four g lanes after the reduction)
+    [[maybe_unused]] float tsc[NQ];
+    if constexpr (TAIL) {
+        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(cx.tail + g * 16);
+        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(cx.tail + (4 + g) * 16);
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a += (float)qf[t][0][j] * (float)k0[j] + (float)qf[t][1][j] * (float)k1[j];
+            tsc[t] = rows_sum(a);
+        }
+    }
     // ---- mask, row max, exp, row sum (lane holds query qidx[t], keys kt*16 + 4g + r)
     float inv[NQ];
+    [[maybe_unused]] float tp[NQ];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
         float mx = -INFINITY;
@@ -104,6 +122,7 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
                 mx = fmaxf(mx, v);
             }
         mx = rows_max(mx);
+        if constexpr (TAIL) mx = fmaxf(mx, tsc[t]);
         const float nmx = -mx * sl2;
         // packed fp32 math (v_pk_fma_f32 / v_pk_add_f32: two elements per VALU issue); v_exp_f32 stays per element
         const f32x2 vs = f32x2{sl2, sl2}, vn = f32x2{nmx, nmx};
@@ -125,6 +144,11 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
         }
         float sum = vsum[0] + vsum[1];
         sum = rows_sum(sum);
+        if constexpr (TAIL) {
+            const float e = __builtin_amdgcn_exp2f(tsc[t] * sl2 + nmx);
+            sum += e;
+            tp[t] = (float)(bf16_t)e;             // rounded like the probabilities the MFMA path multiplies
+        }
         inv[t] = 1.0f / sum;
     }
     // ---- O^T = V^T . P^T
@@ -155,6 +179,16 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
             }
         }
         if (u % 3 == 2) __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (TAIL) {      // + p_last * V[last key][16 dt + 4 g + r]
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const bf16x4 v = *reinterpret_cast<const bf16x4*>(cx.tail + 128 + (16 * dt + 4 * g) * 2);
+#pragma unroll
+            for (int t = 0; t < NQ; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[t][dt][r] += tp[t] * (float)v[r];
+        }
     }
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
@@ -266,7 +300,149 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     }
 }
 
+// ---- S = 16 * NKT + 1, non-causal (ViT-L/14: 257 = 16 * 16 + 1 tokens) ------------------------------------------------
+// The generic kernel pads 257 keys to 288 and 257 queries to 272: a fifth of its MFMA, exp and LDS-read work is padding, and
+// the 17th query tile lands on one wave as a third step where the others run two.  Here the 256 leading keys / queries are
+// 16 key tiles x 8 query-tile pairs (two per wave: balanced), the last KEY is a rank-1 VALU update inside attn_tiles<TAIL>,
+// and the last QUERY is one row of plain VALU work split over the four waves after their tile loops: wave w scores keys
+// [64 w, 64 w + 64) (one per lane), the scores and then the probabilities cross waves through 2 KB of LDS, and wave w
+// accumulates output dims [16 w, 16 w + 16) (lane = dim x key quarter, reduced over the quarters with permlane swaps).
+constexpr int TAIL_LDS = 256 + 2 * 1056;      // last key's K and V rows | scores [257+] | probabilities [257+]
+
+template <int NKT, int DBG = 0>
+__global__ __launch_bounds__(256, 2) void attention_tail1_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                 int heads, int q_limit) {
+    using C = AttnCfg<NKT>;
+    constexpr int S = 16 * NKT + 1, LAST = 16 * NKT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* vt_lds = smem + C::K_BYTES;
+    char* tail = smem + C::LDS;
+    float* sc_lds = reinterpret_cast<float*>(tail + 256);
+    float* p_lds = sc_lds + 264;
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int d = heads * DH;
+    const int ld = 3 * d;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const bf16_t* base = qkv + (size_t)b * S * ld + h * DH;
+
+    // ---- stage K (swizzled rows), V^T (permuted key order) of the 16 * NKT leading keys, and the last key's two rows
+    {
+        constexpr int ITEMS = (C::KEYS / 4) * 8;
+        constexpr int PER = ITEMS / 256;
+        static_assert(ITEMS % 256 == 0, "staging items must divide over the workgroup");
+        bf16x8 kreg[PER][4], vreg[PER][4];
+        bf16x8 treg = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int id = tid + it * 256;
+            const int quad = id >> 3, ch = id & 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bf16_t* row = base + (size_t)(quad * 4 + e) * ld + ch * 8;
+                kreg[it][e] = *reinterpret_cast<const bf16x8*>(row + d);
+                vreg[it][e] = *reinterpret_cast<const bf16x8*>(row + 2 * d);
+            }
+        }
+        if (tid < 16) treg = *reinterpret_cast<const bf16x8*>(base + (size_t)LAST * ld + (tid < 8 ? d : 2 * d) + (tid & 7) * 8);
+#pragma unroll
+        for (int it = 0; it < PER; ++it) {
+            const int id = tid + it * 256;
+            const int quad = id >> 3, ch = id & 7;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int key = quad * 4 + e;
+                *reinterpret_cast<bf16x8*>(k_lds + key * 128 + ((ch ^ ((key >> 1) & 7)) << 4)) = kreg[it][e];
+            }
+            const int k0 = quad * 4;
+            const int u = k0 >> 5, w = k0 & 31;
+            const int pos = (4 * u + ((w & 15) >> 2)) * 16 + ((w >> 4) << 2) * 2;
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                *reinterpret_cast<bf16x4*>(vt_lds + (ch * 8 + j) * C::VT_ROW + pos) =
+                    bf16x4{vreg[it][0][j], vreg[it][1][j], vreg[it][2][j], vreg[it][3][j]};
+        }
+        if (tid < 16) *reinterpret_cast<bf16x8*>(tail + tid * 16) = treg;
+    }
+    __syncthreads();
+
+    const int ql = q_limit < LAST ? q_limit : LAST;               // query rows covered by the MFMA tiles
+    const int nqt = DBG == 5 ? 0 : (ql + 15) >> 4;
+    AttnCtx cx{base, out + (size_t)b * S * d + h * DH, k_lds, vt_lds, S, q_limit, ld, d, g, c, nullptr, nullptr, 0, b * S, h * DH, tail};
+    const int npair = nqt >> 1;
+    for (int qp = wave; qp < npair; qp += 4) attn_tiles<NKT, false, NKT, DBG, 2, true>(cx, 2 * qp);
+    if ((nqt & 1) && wave == ((blockIdx.x + npair) & 3)) attn_tiles<NKT, false, NKT, DBG, 1, true>(cx, nqt - 1);
+    if (q_limit <= LAST) return;                                   // kernel-uniform: nobody waits at the barriers below
+
+    // ---- the last query row: scores of this wave's 64 keys (lane = key)
+    const float sl2 = 0.125f * 1.4426950408889634f;
+    const bf16_t* qrow = base + (size_t)LAST * ld;
+    float s = 0.f;
+    {
+        const int key = 64 * wave + lane;
+        const char* kr = k_lds + key * 128;
+        const int f = (key >> 1) & 7;
+#pragma unroll
+        for (int ch = 0; ch < 8; ++ch) {
+            const bf16x8 qv = *reinterpret_cast<const bf16x8*>(qrow + 8 * ch);       // same address in every lane: one fetch
+            const bf16x8 kv = *reinterpret_cast<const bf16x8*>(kr + ((ch ^ f) << 4));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)qv[j] * (float)kv[j];
+        }
+        sc_lds[key] = s;
+    }
+    const float q_own = (float)qrow[lane];                                            // lane = head dim
+    const float s_last = wave_sum(q_own * (float)reinterpret_cast<const bf16_t*>(tail)[lane]);
+    __syncthreads();
+    // every wave: softmax statistics over all 16 * NKT + 1 scores (lane reads keys lane, lane + 64, ...)
+    float mx = s_last;
+#pragma unroll
+    for (int i = 0; i < LAST / 64; ++i) mx = fmaxf(mx, sc_lds[lane + 64 * i]);
+    mx = wave_max(mx);
+    const float nmx = -mx * sl2;
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LAST / 64; ++i) sum += __builtin_amdgcn_exp2f(sc_lds[lane + 64 * i] * sl2 + nmx);
+    sum = wave_sum(sum);
+    const float e_last = __builtin_amdgcn_exp2f(s_last * sl2 + nmx);
+    sum += e_last;
+    p_lds[64 * wave + lane] = (float)(bf16_t)__builtin_amdgcn_exp2f(s * sl2 + nmx);   // bf16-rounded like the MFMA path's P
+    __syncthreads();
+    // P.V: lane = (dim 16 wave + c, key quarter g); chunk 4u + gg of a V^T row holds keys 32u + 4gg + {0..3}, 32u + 16 + 4gg + {0..3}
+    {
+        const int dim = 16 * wave + c;
+        const char* vrow = vt_lds + dim * C::VT_ROW;
+        float acc = 0.f;
+#pragma unroll
+        for (int uu = 0; uu < NKT / 8; ++uu) {
+            const int u = g * (NKT / 8) + uu;                       // this quarter's 32-key steps
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(vrow + (4 * u + gg) * 16);
+                const f32x4 pa = *reinterpret_cast<const f32x4*>(p_lds + 32 * u + 4 * gg);
+                const f32x4 pb = *reinterpret_cast<const f32x4*>(p_lds + 32 * u + 16 + 4 * gg);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc += pa[j] * (float)v[j] + pb[j] * (float)v[4 + j];
+            }
+        }
+        acc = rows_sum(acc);
+        acc += (float)(bf16_t)e_last * (float)reinterpret_cast<const bf16_t*>(tail + 128)[dim];
+        if (g == 0) cx.out[(size_t)LAST * d + dim] = (bf16_t)(acc / sum);
+    }
+}
+
 int g_attn_debug = 0;   // timing-only ablations (ViT kernel)
+int g_attn_tail = 1;    // A/B hook: 0 routes S = 257 through the generic (padded) kernel
+
+int launch_attn_tail1(const void* qkv, void* out, int B, int heads, int q_limit, hipStream_t st) {
+    using C = AttnCfg<16>;
+    constexpr int LDS = C::LDS + TAIL_LDS;
+    if (int rc = keds_func_lds_once((const void*)attention_tail1_kernel<16>, LDS, "attention_tail1_kernel")) return rc;
+    KedsProfScope prof(KEDS_PROF_ATTN, st);
+    attention_tail1_kernel<16><<<B * heads, 256, LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, heads, q_limit);
+    return keds_check_launch("attention_tail1_kernel");
+}
 
 template <int NKT, bool CAUSAL, int NFULL>
 int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit, void* q8, void* s8, int q8_rows,
@@ -301,7 +477,8 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit
 }  // namespace
 
 extern "C" int keds_attention_debug(int variant) {
-    g_attn_debug = variant;
+    g_attn_debug = variant & 15;
+    g_attn_tail = (variant >> 4) & 1 ? 0 : 1;      // bit 4: S = 257 through the generic kernel (A/B)
     return KEDS_OK;
 }
 
@@ -325,6 +502,7 @@ extern "C" int keds_attention_mx(const void* qkv, void* out, int B, int S, int h
     }
     if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
     if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
+    if (S == 257 && !q8 && g_attn_tail && !g_attn_debug) return launch_attn_tail1(qkv, out, B, heads, q_limit, st);
     if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);   // ViT-L/14: 257 tokens
     return launch_attn<18, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
 }

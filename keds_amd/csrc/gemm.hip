@@ -679,8 +679,7 @@ constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int OP_BYTES = 256 * 128;             // 32 KiB per operand per K-tile
 constexpr int PBUF_BYTES = 2 * OP_BYTES;        // X | W
 constexpr int SIDE_OFF = 2 * PBUF_BYTES;        // side area: float2 {rstd, -mean rstd}[256 rows] | bias'[256 cols] | colsum[256 cols]
-constexpr int PF_OFF = SIDE_OFF + 4096;         // landing zone of the L2 prefetches: 256 B per wave, never read
-constexpr int LDS_BYTES = PF_OFF + 2048;        // 134 KiB
+constexpr int LDS_BYTES = SIDE_OFF + 4096;      // 132 KiB
 }  // namespace pr
 
 // NOTE (measured, round 1): a persistent variant of this kernel (one workgroup per CU walking its tiles, next tile's
@@ -765,36 +764,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
-    // L2 prefetch of the residual tile the epilogue reads-modifies-writes (RESID_STATS_F16): a 4-byte LDS-DMA per lane
-    // pulls one 128-byte line per lane towards this XCD's L2 (the bytes land in a dump area of LDS nobody reads: no VGPR
-    // destination).  The tile is 1024 lines = two wave-instructions per wave, SPREAD over the K-loop: wave w issues its
-    // j-th one behind the DMA pieces of K-tile pf_tile[j], so each K-tile carries ~9 KB of extra reads; the next K-tile's
-    // wait leaves it in flight (counted vmcnt) and the one after retires it, two K-tiles after its issue.  The epilogue's 16 dependent loads per lane
-    // then hit L2: they cost ~9 k of its ~21 k cycles when they go to HBM.  (Measured, round 2: all 1024 lines issued in
-    // the prologue stall it by 10 k cycles -- 128 KB per CU is an HBM-rate burst wherever it sits; a per-K-tile prefetch of
-    // the OPERANDS two tiles ahead made the K-loop 5 % slower on every shape, c_proj included.)
-    [[maybe_unused]] char* pf_dst = smem + PF_OFF + wave * 256;
-    [[maybe_unused]] const char* ct = reinterpret_cast<const char*>(out) + ((size_t)m0 * N + n0) * 2;
-    [[maybe_unused]] const int pf_span = K / TK > 2 ? K / TK - 2 : 1;          // K-tiles whose pieces are issued in the loop
-    [[maybe_unused]] const int pf_tile0 = 2 + (2 * wave) * pf_span / 16, pf_tile1 = 2 + (2 * wave + 1) * pf_span / 16;
-    // the wait that retires K-tile `prev + 1`'s pieces: a prefetch this wave issued behind the pieces of K-tile `prev` is
-    // the youngest operation in its queue and stays in flight (it is retired by the NEXT K-tile's wait, two K-tiles after
-    // its issue); `steady` = inside the loop (outside it everything is drained)
-    auto wait_tile = [&](int prev, bool steady) {
-        int young = 0;
-        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)
-            if (steady) young = (prev == pf_tile0 ? 1 : 0) + (prev == pf_tile1 ? 1 : 0);
-        if (young == 1) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
-        else if (young == 2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    };
-    auto prefetch_c = [&](int j) {
-        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
-            const unsigned L = (unsigned)tid + 512u * j;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ct + ((L >> 2) * (unsigned)N * 2u + (L & 3) * 128u)),
-                                             (__attribute__((address_space(3))) void*)pf_dst, 4, 0, 0);
-        }
-    };
     // ---- fragment offsets inside a buffer for K-step kk (0/1) of the tile
     const int f = (c >> 1) & 7;
     const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
@@ -878,7 +847,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         if constexpr (SYNC && STAMP != 0) {                                                                    \
             const unsigned long long ta = __builtin_amdgcn_s_memtime();                                        \
-            wait_tile((ip)-1, ISSUE);                                                                          \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
             const unsigned long long tb = __builtin_amdgcn_s_memtime();                                        \
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                    \
             const unsigned long long tc = __builtin_amdgcn_s_memtime();                                        \
@@ -886,10 +855,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
             vm_wait += tb - ta;                                                                                \
             bar_wait += tc - tb;                                                                               \
         }                                                                                                      \
-        if constexpr (SYNC && STAMP == 0) {                                                                    \
-            wait_tile((ip)-1, ISSUE);                                                                          \
-            asm volatile("s_barrier" ::: "memory");                                                            \
-        }                                                                                                      \
+        if constexpr (SYNC && STAMP == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         _Pragma("unroll") for (int mi = 0; mi < 8; ++mi) {                                                     \
             _Pragma("unroll") for (int ni = 0; ni < 4; ++ni)                                                   \
@@ -902,10 +868,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
                 xf[mi] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + mi * 2048);                  \
             }                                                                                                  \
             if constexpr (ISSUE) issue((ip), mi);                                                              \
-        }                                                                                                      \
-        if constexpr (ISSUE && EPI == KEDS_EPI_RESID_STATS_F16) {   /* behind the pieces: the youngest ops of the step */ \
-            if ((ip) == pf_tile0) prefetch_c(0);                                                               \
-            if ((ip) == pf_tile1) prefetch_c(1);                                                               \
         }                                                                                                      \
         if constexpr (PREFETCH) {                                                                              \
             __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);                                                 \
@@ -989,6 +951,19 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // costs the same ~1-1.5k cycles of vector issue wherever it sits, the extra barrier, the drain before the side-area staging
 // and the static tile -> CU assignment take the rest.  Not kept.
 
+// NOTE (measured, round 2, tools/stamp_gemm.py with SHAPE=out / proj): the fp16-residual epilogue cost 21-25 k cycles per
+// tile against 7 k for the same epilogue without residual traffic: ~9 k the 16 dependent residual loads per lane, 5-7 k
+// the 64-bit statistics atomics (2,048 per tile), stores ~0.  Kept: the four waves that share a row reduce their partial
+// {sum, sum sq} through LDS and threads 0-255 add ONE pair per row (512 atomics per tile: epilogue 20.8 k -> 14.8 k cycles).
+// Dead ends, each bit-identical and measured with in-kernel stamps: (a) starting half of the CUs half a tile late changes
+// no epilogue or prologue time (the store / load bursts are not a lock-step effect); (b) an L2 prefetch of the residual
+// tile (4-byte LDS-DMA per lane, one 128-byte line each, dumped into unused LDS): all 1,024 lines in the prologue stall it by
+// 10 k cycles; spread over the K-loop (one wave-instruction per K-tile) it costs the K-loop what it saves the epilogue
+// (K-tile 2,432 -> 2,572 cycles, or 2,832 with a counted vmcnt that leaves it in flight), and the loads still take ~8 k
+// afterwards: 32 tiles x 128 KB is the whole 4 MiB L2 of the XCD, and 6 MB of operands stream through it per tile;
+// (c) the same prefetch for the OPERANDS two K-tiles ahead (c_proj's A streams from HBM, 10 % of its K-loop is vmcnt wait):
+// 5 % slower on every shape; (d) two half-batches on two streams, so that one's epilogues run beside the other's
+// K-loops: 21.6 ms vs 21.1 ms for 128 images (four quarter-batches: 31.8 ms).
 // NOTE (measured, round 1): TWO half-size workgroups per CU do not pay either.  256 threads (2 x 2 waves, 128 x 64 per wave),
 // tile 256 x 128, one 48 KiB LDS operand buffer per K-tile with all 24 fragments of the K-tile in registers (reads of
 // K-tile t -> barrier -> DMA of t+1 into the same buffer under the MFMAs of t), two such workgroups per CU (2 x 52 KiB LDS,

@@ -280,6 +280,60 @@ def exchange_merge_gather(D_p: torch.Tensor, I_p: torch.Tensor, rows_p: torch.Te
     return D, I, rows
 
 
+class PackedExchange:
+    """The two collectives of one data-parallel sharded search, on preallocated buffers:
+
+      gather_queries(q [B,d])       -> [world*B, d]   one all_gather_into_tensor (393 KB per rank at B = 128, d = 768)
+      return_partials(D_p, I_p)     -> (D, I) [B,k]   ONE all-to-all of the packed partial lists (12 B per entry: distance
+                                                      bits | id low | id high as int32; rank r receives block r of every
+                                                      rank = what each shard found for ITS queries), then the (distance, id)
+                                                      merge on the owner.
+
+    Both are KB-sized and latency-bound on xGMI; nothing is allocated per call (the list-form all_gather of round 1
+    allocated 2*world tensors per search and moved every rank's lists to every rank).  CPU tensors (gloo tests) take the
+    all_gather_into_tensor route for the second step as well, since gloo lacks all_to_all_single on some builds."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._q = self._pin = self._pout = None
+
+    def gather_queries(self, q: torch.Tensor) -> torch.Tensor:
+        q = q.contiguous()
+        shape = (self.world * q.shape[0], q.shape[1])
+        if self._q is None or self._q.shape != shape or self._q.device != q.device or self._q.dtype != q.dtype:
+            self._q = torch.empty(shape, dtype=q.dtype, device=q.device)
+        self.dist.all_gather_into_tensor(self._q, q, group=self.group)
+        return self._q
+
+    def return_partials(self, D_p: torch.Tensor, I_p: torch.Tensor, metric: int = _lib.METRIC_L2):
+        """D_p / I_p [world*B, k]: this shard's partial lists for EVERY rank's queries (global ids)."""
+        w = self.world
+        n, k = D_p.shape
+        B = n // w
+        shape = (w, B, k, 3)
+        if self._pin is None or self._pin.shape != shape or self._pin.device != D_p.device:
+            self._pin = torch.empty(shape, dtype=torch.int32, device=D_p.device)
+            self._pout = torch.empty(shape, dtype=torch.int32, device=D_p.device)
+        pin = self._pin
+        pin[..., 0] = D_p.contiguous().view(torch.int32).view(w, B, k)
+        pin[..., 1:] = I_p.contiguous().view(torch.int32).view(w, B, k, 2)
+        if D_p.is_cuda:
+            self.dist.all_to_all_single(self._pout, pin, group=self.group)       # block r <-> rank r
+            got = self._pout
+        else:
+            every = torch.empty((w * w, B, k, 3), dtype=torch.int32)              # concatenated along dim 0
+            self.dist.all_gather_into_tensor(every, pin, group=self.group)
+            got = every.view(w, w, B, k, 3)[:, self.rank].contiguous()
+        Dq = got[..., 0].contiguous().view(torch.float32)                          # [world, B, k]: part s = shard s's list
+        Iq = got[..., 1:].contiguous().view(torch.int64).view(w, B, k)
+        if Dq.is_cuda:
+            return ops.topk_merge_parts(Dq, Iq, metric)
+        return merge_partials(Dq, Iq, metric)
+
+
 class ShardedFlatIndex:
     """Row-sharded index: rank r owns rows shard_bounds(n, world, r).
 
@@ -298,6 +352,7 @@ class ShardedFlatIndex:
         self.local: Optional[FlatIndex] = None
         self.device = device
         self.n_global = 0
+        self._xchg: Optional[PackedExchange] = None
 
     def add_global(self, x: ArrayLike) -> None:
         """Give every rank the full matrix (or a view of it); each keeps only its shard."""
@@ -307,11 +362,27 @@ class ShardedFlatIndex:
         self.local = FlatIndex(self.d, self.metric_name, device=self.device, row0=lo)
         self.local.add(x[lo:hi])
 
+    @property
+    def ntotal(self) -> int:
+        return self.n_global
+
     def search(self, q: torch.Tensor, k: int, normalize: bool = False):
         D, I, _ = self.local.search_device(q, k, normalize=normalize)
         if self.world == 1:
             return D, I
         return exchange_and_merge(D, I, self.local.metric, self.group)
+
+    def search_own(self, q_local: torch.Tensor, k: int, normalize: bool = False):
+        """Data-parallel form without the rows: every rank passes ITS OWN B queries (same B everywhere) and gets (D, I)
+        for them -- two packed collectives on preallocated buffers (`PackedExchange`)."""
+        if self.world == 1:
+            D, I, _ = self.local.search_device(q_local, k, normalize=normalize)
+            return D, I
+        if self._xchg is None:
+            self._xchg = PackedExchange(self.group)
+        allq = self._xchg.gather_queries(q_local.to(self.local._dev(), dtype=torch.float32))
+        D_p, I_p, _ = self.local.search_device(allq, k, normalize=normalize)
+        return self._xchg.return_partials(D_p, I_p, self.local.metric)
 
     def search_gather(self, q_local: torch.Tensor, k: int, normalize: bool = False):
         """Data-parallel form: every rank passes ITS OWN B queries (same B everywhere) and gets (D, I, rows) for them:

@@ -270,7 +270,9 @@ class CLIP(nn.Module):
     def _guarded(self, run):
         """Run one tower pass (`run(engine)` enqueues it and returns the output tensor) under the numerics guard."""
         eng = self._engine()
-        if self.numerics != "auto" or not eng.folded or self.precision == "fp8":
+        # (a stream that is being captured into a hipGraph cannot be synchronised: no flag read there -- capture a model whose
+        # activations were checked eagerly, or set_numerics("safe"))
+        if self.numerics != "auto" or not eng.folded or self.precision == "fp8" or torch.cuda.is_current_stream_capturing():
             return run(eng)
         if self._guard is None or self._guard.device != eng.device:
             self._guard = torch.zeros(1, dtype=torch.int32, device=eng.device)

@@ -594,11 +594,13 @@ def synth_tokens(batch: int, context_length: int = 77, seed: int = 4004,
 # ----------------------------------------------------------------------------
 # weight / input variants for the full-size parity fixtures (tools/mint_golden.py, tests/test_gpu_fullsize.py)
 # ----------------------------------------------------------------------------
-def sharpen_clip(sd: Mapping[str, Tensor], qk: float = 3.0, resid: float = 4.0) -> Dict[str, Tensor]:
+def sharpen_clip(sd: Mapping[str, Tensor], qk: float = 1.5, resid: float = 2.0) -> Dict[str, Tensor]:
     """Random-init towers average their tokens almost uniformly, so every input lands on nearly the same embedding
     (cosine 0.995 between unrelated images) and a ranking over such features is decided by rounding noise.  Scaling the
-    q/k projections (peaky attention) and the residual-branch output projections of the VISUAL tower gives embeddings with
-    cosine ~0.4 between unrelated images: a retrieval problem whose margins are far above the stated fp tolerance."""
+    q/k projections (peakier attention) and the residual-branch output projections of the VISUAL tower spreads the
+    embeddings: cosine ~0.9 between unrelated images at (1.5, 2.0).  Stronger settings turn the random network chaotic --
+    at (3, 4) rounding the WEIGHTS to bf16 alone moves the fp32 embedding to cosine 0.90, at (2.5, 3) to 0.997, at (1.5, 2)
+    to 0.999993 (measured with this oracle) -- which would test the network's conditioning, not the kernels."""
     out = dict(sd)
     w = sd["visual.conv1.weight"].shape[0]
     i = 0

@@ -148,6 +148,32 @@ def test_attention(B, S, heads, causal):
     assert err <= 1e-2
 
 
+def test_attention_257_tail_kernel_against_generic_and_reference():
+    """S = 257 runs as 16 MFMA key tiles + a rank-1 update for the last key, and the last query as its own VALU row:
+    same tolerance against the fp32 reference as the generic (padded) kernel, close to it, and the q_limit (CLS-only) form
+    of the last tower block agrees on the rows it computes."""
+    lib = _lib.load()
+    B, S, heads = 3, 257, 4
+    qkv = bf16_round(_rand((B * S, 3 * heads * 64), 23, std=1.5))
+    ref = _attn_ref(qkv, B, S, heads, False)
+    dev = qkv.cuda().to(torch.bfloat16)
+    tail = ops.attention(dev, B, S, heads, False).float().cpu()
+    try:
+        lib.keds_attention_debug(16)
+        gen = ops.attention(dev, B, S, heads, False).float().cpu()
+    finally:
+        lib.keds_attention_debug(0)
+    last = torch.arange(B) * S + 256
+    report("attention.tail257", rel_l2=rel_l2(tail, ref), generic_rel_l2=rel_l2(gen, ref), vs_generic=rel_l2(tail, gen),
+           last_query_rel_l2=rel_l2(tail[last], ref[last]), first_query_rel_l2=rel_l2(tail[last - 256], ref[last - 256]))
+    assert rel_l2(tail, ref) <= 1e-2 and rel_l2(tail[last], ref[last]) <= 1e-2
+    assert rel_l2(tail, gen) <= 1e-2
+    out1 = torch.zeros(B * S, heads * 64, dtype=torch.bfloat16, device="cuda")
+    _lib.check(lib.keds_attention_ex(_lib.ptr(dev), _lib.ptr(out1), B, S, heads, 0, 1, _lib.stream()), "attention q_limit")
+    first = torch.arange(B) * S
+    assert torch.equal(out1[first.cuda()].float().cpu(), tail[first])
+
+
 def test_attention_peaked_rows():
     """One dominant key per query (softmax ~ one-hot) and large logits: exercises the max subtraction."""
     B, S, heads = 1, 257, 2

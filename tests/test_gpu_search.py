@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 D_ATOL = 2e-6
 
 
-def _check(index, db, q, k, name, normalize=False):
+def _check(index, db, q, k, name, normalize=False, max_swap_rows=None):
     """Indices equal to the oracle's, except that two rows whose exact (fp64) distances agree within 1e-6 may swap
     ranks: the GPU orders the final candidates by fp32 distances (error ~1e-7), the oracle by fp64."""
     D, I, rows = index.search_gather(q.cuda(), k, normalize=normalize)
@@ -31,7 +31,8 @@ def _check(index, db, q, k, name, normalize=False):
     assert max_abs(D, Do) <= D_ATOL
     if mism:
         bad_rows = torch.nonzero((I != Io).any(dim=1)).flatten()
-        assert len(bad_rows) <= max(1, q.shape[0] // 200), f"{len(bad_rows)} rows differ"
+        limit = max(1, q.shape[0] // 200) if max_swap_rows is None else max_swap_rows
+        assert len(bad_rows) <= limit, f"{len(bad_rows)} rows differ"
         for r in bad_rows.tolist():
             exact = ((qq[r].double()[None, :] - db[I[r]].double()) ** 2).sum(1)      # fp64 distances of OUR ids
             assert float((exact - Do[r].double()).abs().max()) <= 1e-6, "not a near-tie swap"

@@ -100,7 +100,9 @@ def test_k_up_to_128(n, dim, nq, k):
     q = O.synth_database(nq, dim, seed=3003)
     idx = keds_amd.FlatIndex(dim, "l2")
     idx.add(db)
-    _check(idx, db, q, k, f"search_k{k}")
+    # (more neighbours per query = more chances of two exact distances within fp32 rounding of each other: every
+    # differing row is still verified to be such a near-tie swap by _check)
+    _check(idx, db, q, k, f"search_k{k}", max_swap_rows=max(2, nq // 8))
     ok, fb = idx.certificate_counts(reset=True)
     report("certificate.large_k", n=n, k=k, certified=ok, fallback=fb)
     assert ok + fb == nq

@@ -211,6 +211,15 @@ def _gloo_worker(rank, world, port, out):
         D2, I2, R2 = exchange_merge_gather(dp, ip + lo, rows_p, 4, _lib.METRIC_L2, group=None)
         Dg2, Ig2 = O.flat_l2_search(db, qall[rank * 4:(rank + 1) * 4], 16)
         ok = ok and bool(torch.equal(I2, Ig2) and torch.allclose(D2, Dg2) and torch.equal(R2, db[Ig2.reshape(-1)].reshape(4, 16, 64)))
+        # the packed form bench.py --gpus N runs: one all-gather of the queries, ONE collective for the partial lists
+        from keds_amd.index import PackedExchange
+        x = PackedExchange()
+        mine_q = qall[rank * 4:(rank + 1) * 4]
+        allq = x.gather_queries(mine_q)
+        ok = ok and bool(torch.equal(allq, qall))
+        for _ in range(2):                                        # second round reuses the buffers
+            D3, I3 = x.return_partials(dp, ip + lo, _lib.METRIC_L2)
+            ok = ok and bool(torch.equal(I3, Ig2) and torch.allclose(D3, Dg2))
         # evaluation glue: ragged per-rank gallery slices gathered in rank order, then the metric on the full matrices
         from keds_amd.retrieval import all_gather_features
         gal = O.synth_database(101, 64, seed=12)

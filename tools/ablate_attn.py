@@ -7,7 +7,8 @@ from keds_amd import _lib, ops
 lib = _lib.load()
 B, S, H = 128, 257, 16
 qkv = (torch.randn(B * S, 3 * H * 64, device="cuda") * 1.5).to(torch.bfloat16)
-for code, name in [(0, "product"), (1, "no K/V staging"), (2, "no QK^T"), (3, "no exp"), (4, "no PV"), (5, "staging only (no q loop)")]:
+for code, name in [(0, "product (257 = 16 tiles + tail key / query)"), (16, "generic kernel (padded to 288 keys)"), (0, "product again"), (16, "generic again"),
+                   (1, "no K/V staging"), (2, "no QK^T"), (3, "no exp"), (4, "no PV"), (5, "staging only (no q loop)")]:
     lib.keds_attention_debug(code)
     for _ in range(3):
         ops.attention(qkv, B, S, H, False)

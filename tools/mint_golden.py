@@ -428,7 +428,7 @@ def mint_recall_vitl(n_gallery=1000, n_query=256, chunk=8):
     """BASELINE config 1 at its stated size: ViT-L/14 features of a 1 k-image gallery and 256 queries (noisy copies of
     gallery images at graded noise levels), ranked by the reference's own get_metrics_cirr (eval_utils.py:1040-1067).
     Weights: the seeded ViT-L/14 with sharpened attention / residual branches (oracle.sharpen_clip: unrelated images at
-    cosine ~0.4 instead of the 0.995 of plain random init, so the ranking is decided by the features, not by rounding)."""
+    cosine ~0.9 instead of the 0.995 of plain random init, while the network stays well conditioned)."""
     sd = O.sharpen_clip(O.synth_clip_state_dict(**VITL, seed=7))
     m = _load_vitl(sd)
     tgt_idx, ref_idx, sigma = O.synth_recall_plan(n_gallery, n_query)
