@@ -76,10 +76,24 @@ __device__ __forceinline__ void wait_stage_and_barrier(int ahead) {
 // DBG (timing-only ablations; results wrong unless 0): 1 = no list update, 2 = no MFMA (and no list update),
 // 3 = no LDS fragment reads
 // L = per-lane list depth: LISTK (16) for the candidate pass, 4 for the threshold pass
-template <int D, int L = LISTK, int DBG = 0>
+// order-preserving integer image of a score: a > b  <=>  ord_key(a) > ord_key(b); 0 is below every real score's key
+__device__ __forceinline__ unsigned ord_key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_float(unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); }
+
+// NT: LDS-DMA cache policy of the key stream (aux = 2: non-temporal -- the image is read once per search and is far larger
+// than the caches; measured 3-6 % faster on the whole 0.5 M-row search).
+// Output: the VALID entries of the workgroup's four lists of a query (its 16-lane key quarters), packed to the front of the
+// workgroup's segment out_pairs[(query * nwg + wg) * 4L ..] as (ord_key(score) << 32 | row id), and
+// out_meta[query * nwg + wg] = {entries written, largest key sitting in the LAST slot of a full list (0: none)}.
+// With insert thresholds almost every list slot stays empty: the merge then reads a handful of pairs per segment instead
+// of all 4L slots of it.
+template <int D, int L = LISTK, int DBG = 0, int NT = 0>
 __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
     const char* __restrict__ packed, int stage_begin, int total_stages, const bf16_t* __restrict__ qb,
-    const float* __restrict__ thr, float* __restrict__ out_val, int* __restrict__ out_idx) {
+    const float* __restrict__ thr, unsigned long long* __restrict__ out_pairs, uint2* __restrict__ out_meta) {
     using C = ScanCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -119,11 +133,11 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
         for (int i = 0; i < C::PPW; ++i) {
             const int piece = wave + 8 * i;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, NT ? 2 : 0);
         }
         if (lane < 8) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + C::KEYB),
-                                             (__attribute__((address_space(3))) void*)(dst + C::KEYB + wave * 128), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(dst + C::KEYB + wave * 128), 16, 0, NT ? 2 : 0);
         }
     };
 
@@ -200,13 +214,25 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
         slot = slot + 1 == C::NST ? 0 : slot + 1;
     }
 
-    // lists out: [query][wg][g][L]
-    const size_t o = (((size_t)qglob * nwg + blockIdx.x) * 4 + g) * L;
+    // valid entries out (a list is sorted, its valid entries come first), packed over the four lanes of the query
+    int n = 0;
 #pragma unroll
-    for (int j = 0; j < L; j += 4) {
-        *reinterpret_cast<f32x4*>(out_val + o + j) = f32x4{lv[j], lv[j + 1], lv[j + 2], lv[j + 3]};
-        *reinterpret_cast<int4*>(out_idx + o + j) = make_int4(li[j], li[j + 1], li[j + 2], li[j + 3]);
+    for (int j = 0; j < L; ++j) n += li[j] >= 0 ? 1 : 0;
+    const int n0 = __shfl(n, c, 64), n1 = __shfl(n, c + 16, 64), n2 = __shfl(n, c + 32, 64), n3 = __shfl(n, c + 48, 64);
+    const int base = g == 0 ? 0 : (g == 1 ? n0 : (g == 2 ? n0 + n1 : n0 + n1 + n2));
+    unsigned lk = n == L ? ord_key(lv[L - 1]) : 0u;
+    {
+        auto a = __builtin_amdgcn_permlane16_swap(lk, lk, false, false);
+        lk = a[0] > a[1] ? a[0] : a[1];
+        auto b = __builtin_amdgcn_permlane32_swap(lk, lk, false, false);
+        lk = b[0] > b[1] ? b[0] : b[1];
     }
+    const size_t seg = (size_t)qglob * nwg + blockIdx.x;
+    unsigned long long* op = out_pairs + seg * (4 * L) + base;
+#pragma unroll
+    for (int j = 0; j < L; ++j)
+        if (j < n) op[j] = ((unsigned long long)ord_key(lv[j]) << 32) | (unsigned)li[j];
+    if (g == 0) out_meta[seg] = uint2{(unsigned)(n0 + n1 + n2 + n3), lk};
 }
 
 // ------------------------------------------------------------------------------------------
@@ -279,25 +305,45 @@ __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q,
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) counters[0] = 0;
     if (row >= qb_rows) return;
+    constexpr int MAXV = 4;                       // dim <= 1024: four float4 per lane, all loads in flight together
+    const int nv = dim >> 8;                      // 256 floats per wave pass (dim % 128 == 0: a last half pass is predicated)
+    const bool half = (dim & 255) != 0;
+    bf16_t* qbr = qb + (size_t)row * dim;
     if (row >= nq) {
-        for (int i = lane; i < dim; i += 64) qb[(size_t)row * dim + i] = (bf16_t)0.f;
+        for (int i = lane * 4; i < dim; i += 256) *reinterpret_cast<bf16x4*>(qbr + i) = bf16x4{0, 0, 0, 0};
         return;
     }
     const float* p = q + (size_t)row * dim;
+    f32x4 v[MAXV + 1];
+#pragma unroll
+    for (int j = 0; j <= MAXV; ++j) {
+        const int i = lane * 4 + 256 * j;
+        const bool on = j < nv || (j == nv && half && i < dim);
+        v[j] = on ? *reinterpret_cast<const f32x4*>(p + i) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     float s = 0.f;
-    for (int i = lane; i < dim; i += 64) s += p[i] * p[i];
+#pragma unroll
+    for (int j = 0; j <= MAXV; ++j) s += v[j][0] * v[j][0] + v[j][1] * v[j][1] + v[j][2] * v[j][2] + v[j][3] * v[j][3];
     s = wave_sum(s);
     const float nrm = sqrtf(s);
     float s2 = 0.f, st = 0.f, sr = 0.f;
-    for (int i = lane; i < dim; i += 64) {
-        const float v = normalize ? p[i] / nrm : p[i];
-        const bf16_t vb = (bf16_t)v;
-        const float vt = (float)vb;
-        qn[(size_t)row * dim + i] = v;
-        qb[(size_t)row * dim + i] = vb;
-        s2 += v * v;
-        st += vt * vt;
-        sr += (v - vt) * (v - vt);
+#pragma unroll
+    for (int j = 0; j <= MAXV; ++j) {
+        const int i = lane * 4 + 256 * j;
+        const bool on = j < nv || (j == nv && half && i < dim);
+        if (!on) continue;
+        f32x4 x = v[j];
+        if (normalize) x = f32x4{x[0] / nrm, x[1] / nrm, x[2] / nrm, x[3] / nrm};
+        const bf16x4 xb = bf16x4{(bf16_t)x[0], (bf16_t)x[1], (bf16_t)x[2], (bf16_t)x[3]};
+        *reinterpret_cast<f32x4*>(qn + (size_t)row * dim + i) = x;
+        *reinterpret_cast<bf16x4*>(qbr + i) = xb;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float vt = (float)xb[e];
+            s2 += x[e] * x[e];
+            st += vt * vt;
+            sr += (x[e] - vt) * (x[e] - vt);
+        }
     }
     s2 = wave_sum(s2);
     st = wave_sum(st);
@@ -306,187 +352,194 @@ __global__ __launch_bounds__(256) void qprep_kernel(const float* __restrict__ q,
 }
 
 // ------------------------------------------------------------------------------------------
-// merge: exact top-NCAND of the per-lane lists (+ optional extra candidates) of one query by a 4-pass
-// 8-bit radix select on the order-preserving integer image of the score; ties at the cut go to the smaller id.
-// One 256-thread block per query, entries held in registers.  Output order is arbitrary (the re-rank sorts).
-// thr_out[q] = the NCAND-th best score (or -inf if fewer valid entries): the insert threshold of phase B.
-__device__ __forceinline__ unsigned ord_key(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+// merge: exact top-ncand of the union of a query's scan lists, by (score, smaller id at the cut), + the score bound of
+// everything left out of it (certificate).  One 256-thread block per query; thread t owns the segment of scan workgroup t
+// (meta = {valid entries, last-slot key}, pairs packed at the front).
+//   V <= 4096 valid entries (the normal case: with insert thresholds ~1 entry per list): the pairs are packed into LDS,
+//     ONE wave takes all keys into registers and finds the cut T = the ncand-th largest key by bisection on the bits that
+//     differ, counting with wave-wide DPP reductions (no barrier per bit), and the block collects from LDS;
+//   more (dense lists: single-phase scans of small databases): every thread keeps its segment's <= 64 pairs in registers
+//     and the block bisects together (two barriers per bit).
+// thr_out[q] = T (or -inf if fewer than ncand valid entries): the insert threshold of the candidate pass.
+// sbound_out[q]: upper bound on the bf16 score of every row that is NOT among the candidates.  Such a row was (a) in the
+//   union and cut: score <= T; (b) rejected by the insert threshold: score <= thr_in; (c) pushed out of a full per-lane
+//   list: score <= that list's last entry (meta.y).  (a) only exists when V > ncand, and then T > thr_in.
+template <class Op>
+__device__ __forceinline__ unsigned wave_reduce_u32(unsigned x, Op op) {       // DPP (lane bits 0-3) + permlane swaps (4, 5)
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    x = op(x, (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x140, 0xF, 0xF, true));    // row_mirror
+    auto a = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    x = op(a[0], a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    return op(b[0], b[1]);
 }
 
-constexpr int MERGE_THREADS = 256;    // measured: 1024 threads is 8 % faster for 128 queries but 45 % slower for 1024
+constexpr int MERGE_THREADS = 256;
 constexpr int MERGE_WAVES = MERGE_THREADS / 64;
-constexpr int MERGE_MAXE = 66;         // entries per thread: (1024 lists * 16 + 64 extra) / 256 = 64.25
-constexpr int MERGE_DENSE = 1024;      // packed valid keys per wave that still fit 16 registers per lane
+constexpr int MERGE_SLOTS = 4 * LISTK;    // pairs per segment at most (64)
+constexpr int MERGE_LDS_PAIRS = 4096;
+constexpr int MERGE_SPEC = 16;            // segment slots loaded before the segment's count is known
 
-__global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float* __restrict__ val, const int* __restrict__ idx,
-                                                           int nlists, int listk, const float* __restrict__ xval,
-                                                           const int* __restrict__ xidx, int nextra,
-                                                           int* __restrict__ cand_idx, float* __restrict__ cand_val,
-                                                           float* __restrict__ thr_out, int ncand,
-                                                           const float* __restrict__ thr_in, float* __restrict__ sbound_out) {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned ckeys[MERGE_WAVES][MERGE_DENSE];
-    __shared__ unsigned s_out, s_eq;
+__global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsigned long long* __restrict__ pairs,
+                                                                    const uint2* __restrict__ meta, int nwg, int slots,
+                                                                    int* __restrict__ cand_idx, float* __restrict__ cand_val,
+                                                                    float* __restrict__ thr_out, int ncand,
+                                                                    const float* __restrict__ thr_in,
+                                                                    float* __restrict__ sbound_out) {
+    __shared__ unsigned long long lp[MERGE_LDS_PAIRS];
+    __shared__ unsigned s_red[4][MERGE_WAVES];
+    __shared__ unsigned s_T, s_rem, s_out, s_eq;
     __shared__ int eq_idx[256];
     __shared__ float eq_val[256];
-    const int q = blockIdx.x, tid = threadIdx.x;
-    const int nmain = nlists * listk;
-    const int total = nmain + nextra;
-    const float* v = val + (size_t)q * nmain;
-    const int* ix = idx + (size_t)q * nmain;
-    unsigned key[MERGE_MAXE];
-    int id[MERGE_MAXE];
-    unsigned nvalid = 0;
-    unsigned lastkey = 0;      // largest key that sits in the LAST slot of a (therefore full) per-lane list
-    {
-        // unconditional (index-clamped) loads so that all of a thread's entries are in flight together; predicated
-        // loads were being issued one round trip at a time
-        float fv[MERGE_MAXE];
-        const int last = total > 0 ? total - 1 : 0;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    auto umax = [](unsigned a, unsigned b) { return a > b ? a : b; };
+    auto umin = [](unsigned a, unsigned b) { return a < b ? a : b; };
+    auto uadd = [](unsigned a, unsigned b) { return a + b; };
+    // A dependent global round trip costs ~5 us in these small kernels: the first MERGE_SPEC slots of the segment are
+    // loaded SPECULATIVELY together with the segment's count (a segment rarely holds more with insert thresholds, and the
+    // threshold pass has exactly 16), so the usual merge waits for memory once.
+    const unsigned long long* seg = pairs + ((size_t)q * nwg + (tid < nwg ? tid : 0)) * slots;
+    unsigned long long pr[MERGE_SLOTS];
 #pragma unroll
-        for (int i = 0; i < MERGE_MAXE; ++i) {
-            const int e = tid + i * MERGE_THREADS;
-            const int ec = e < last ? e : last;
-            const bool main_e = ec < nmain;
-            const float* vp = main_e ? v + ec : xval + (size_t)q * nextra + (ec - nmain);
-            const int* ip = main_e ? ix + ec : xidx + (size_t)q * nextra + (ec - nmain);
-            fv[i] = *vp;
-            id[i] = *ip;
-        }
+    for (int j = 0; j < MERGE_SLOTS; ++j) pr[j] = 0ull;
 #pragma unroll
-        for (int i = 0; i < MERGE_MAXE; ++i) {
-            const int e = tid + i * MERGE_THREADS;
-            if (e >= total) id[i] = -1;
-            key[i] = id[i] >= 0 ? ord_key(fv[i]) : 0u;      // 0 is below every real score's key
-            nvalid += id[i] >= 0 ? 1u : 0u;
-            if (id[i] >= 0 && e < nmain && (e % listk) == listk - 1 && key[i] > lastkey) lastkey = key[i];
+    for (int j = 0; j < MERGE_SPEC; ++j)
+        if (j < slots) pr[j] = seg[j];                                                  // slots is kernel-uniform
+    const uint2 m = tid < nwg ? meta[(size_t)q * nwg + tid] : uint2{0u, 0u};
+    const unsigned cnt = m.x;
+    const unsigned wmax = wave_reduce_u32(cnt, umax);
+#pragma unroll
+    for (int j = MERGE_SPEC; j < MERGE_SLOTS; ++j)
+        if ((unsigned)j < wmax) pr[j] = (unsigned)j < cnt ? seg[j] : 0ull;             // wave-uniform skip of the tail
+#pragma unroll
+    for (int j = 0; j < MERGE_SPEC; ++j)
+        if ((unsigned)j >= cnt) pr[j] = 0ull;                                           // stale bytes of earlier searches
+    unsigned kmax = 0, kmin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < MERGE_SLOTS; ++j)
+        if ((unsigned)j < cnt) {
+            const unsigned k = (unsigned)(pr[j] >> 32);
+            kmax = k > kmax ? k : kmax;
+            kmin = k < kmin ? k : kmin;
         }
+    // block totals: V, key range, last-slot key; and this thread's offset into the packed LDS list
+    unsigned incl = cnt;                                           // inclusive prefix over the lanes of the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned up = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += up;
     }
-    // block-wide reductions through 4 LDS words (one per wave); no atomics on shared bins: the scores of one
-    // query share their high bits, so histogram atomics would serialise
-    const int lane = tid & 63, wv = tid >> 6;
-    auto block_sum = [&](unsigned x) -> unsigned {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
-        __syncthreads();                       // previous readers of hist[0..3] are done
-        if (lane == 0) hist[wv] = x;
-        __syncthreads();
-        unsigned t = 0;
-#pragma unroll
-        for (int w = 0; w < MERGE_WAVES; ++w) t += hist[w];
-        return t;
-    };
-    auto block_or = [&](unsigned x) -> unsigned {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) x |= __shfl_xor(x, o, 64);
-        __syncthreads();
-        if (lane == 0) hist[wv] = x;
-        __syncthreads();
-        unsigned t = 0;
-#pragma unroll
-        for (int w = 0; w < MERGE_WAVES; ++w) t |= hist[w];
-        return t;
-    };
+    const unsigned wsum = __shfl(incl, 63, 64);
+    kmax = wave_reduce_u32(kmax, umax);
+    kmin = wave_reduce_u32(kmin, umin);
+    unsigned lastkey = wave_reduce_u32(m.y, umax);
     if (tid == 0) {
         s_out = 0;
         s_eq = 0;
     }
-    const unsigned V = block_sum(nvalid);
+    if (lane == 0) {
+        s_red[0][wv] = wsum;
+        s_red[1][wv] = kmax;
+        s_red[2][wv] = kmin;
+        s_red[3][wv] = lastkey;
+    }
+    __syncthreads();
+    unsigned V = 0, wbase = 0;
+#pragma unroll
+    for (int w = 0; w < MERGE_WAVES; ++w) {
+        if (w < wv) wbase += s_red[0][w];
+        V += s_red[0][w];
+        kmax = umax(kmax, s_red[1][w]);
+        kmin = umin(kmin, s_red[2][w]);
+        lastkey = umax(lastkey, s_red[3][w]);
+    }
     const unsigned want = V < (unsigned)ncand ? V : (unsigned)ncand;
-    unsigned T = 0;          // threshold key: entries with key > T are taken, `rem` of those with key == T
-    unsigned rem = want;
-    if (V > (unsigned)ncand) {
-        // bits that differ between valid keys: skip the common leading bits
-        unsigned kmax = 0, kxor = 0;
-#pragma unroll
-        for (int i = 0; i < MERGE_MAXE; ++i)
-            if (id[i] >= 0) kmax = key[i] > kmax ? key[i] : kmax;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned other = __shfl_xor(kmax, o, 64);
-            kmax = other > kmax ? other : kmax;
+    unsigned T = 0, rem = want;
+    const unsigned kx = kmax ^ kmin;
+    const int top = (V > 0 && kx) ? 31 - __builtin_clz(kx) : -1;                  // highest bit in which two valid keys differ
+    unsigned prefix = top < 0 ? kmax : (top >= 31 ? 0u : (kmax & ~((2u << top) - 1u)));
+    const bool small = V <= (unsigned)MERGE_LDS_PAIRS;                            // block-uniform
+    // collect: key > T always; key == T into the tie buffer (only when a cut exists)
+    auto take = [&](unsigned long long p2, unsigned Tc) {
+        const unsigned k = (unsigned)(p2 >> 32);
+        const int id = (int)(unsigned)(p2 & 0xFFFFFFFFu);
+        if (V <= (unsigned)ncand || k > Tc) {
+            const unsigned o = atomicAdd(&s_out, 1u);
+            cand_idx[q * ncand + o] = id;
+            cand_val[q * ncand + o] = key_float(k);
+        } else if (k == Tc) {
+            const unsigned o = atomicAdd(&s_eq, 1u);
+            if (o < 256) {
+                eq_idx[o] = id;
+                eq_val[o] = key_float(k);
+            }
         }
+    };
+    if (small) {
+        const unsigned off = wbase + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < MERGE_SLOTS; ++j)
+            if ((unsigned)j < cnt) lp[off + j] = pr[j];
         __syncthreads();
-        if (lane == 0) hist[wv] = kmax;
-        __syncthreads();
-        kmax = hist[0];
+        if (V > (unsigned)ncand) {
+            if (wv == 0) {
+                unsigned ck[MERGE_LDS_PAIRS / 64];
+                const int nj = (int)((V + 63u) >> 6);
 #pragma unroll
-        for (int w = 1; w < MERGE_WAVES; ++w) kmax = hist[w] > kmax ? hist[w] : kmax;
+                for (int j = 0; j < MERGE_LDS_PAIRS / 64; ++j)
+                    ck[j] = (j < nj && (unsigned)(lane + 64 * j) < V) ? (unsigned)(lp[lane + 64 * j] >> 32) : 0u;
+                // T = the ncand-th largest key: greedy bit by bit, largest T with count(key >= T) >= want
+#pragma unroll 1
+                for (int bit = top; bit >= 0; --bit) {
+                    const unsigned cand = prefix | (1u << bit);
+                    unsigned c2 = 0;
 #pragma unroll
-        for (int i = 0; i < MERGE_MAXE; ++i)
-            if (id[i] >= 0) kxor |= key[i] ^ kmax;
-        kxor = block_or(kxor);
-        const int top = kxor ? 31 - __builtin_clz(kxor) : -1;      // highest differing bit
-        // T = the NCAND-th largest key: greedy bit by bit, largest T with count(key >= T) >= want
-        unsigned prefix = top >= 31 ? 0u : (kmax & ~((2u << top) - 1u));   // common high bits (top == -1: all equal)
-        if (top < 0) prefix = kmax;
-        // With thresholds most list slots are empty.  Each wave packs its valid keys densely into LDS (ballot prefix,
-        // no atomics); if every wave holds <= 1024 of them a lane re-reads at most 16, and the bisection counts over
-        // 16 registers instead of MERGE_MAXE.
-        unsigned wcnt = 0;
+                    for (int j = 0; j < MERGE_LDS_PAIRS / 64; ++j)
+                        if (j < nj) c2 += ck[j] >= cand ? 1u : 0u;               // wave-uniform skip
+                    if (wave_reduce_u32(c2, uadd) >= want) prefix = cand;
+                }
+                unsigned gtc = 0;
 #pragma unroll
-        for (int i = 0; i < MERGE_MAXE; ++i) {
-            const bool valid = id[i] >= 0;
-            const unsigned long long mask = __ballot(valid);
-            if (valid) {
-                const unsigned pos = wcnt + __popcll(mask & ((1ull << lane) - 1ull));
-                if (pos < (unsigned)MERGE_DENSE) ckeys[wv][pos] = key[i];
+                for (int j = 0; j < MERGE_LDS_PAIRS / 64; ++j) gtc += ck[j] > prefix ? 1u : 0u;
+                gtc = wave_reduce_u32(gtc, uadd);
+                if (lane == 0) {
+                    s_T = prefix;
+                    s_rem = want - gtc;
+                }
             }
-            wcnt += (unsigned)__popcll(mask);
+            __syncthreads();
+            T = s_T;
+            rem = s_rem;
         }
-        const bool dense = block_or(wcnt > (unsigned)MERGE_DENSE ? 1u : 0u) == 0u;   // also makes the LDS writes visible
-        if (dense) {
-            unsigned ck[MERGE_DENSE / 64];
-#pragma unroll
-            for (int j = 0; j < MERGE_DENSE / 64; ++j) ck[j] = (unsigned)(lane + 64 * j) < wcnt ? ckeys[wv][lane + 64 * j] : 0u;
+        for (unsigned p2 = tid; p2 < V; p2 += MERGE_THREADS) take(lp[p2], T);
+    } else {
+        // dense lists: block-wide bisection over the registers (two barriers per bit)
+        auto block_sum = [&](unsigned x) -> unsigned {
+            x = wave_reduce_u32(x, uadd);
+            __syncthreads();
+            if (lane == 0) s_red[0][wv] = x;
+            __syncthreads();
+            return s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3];
+        };
 #pragma unroll 1
-            for (int bit = top; bit >= 0; --bit) {
-                const unsigned cand = prefix | (1u << bit);
-                unsigned cnt = 0;
+        for (int bit = top; bit >= 0; --bit) {
+            const unsigned cand = prefix | (1u << bit);
+            unsigned c2 = 0;
 #pragma unroll
-                for (int j = 0; j < MERGE_DENSE / 64; ++j) cnt += ck[j] >= cand ? 1u : 0u;
-                if (block_sum(cnt) >= want) prefix = cand;
-            }
-        } else {
-#pragma unroll 1
-            for (int bit = top; bit >= 0; --bit) {
-                const unsigned cand = prefix | (1u << bit);
-                unsigned cnt = 0;
-#pragma unroll
-                for (int i = 0; i < MERGE_MAXE; ++i) cnt += key[i] >= cand ? 1u : 0u;    // invalid keys are 0 < cand
-                if (block_sum(cnt) >= want) prefix = cand;
-            }
+            for (int j = 0; j < MERGE_SLOTS; ++j) c2 += ((unsigned)j < cnt && (unsigned)(pr[j] >> 32) >= cand) ? 1u : 0u;
+            if (block_sum(c2) >= want) prefix = cand;
         }
         T = prefix;
         unsigned gt = 0;
 #pragma unroll
-        for (int i = 0; i < MERGE_MAXE; ++i) gt += key[i] > T ? 1u : 0u;
+        for (int j = 0; j < MERGE_SLOTS; ++j) gt += ((unsigned)j < cnt && (unsigned)(pr[j] >> 32) > T) ? 1u : 0u;
         rem = want - block_sum(gt);
         __syncthreads();
-    }
-    // collect: key > T always; key == T into the tie buffer (only when a cut exists)
 #pragma unroll
-    for (int i = 0; i < MERGE_MAXE; ++i) {
-        if (id[i] < 0) continue;
-        const unsigned k = key[i];
-        float f;
-        {
-            const unsigned u = (k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k;
-            f = __uint_as_float(u);
-        }
-        if (V <= (unsigned)ncand || k > T) {
-            const unsigned o = atomicAdd(&s_out, 1u);
-            cand_idx[q * ncand + o] = id[i];
-            cand_val[q * ncand + o] = f;
-        } else if (k == T) {
-            const unsigned o = atomicAdd(&s_eq, 1u);
-            if (o < 256) {
-                eq_idx[o] = id[i];
-                eq_val[o] = f;
-            }
-        }
+        for (int j = 0; j < MERGE_SLOTS; ++j)
+            if ((unsigned)j < cnt) take(pr[j], T);
     }
     __syncthreads();
     if (V > (unsigned)ncand) {
@@ -503,32 +556,16 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_select_kernel(const float
             }
         }
     }
-    // fillers when fewer than NCAND valid entries
-    for (int o = (int)want + tid; o < ncand; o += MERGE_THREADS) {
+    for (int o = (int)want + tid; o < ncand; o += MERGE_THREADS) {       // fillers when fewer than ncand valid entries
         cand_idx[q * ncand + o] = -1;
         cand_val[q * ncand + o] = -INFINITY;
     }
-    auto key_float = [](unsigned k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k); };
-    if (thr_out && tid == 0) thr_out[q] = V > (unsigned)ncand ? key_float(T) : -INFINITY;
-    if (sbound_out) {
-        // Upper bound on the bf16 score of every row that is NOT among the candidates.  Such a row was (a) in the union
-        // and cut: score <= T; (b) rejected by the insert threshold: score <= thr_in; (c) pushed out of a full per-lane
-        // list: score <= that list's last entry.  (a) only exists when V > ncand, and then T > thr_in.
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const unsigned other = __shfl_xor(lastkey, o, 64);
-            lastkey = other > lastkey ? other : lastkey;
-        }
-        __syncthreads();
-        if (lane == 0) hist[wv] = lastkey;
-        __syncthreads();
-        if (tid == 0) {
-            unsigned lk = hist[0];
-#pragma unroll
-            for (int w = 1; w < MERGE_WAVES; ++w) lk = hist[w] > lk ? hist[w] : lk;
-            float b = V > (unsigned)ncand ? key_float(T) : (thr_in ? thr_in[q] : -INFINITY);
-            if (lk) b = fmaxf(b, key_float(lk));
-            sbound_out[q] = b;
+    if (tid == 0) {
+        if (thr_out) thr_out[q] = V > (unsigned)ncand ? key_float(T) : -INFINITY;
+        if (sbound_out) {
+            float b2 = V > (unsigned)ncand ? key_float(T) : (thr_in ? thr_in[q] : -INFINITY);
+            if (lastkey) b2 = fmaxf(b2, key_float(lastkey));
+            sbound_out[q] = b2;
         }
     }
 }
@@ -594,6 +631,10 @@ __global__ __launch_bounds__(256) void certify_select_kernel(const int* __restri
     const int q = blockIdx.x, t = threadIdx.x;
     const float d = cand_d[q * ncand + t];
     const int id = cand_idx[q * ncand + t];
+    // (loaded up front by every thread: the certificate at the end then waits for no further memory round trip)
+    const f32x4 qs = qstat[q];
+    const float sb = sbound[q];
+    const float xt = bounds->xt, rm = bounds->r;
     const float key = metric == KEDS_METRIC_L2 ? d : -d;           // smaller is better
     s_key[t] = key;
     s_id[t] = id;
@@ -624,12 +665,9 @@ __global__ __launch_bounds__(256) void certify_select_kernel(const int* __restri
         I[(size_t)q * k + t] = -1;
     }
     if (t == 0) {
-        const float sb = sbound[q];
         bool ok = sb == -INFINITY;           // nothing was ever left out of the candidate set
         if (force_fail) ok = false;          // test hook (keds_scan_debug bit 5): every query takes the exact pass
         else if (!ok && nvalid >= k) {
-            const f32x4 qs = qstat[q];
-            const float xt = bounds->xt, rm = bounds->r;
             const float tk = metric == KEDS_METRIC_L2 ? 0.5f * (qs[0] - s_dk) : s_dk;
             const float eps = (qs[1] * xt + qs[2] * rm + qs[1] * rm + 2e-4f * qs[2] * xt) * 1.01f +
                               1e-6f * (fabsf(tk) + qs[0] + 1.0f);
@@ -864,8 +902,8 @@ int exact_chunk_rows(int64_t n, int nq_set, int k) {
 struct SearchWs {
     float* qn;       // [nq_pad, dim]
     bf16_t* qb;      // [1024, dim]
-    float* lval;     // [128, nwg, 4, LISTK]
-    int* lidx;
+    unsigned long long* lpairs;   // [1024 queries x (256 / nqb) workgroups][4 * LISTK] packed (key, id) pairs of the scan
+    uint2* lmeta;                 // [1024 x (256 / nqb)] {valid pairs, last-slot key}
     int* cidx;       // [1024, ncand]
     float* cval;
     float* cdist;
@@ -899,8 +937,8 @@ SearchWs carve(void* ws, int nq, int dim, int64_t n, int k) {
     const size_t set = MAXQB * QBLOCK;
     w.qn = (float*)take(nq_pad * dim * sizeof(float));
     w.qb = (bf16_t*)take(set * dim * 2);
-    w.lval = (float*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(float));
-    w.lidx = (int*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(int));
+    w.lpairs = (unsigned long long*)take((size_t)QBLOCK * nwg * 4 * LISTK * sizeof(unsigned long long));
+    w.lmeta = (uint2*)take((size_t)QBLOCK * nwg * sizeof(uint2));
     w.cidx = (int*)take(set * ncand * sizeof(int));
     w.cval = (float*)take(set * ncand * sizeof(float));
     w.cdist = (float*)take(set * ncand * sizeof(float));
@@ -925,10 +963,11 @@ SearchWs carve(void* ws, int nq, int dim, int64_t n, int k) {
 int g_scan_debug = 0;   // timing-only ablations of the D=768 scan kernel
 int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresholds)
 int g_force_exact = 0;  // test hook: 1 sends every query through the exact fallback
+int g_scan_nt = 1;      // non-temporal LDS-DMA for the D = 768 candidate pass (A/B hook: keds_scan_debug bit 6 turns it off)
 
 template <int D, int L>
-int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr, float* lval,
-                int* lidx, int nwg, int nqb, hipStream_t st) {
+int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr,
+                unsigned long long* lval, uint2* lidx, int nwg, int nqb, hipStream_t st) {
     using C = ScanCfg<D>;
     const size_t lds = (size_t)C::NST * C::LDS_STAGE;
     if (int rc = keds_func_lds_once((const void*)scan_topk_kernel<D, L>, (int)lds, "scan_topk_kernel")) return rc;
@@ -949,6 +988,14 @@ int launch_scan(const void* packed, int stage_begin, int total_stages, const bf1
             }
 #undef KEDS_SCAN_DBG
             return keds_check_launch("scan_topk_kernel<dbg>");
+        }
+    }
+    if constexpr (D == 768 && L == LISTK) {
+        if (g_scan_nt) {
+            if (int rc = keds_func_lds_once((const void*)scan_topk_kernel<D, L, 0, 1>, (int)lds, "scan_topk_kernel<nt>")) return rc;
+            scan_topk_kernel<D, L, 0, 1><<<dim3(nwg, nqb), SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb,
+                                                                                     thr, lval, lidx);
+            return keds_check_launch("scan_topk_kernel<nt>");
         }
     }
     scan_topk_kernel<D, L><<<dim3(nwg, nqb), SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, lval,
@@ -987,6 +1034,7 @@ extern "C" int keds_scan_debug(int variant) {
     g_scan_debug = variant & 15;          // bits 0-3: timing-only ablation
     g_scan_phases = (variant >> 4) & 1;   // bit 4: force the single-phase scan (exact as well; for A/B tests)
     g_force_exact = (variant >> 5) & 1;   // bit 5: fail every certificate (tests of the exact fallback)
+    g_scan_nt = (variant >> 6) & 1 ? 0 : 1;   // bit 6: default-policy key stream instead of non-temporal (A/B)
     return KEDS_OK;
 }
 
@@ -1074,20 +1122,20 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
         if ((rc = keds_check_launch("qprep_kernel"))) return rc;
         auto scan_thr = [&]() -> int {                             // depth-4 lists, no threshold
             switch (dim) {
-                case 128: return launch_scan<128, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
-                case 256: return launch_scan<256, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
-                case 512: return launch_scan<512, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
-                case 768: return launch_scan<768, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
-                default: return launch_scan<1024, 4>(packed, 0, stagesA, w.qb, nullptr, w.lval, w.lidx, nwgA, nqb, st);
+                case 128: return launch_scan<128, 4>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                case 256: return launch_scan<256, 4>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                case 512: return launch_scan<512, 4>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                case 768: return launch_scan<768, 4>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                default: return launch_scan<1024, 4>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
             }
         };
         auto scan_all = [&](const float* thr) -> int {            // depth-16 lists over every stage
             switch (dim) {
-                case 128: return launch_scan<128, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
-                case 256: return launch_scan<256, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
-                case 512: return launch_scan<512, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
-                case 768: return launch_scan<768, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
-                default: return launch_scan<1024, LISTK>(packed, 0, total_stages, w.qb, thr, w.lval, w.lidx, nwgB, nqb, st);
+                case 128: return launch_scan<128, LISTK>(packed, 0, total_stages, w.qb, thr, w.lpairs, w.lmeta, nwgB, nqb, st);
+                case 256: return launch_scan<256, LISTK>(packed, 0, total_stages, w.qb, thr, w.lpairs, w.lmeta, nwgB, nqb, st);
+                case 512: return launch_scan<512, LISTK>(packed, 0, total_stages, w.qb, thr, w.lpairs, w.lmeta, nwgB, nqb, st);
+                case 768: return launch_scan<768, LISTK>(packed, 0, total_stages, w.qb, thr, w.lpairs, w.lmeta, nwgB, nqb, st);
+                default: return launch_scan<1024, LISTK>(packed, 0, total_stages, w.qb, thr, w.lpairs, w.lmeta, nwgB, nqb, st);
             }
         };
         if (two_phase) {
@@ -1097,18 +1145,18 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
             // inserts are rare for ANY data.
             if ((rc = scan_thr())) return rc;
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgA * 4, 4, nullptr, nullptr, 0, w.aidx, w.aval,
-                                                              w.thr, ncand, nullptr, nullptr);
-            if ((rc = keds_check_launch("merge_select_kernel(thr)"))) return rc;
+            merge_pairs_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgA, 4 * 4, w.aidx, w.aval, w.thr, ncand, nullptr,
+                                                             nullptr);
+            if ((rc = keds_check_launch("merge_pairs_kernel(thr)"))) return rc;
         }
         if ((rc = scan_all(two_phase ? w.thr : nullptr))) return rc;
         {
             KedsProfScope prof(KEDS_PROF_OTHER, st);
             float* Dq = D + (size_t)q0 * k;
             long long* Iq = (long long*)I + (size_t)q0 * k;
-            merge_select_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lval, w.lidx, nwgB * 4, LISTK, nullptr, nullptr, 0, w.cidx, w.cval,
-                                                              nullptr, ncand, two_phase ? w.thr : nullptr, w.sbound);
-            if ((rc = keds_check_launch("merge_select_kernel"))) return rc;
+            merge_pairs_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgB, 4 * LISTK, w.cidx, w.cval, nullptr, ncand,
+                                                             two_phase ? w.thr : nullptr, w.sbound);
+            if ((rc = keds_check_launch("merge_pairs_kernel"))) return rc;
             rerank_kernel<<<(nb * ncand + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * ncand, ncand);
             if ((rc = keds_check_launch("rerank_kernel"))) return rc;
             certify_select_kernel<<<nb, ncand, 0, st>>>(w.cidx, w.cdist, ncand, metric, k, (long long)id_base, Dq, Iq, w.qstat,
