@@ -347,6 +347,14 @@ int keds_tower_forward(const keds_tower_params* p, float* x, int B,
 /* _transform of src/model/clip.py:107-123 (eval branch) on the device: raw uint8 images [B,H,W,3] of one size (device) ->
  * fp32 [B,3,n_px,n_px]: bicubic Resize of the shorter side to n_px (PIL semantics: two antialiased passes with a uint8
  * intermediate), CenterCrop, /255, (x - mean) / std.  mean3 / std3: HOST arrays of 3 floats. */
+/* bit-exact form: PIL's integer resampling (22-bit fixed-point weights computed by the host exactly as PIL's Resample.c
+ * does, horizontal pass first, uint8 intermediate).  need_h / need_v: the axis is resampled at all (PIL skips a pass that
+ * keeps the size); xb/yb [n_px][2] = {first source index, taps} of every output column/row of the crop, xk/yk
+ * [n_px][ksx|ksy] their int32 weights; left/top: crop offset when an axis is NOT resampled.  out_u8 (nullable)
+ * [B,n_px,n_px,3]: the uint8 image PIL would hand to ToTensor. */
+int keds_preprocess_pil(const unsigned char* images, int B, int H, int W, int n_px, int need_h, int need_v, int left, int top,
+                        const int32_t* xb, const int32_t* xk, int ksx, const int32_t* yb, const int32_t* yk, int ksy,
+                        const float* mean3, const float* std3, float* out, unsigned char* out_u8, void* stream);
 int keds_preprocess(const unsigned char* images, int B, int H, int W, int n_px, const float* mean3, const float* std3,
                     float* out, void* stream);
 

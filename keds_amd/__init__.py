@@ -11,7 +11,7 @@ from .index import (FlatIndex, IndexFlatIP, IndexFlatL2, PackedExchange, Sharded
 from .model import (CLIP, CrossAttention, CrossFormer, IM2TEXT, KnowledgeStream, LayerNorm, QuickGELU,   # noqa: F401
                     ResidualAttentionBlock, Transformer, VisualTransformer, build_model,
                     clip_config_from_state_dict, convert_models_to_fp32, convert_weights)
-from .retrieval import (all_gather_features, build_database, compose_query_features, extract_feature_database, get_cirr_testoutput, get_metrics_cirr, get_metrics_cirr_topk,   # noqa: F401
+from .retrieval import (all_gather_features, build_database, compose_query_features, extract_feature_database, extract_feature_database_sharded, load_database_shard, get_cirr_testoutput, get_metrics_cirr, get_metrics_cirr_topk,   # noqa: F401
                         get_metrics_coco, get_metrics_fashion, get_metrics_imgnet, get_retrieved_features,
                         load_checkpoint, make_stream_modules)
 

@@ -146,6 +146,8 @@ SIGNATURES = {
     "keds_attention_mx": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     "keds_attention": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_preprocess": (i32, [vp, i32, i32, i32, i32, C.POINTER(f32), C.POINTER(f32), vp, vp]),
+    "keds_preprocess_pil": (i32, [vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, C.POINTER(f32),
+                                  C.POINTER(f32), vp, vp, vp]),
     "keds_im2col": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_embed_tokens": (i32, [vp, vp, vp, vp, i32, i32, vp, i32, i32, i32, vp]),
     "keds_readout_workspace_bytes": (sz, [i32, i32]),

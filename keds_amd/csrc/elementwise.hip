@@ -222,6 +222,64 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const unsigned char* __
     o[2 * plane] = (acc2 * (1.f / 255.f) - m2) / s2;
 }
 
+// The same pipeline with PIL's own arithmetic, bit for bit (src/model/clip.py:107-123 runs PIL's ImagingResample): the
+// filter weights arrive as PIL's 22-bit fixed-point integers (computed on the host in float64 exactly as
+// Resample.c:precompute_coeffs / normalize_coeffs_8bpc do -- keds_amd.ops.pil_bicubic_coeffs), every pass accumulates in
+// int32 from the rounding constant 1 << 21 and stores clip8(acc >> 22), the horizontal pass first.  xb / yb: {first source
+// index, taps} per OUTPUT column / row of the crop; xk / yk: their `ks` integer weights.  The uint8 result (optional u8
+// output) equals PIL's resize + crop exactly, and the float output equals ToTensor + Normalize on it in fp32.
+__global__ __launch_bounds__(256) void preprocess_pil_kernel(const unsigned char* __restrict__ img, int B, int H, int W,
+                                                             int n_px, int need_h, int need_v, int left, int top,
+                                                             const int* __restrict__ xb, const int* __restrict__ xk, int ksx,
+                                                             const int* __restrict__ yb, const int* __restrict__ yk, int ksy,
+                                                             float m0, float m1, float m2, float s0, float s1, float s2,
+                                                             float* __restrict__ out, unsigned char* __restrict__ out_u8) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * n_px * n_px) return;
+    const int b = idx / (n_px * n_px), rem = idx - b * n_px * n_px;
+    const int oy = rem / n_px, ox = rem - oy * n_px;
+    const unsigned char* src = img + (size_t)b * H * W * 3;
+    const int x0 = need_h ? xb[2 * ox] : ox + left, xn = need_h ? xb[2 * ox + 1] : 1;
+    const int y0 = need_v ? yb[2 * oy] : oy + top, yn = need_v ? yb[2 * oy + 1] : 1;
+    const int* kx = xk + (size_t)ox * ksx;
+    const int* ky = yk + (size_t)oy * ksy;
+    auto clip8 = [](int v) { v >>= 22; return v < 0 ? 0 : (v > 255 ? 255 : v); };
+    int a0 = 1 << 21, a1 = 1 << 21, a2 = 1 << 21;
+    int r0 = 0, r1 = 0, r2 = 0;
+    for (int y = 0; y < yn; ++y) {
+        const unsigned char* row = src + ((size_t)(y0 + y) * W + x0) * 3;
+        int h0, h1, h2;
+        if (need_h) {
+            h0 = h1 = h2 = 1 << 21;
+            for (int x = 0; x < xn; ++x) {
+                const int k = kx[x];
+                h0 += k * row[3 * x];
+                h1 += k * row[3 * x + 1];
+                h2 += k * row[3 * x + 2];
+            }
+            h0 = clip8(h0); h1 = clip8(h1); h2 = clip8(h2);     // the horizontal pass is stored as uint8
+        } else {
+            h0 = row[0]; h1 = row[1]; h2 = row[2];
+        }
+        if (need_v) {
+            const int k = ky[y];
+            a0 += k * h0; a1 += k * h1; a2 += k * h2;
+        } else {
+            r0 = h0; r1 = h1; r2 = h2;
+        }
+    }
+    if (need_v) { r0 = clip8(a0); r1 = clip8(a1); r2 = clip8(a2); }
+    const size_t plane = (size_t)n_px * n_px;
+    float* o = out + (size_t)b * 3 * plane + (size_t)oy * n_px + ox;
+    o[0] = ((float)r0 / 255.0f - m0) / s0;                      // ToTensor then Normalize, fp32, same operations
+    o[plane] = ((float)r1 / 255.0f - m1) / s1;
+    o[2 * plane] = ((float)r2 / 255.0f - m2) / s2;
+    if (out_u8) {
+        unsigned char* u = out_u8 + ((size_t)b * plane + (size_t)oy * n_px + ox) * 3;
+        u[0] = (unsigned char)r0; u[1] = (unsigned char)r1; u[2] = (unsigned char)r2;
+    }
+}
+
 // one block per output row (b, patch); columns c*P*P + ky*P + kx, zero padded to Kpad
 __global__ __launch_bounds__(256) void im2col_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int R,
                                                      int P, int Kpad) {
@@ -472,6 +530,23 @@ extern "C" int keds_fold_layernorm_ex(const float* W, const float* bias, const f
 extern "C" int keds_fold_layernorm(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,
                                    void* w_folded, float* bias_csum, void* stream) {
     return keds_fold_layernorm_ex(W, bias, gamma, beta, N, K, w_folded, 0, bias_csum, stream);
+}
+
+extern "C" int keds_preprocess_pil(const unsigned char* images, int B, int H, int W, int n_px, int need_h, int need_v,
+                                   int left, int top, const int32_t* xb, const int32_t* xk, int ksx, const int32_t* yb,
+                                   const int32_t* yk, int ksy, const float* mean3, const float* std3, float* out,
+                                   unsigned char* out_u8, void* stream) {
+    KEDS_REQUIRE(images && out && mean3 && std3 && B > 0 && H > 0 && W > 0 && n_px > 0, "keds_preprocess_pil: bad argument");
+    KEDS_REQUIRE((!need_h || (xb && xk && ksx > 0)) && (!need_v || (yb && yk && ksy > 0)),
+                 "keds_preprocess_pil: a resampled axis needs its bounds and weights");
+    KEDS_REQUIRE(left >= 0 && top >= 0, "keds_preprocess_pil: negative crop offset");
+    const long long total = (long long)B * n_px * n_px;
+    hipStream_t st = (hipStream_t)stream;
+    KedsProfScope prof(KEDS_PROF_OTHER, st);
+    preprocess_pil_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(images, B, H, W, n_px, need_h, need_v, left, top, xb, xk,
+                                                                           ksx, yb, yk, ksy, mean3[0], mean3[1], mean3[2],
+                                                                           std3[0], std3[1], std3[2], out, out_u8);
+    return keds_check_launch("preprocess_pil_kernel");
 }
 
 extern "C" int keds_preprocess(const unsigned char* images, int B, int H, int W, int n_px, const float* mean3,

@@ -73,19 +73,106 @@ def im2col(image: torch.Tensor, patch: int, kpad: int) -> torch.Tensor:
     return out
 
 
+_PIL_COEFFS = {}
+
+
+def pil_bicubic_coeffs(in_size: int, out_size: int):
+    """PIL's bicubic resampling weights for one axis, as PIL computes and quantises them (Pillow src/libImaging/Resample.c:
+    precompute_coeffs with the bicubic filter a = -0.5, antialiasing support 2 * max(scale, 1), weights normalised to 1 in
+    float64, then normalize_coeffs_8bpc: round-half-away to 22 fractional bits).  Returns (bounds int32 [out, 2] =
+    {first source index, taps}, kk int32 [out, ksize]).  Pure host integer / float64 work (cached per size pair); pinned to
+    PIL bit for bit in tests/test_clip_host.py."""
+    import math
+    key = (int(in_size), int(out_size))
+    hit = _PIL_COEFFS.get(key)
+    if hit is not None:
+        return hit
+    import numpy as np
+    a = -0.5
+
+    def bicubic(x: float) -> float:
+        if x < 0.0:
+            x = -x
+        if x < 1.0:
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+        if x < 2.0:
+            return (((x - 5) * x + 8) * x - 4) * a
+        return 0.0
+
+    scale = filterscale = in_size / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [0.0] * ksize
+        ww = 0.0
+        for x in range(xmax):
+            w = bicubic((x + xmin - center + 0.5) * ss)
+            k[x] = w
+            ww += w
+        for x in range(xmax):
+            if ww != 0.0:
+                k[x] /= ww
+        bounds[xx] = (xmin, xmax)
+        for x in range(ksize):
+            kk[xx, x] = int(-0.5 + k[x] * (1 << 22)) if k[x] < 0 else int(0.5 + k[x] * (1 << 22))
+    _PIL_COEFFS[key] = (bounds, kk)
+    return bounds, kk
+
+
+def resize_crop_geometry(H: int, W: int, n_px: int):
+    """torchvision Resize(int) + CenterCrop(int) as the reference's `_transform` applies them (src/model/clip.py:107-123):
+    the shorter side becomes n_px, the other int(n_px * long / short); crop offsets int(round((size - n_px) / 2.0))."""
+    if W <= H:
+        RW, RH = n_px, int(n_px * H / W)
+    else:
+        RW, RH = int(n_px * W / H), n_px
+    if RW < n_px or RH < n_px:
+        raise ValueError("resized image smaller than the crop")
+    return RW, RH, int(round((RW - n_px) / 2.0)), int(round((RH - n_px) / 2.0))
+
+
 def preprocess(images_u8: torch.Tensor, n_px: int, mean=(0.48145466, 0.4578275, 0.40821073),
-               std=(0.26862954, 0.26130258, 0.27577711)) -> torch.Tensor:
+               std=(0.26862954, 0.26130258, 0.27577711), return_u8: bool = False):
     """uint8 [B,H,W,3] (one size per batch, device) -> fp32 [B,3,n_px,n_px]: the eval `_transform` of the reference
-    (bicubic resize of the shorter side, centre crop, normalise) in one kernel."""
+    (bicubic resize of the shorter side, centre crop, ToTensor, Normalize) in one kernel, BIT-EXACT with the PIL pipeline:
+    PIL's own 22-bit integer filter weights (host, float64, cached per image size), integer accumulation, the horizontal
+    pass rounded to uint8 before the vertical one.  return_u8: also the uint8 image [B,n_px,n_px,3] PIL hands to ToTensor."""
     import ctypes as C
     if images_u8.dtype != torch.uint8 or images_u8.dim() != 4 or images_u8.shape[3] != 3:
         raise ValueError("expected uint8 images [B,H,W,3]")
     images_u8 = images_u8.contiguous()
     B, H, W, _ = images_u8.shape
-    out = torch.empty((B, 3, n_px, n_px), dtype=torch.float32, device=images_u8.device)
-    check(load().keds_preprocess(ptr(images_u8), B, H, W, n_px, (C.c_float * 3)(*mean), (C.c_float * 3)(*std), ptr(out),
-                                 stream()), "keds_preprocess")
-    return out
+    dev = images_u8.device
+    RW, RH, left, top = resize_crop_geometry(H, W, n_px)
+    need_h, need_v = RW != W, RH != H                     # PIL skips a pass that keeps the size
+    tabs = {}
+    for name, need, in_size, out_size, off in (("x", need_h, W, RW, left), ("y", need_v, H, RH, top)):
+        if need:
+            b, k = pil_bicubic_coeffs(in_size, out_size)
+            tabs[name] = (torch.from_numpy(b[off:off + n_px].copy()).to(dev), torch.from_numpy(k[off:off + n_px].copy()).to(dev),
+                          k.shape[1])
+        else:
+            tabs[name] = (None, None, 0)
+    out = torch.empty((B, 3, n_px, n_px), dtype=torch.float32, device=dev)
+    u8 = torch.empty((B, n_px, n_px, 3), dtype=torch.uint8, device=dev) if return_u8 else None
+    (xb, xk, ksx), (yb, yk, ksy) = tabs["x"], tabs["y"]
+    check(load().keds_preprocess_pil(ptr(images_u8), B, H, W, n_px, int(need_h), int(need_v), left, top, ptr(xb), ptr(xk), ksx,
+                                     ptr(yb), ptr(yk), ksy, (C.c_float * 3)(*mean), (C.c_float * 3)(*std), ptr(out), ptr(u8),
+                                     stream()), "keds_preprocess_pil")
+    return (out, u8) if return_u8 else out
 
 
 def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor,

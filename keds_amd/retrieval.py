@@ -55,6 +55,63 @@ def extract_feature_database(model: CLIP, image_batches, text_batches, out_dir: 
     return image_bases, text_bases
 
 
+SHARD_MANIFEST = "cc_database_shards.json"
+
+
+@torch.no_grad()
+def extract_feature_database_sharded(model: CLIP, n_rows: int, image_rows, text_rows, out_dir: str, rank: int = 0,
+                                     world: int = 1, batch: int = 128, device=None, encode_image=None, encode_text=None):
+    """Per-rank build of the row-sharded bi-modal database: rank r encodes ONLY the dataset rows
+    `shard_bounds(n_rows, world, r)` -- `image_rows(lo, hi)` / `text_rows(lo, hi)` return the preprocessed images
+    [hi-lo,3,R,R] / token rows [hi-lo,77] of that range -- normalises them and writes its two shard files
+    `cc_{image,text}_index.shard{r}-of-{world}.pt` (FlatIndex.save: fp32 rows + the packed bf16 scan image + the shard's
+    first global row id), exactly what `load_database_shard` puts back on the device.  A pure partition: no collective, no
+    rank ever holds another rank's rows.  Rank 0 also writes the manifest.  Returns this rank's (image_index, text_index)."""
+    import json
+    from .index import shard_bounds
+    lo, hi = shard_bounds(n_rows, world, rank)
+    enc_i = encode_image or (lambda x: model.encode_image(x, normalize=True))
+    enc_t = encode_text or (lambda x: model.encode_text(x, normalize=True))
+    os.makedirs(out_dir, exist_ok=True)
+    out = []
+    for name, rows_fn, enc in (("image", image_rows, enc_i), ("text", text_rows, enc_t)):
+        idx = None
+        for a in range(lo, hi, batch):
+            b = min(hi, a + batch)
+            x = rows_fn(a, b)
+            f = enc(x.to(device) if device is not None else x).float()
+            if idx is None:
+                idx = FlatIndex(f.shape[1], "l2", device=f.device, row0=lo)
+            idx.add(f)                                            # chunked add: packs only the new stages
+        if idx is None:
+            raise RuntimeError(f"rank {rank} of {world} owns no rows of a {n_rows}-row database")
+        idx.save(os.path.join(out_dir, f"cc_{name}_index.shard{rank}-of-{world}.pt"))
+        out.append(idx)
+    if rank == 0:
+        with open(os.path.join(out_dir, SHARD_MANIFEST), "w") as f:
+            json.dump({"n_rows": int(n_rows), "world": int(world), "dim": int(out[0].d),
+                       "bounds": [list(shard_bounds(n_rows, world, r)) for r in range(world)]}, f)
+    return out[0], out[1]
+
+
+def load_database_shard(out_dir: str, rank: int = 0, world: int = 1, device=None) -> list:
+    """database = [image rows, text rows, None, image_index, text_index] of THIS rank's shard, from the files
+    `extract_feature_database_sharded` wrote (same list shape as `build_database`, eval_retrieval.py:287,297-298); the
+    indices carry the shard's first global row id, so `ShardedFlatIndex` / `PackedExchange` merge them directly."""
+    import json
+    from .index import shard_bounds
+    with open(os.path.join(out_dir, SHARD_MANIFEST)) as f:
+        man = json.load(f)
+    if man["world"] != world:
+        raise RuntimeError(f"database was sharded {man['world']} ways, this job has {world} ranks: rebuild or re-shard")
+    ii = FlatIndex.load(os.path.join(out_dir, f"cc_image_index.shard{rank}-of-{world}.pt"), device=device)
+    ti = FlatIndex.load(os.path.join(out_dir, f"cc_text_index.shard{rank}-of-{world}.pt"), device=device)
+    lo, hi = shard_bounds(man["n_rows"], world, rank)
+    if ii.row0 != lo or ii.ntotal != hi - lo or ti.row0 != lo or ti.ntotal != hi - lo:
+        raise RuntimeError("shard file does not match the manifest")
+    return [ii.rows, ti.rows, None, ii, ti]
+
+
 def get_retrieved_features(feature: torch.Tensor, database, args=None, topk: int = 16, use_faiss: bool = True):
     """eval_utils.py:153-186.  feature [B,D] (any norm) -> (topk_image [B,k,D], topk_text [B,k,D]).
     The reference shuffles the image neighbours along K (a numerical no-op for attention over keys);

@@ -164,3 +164,38 @@ def test_load_local_checkpoints(tmp_path):
     with pytest.raises(RuntimeError, match="not found"):
         kclip.load("ViT-L/14", device="cpu")
     assert kclip.available_models() == []
+
+
+def test_pil_bicubic_coefficients_reproduce_pil_resize_bit_for_bit():
+    """The host half of the bit-exact image preprocessing (reference: src/model/clip.py:107-123 runs
+    PIL's ImagingResample): `ops.pil_bicubic_coeffs` must give PIL's own 22-bit integer weights.  Pinned by running the
+    integer two-pass resampler on those tables in numpy and comparing with PIL's resize byte for byte (down- and
+    up-scaling, odd sizes)."""
+    from PIL import Image
+    from keds_amd import ops
+
+    def resample(img, out_size, axis):
+        if axis == 0:
+            img = img.transpose(1, 0, 2)
+        b, kk = ops.pil_bicubic_coeffs(img.shape[1], out_size)
+        im = img.astype(np.int64)
+        out = np.zeros((img.shape[0], out_size, 3), np.uint8)
+        for xx in range(out_size):
+            x0, n = b[xx]
+            acc = (1 << 21) + (im[:, x0:x0 + n, :] * kk[xx, :n][None, :, None]).sum(1)
+            out[:, xx, :] = np.clip(acc >> 22, 0, 255).astype(np.uint8)
+        return out.transpose(1, 0, 2) if axis == 0 else out
+
+    rs = np.random.RandomState(0)
+    for H, W, oh, ow in ((480, 640, 224, 298), (640, 427, 335, 224), (231, 1000, 224, 969), (300, 300, 224, 224),
+                         (100, 80, 280, 224), (97, 211, 224, 487)):
+        arr = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+        want = np.asarray(Image.fromarray(arr).resize((ow, oh), Image.BICUBIC))
+        got = arr
+        if ow != W:
+            got = resample(got, ow, 1)                       # PIL: horizontal pass first, uint8 intermediate
+        if oh != H:
+            got = resample(got, oh, 0)
+        assert np.array_equal(got, want), (H, W, oh, ow)
+    assert ops.resize_crop_geometry(480, 640, 224) == (298, 224, 37, 0)
+    assert ops.resize_crop_geometry(640, 427, 224) == (224, 335, 0, 56)

@@ -427,25 +427,26 @@ def test_gemm_random_shapes_all_epilogues():
     assert cases >= 20
 
 
-@pytest.mark.parametrize("H,W", [(480, 640), (640, 427), (224, 224), (500, 224), (231, 1000)])
-def test_gpu_preprocess_matches_pil_transform(H, W):
-    """keds_preprocess vs the PIL pipeline of keds_amd.clip._transform (the reference's eval `_transform`): identical up to
-    one 8-bit step on rare pixels (PIL quantises its filter weights to 22 bits, the kernel keeps fp32)."""
+@pytest.mark.parametrize("H,W", [(480, 640), (640, 427), (224, 224), (500, 224), (231, 1000), (150, 180), (224, 300)])
+def test_gpu_preprocess_equals_pil_transform_bit_for_bit(H, W):
+    """keds_preprocess_pil vs the PIL pipeline of keds_amd.clip._transform (the reference's eval `_transform`,
+    src/model/clip.py:107-123): byte work, so the uint8 image after resize + crop must be EQUAL to PIL's, and the normalised
+    float tensor equal to ToTensor + Normalize on it (same fp32 operations).  Down- and up-scaling, a pass that PIL skips
+    (one side already n_px), both orientations."""
     from PIL import Image
     from keds_amd import clip as kclip
     rs = np.random.RandomState(H + W)
     base = rs.randint(0, 256, (H // 8 + 1, W // 8 + 1, 3)).astype(np.uint8)           # smooth-ish content + noise
     arr = np.asarray(Image.fromarray(base).resize((W, H), Image.BILINEAR), dtype=np.int16) + rs.randint(-20, 21, (H, W, 3))
     arr = np.clip(arr, 0, 255).astype(np.uint8)
+    pil = kclip._center_crop(kclip._resize_shorter_side(Image.fromarray(arr), 224), 224)
+    want_u8 = torch.from_numpy(np.asarray(pil))
     want = kclip._transform(224, is_train=False)(Image.fromarray(arr))
-    got = ops.preprocess(torch.from_numpy(arr)[None].cuda(), 224)[0].cpu()
-    step = (1.0 / 255.0) / torch.tensor(kclip.CLIP_STD)[:, None, None]                 # one 8-bit step in normalised units
-    diff = (got - want).abs() / step
-    frac_off = float((diff > 0.01).float().mean())
-    report("preprocess_vs_pil", H=H, W=W, max_steps=float(diff.max()), frac_pixels_off=frac_off)
-    assert float(diff.max()) <= 1.01 and frac_off <= 2e-3
+    got, got_u8 = ops.preprocess(torch.from_numpy(arr)[None].cuda(), 224, return_u8=True)
+    assert torch.equal(got_u8[0].cpu(), want_u8), "uint8 image after resize + crop differs from PIL"
+    assert torch.equal(got[0].cpu(), want), "normalised tensor differs from ToTensor + Normalize"
     two = ops.preprocess(torch.from_numpy(np.stack([arr, arr[::-1].copy()])).cuda(), 224)
-    assert torch.equal(two[0].cpu(), got)
+    assert torch.equal(two[0].cpu(), got[0].cpu())
 
 
 @pytest.mark.parametrize("nq,ng", [(37, 8193), (20, 17000), (5, 40000)])

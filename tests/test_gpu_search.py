@@ -4,6 +4,8 @@ Bar: indices bit-exact (integer work), distances within 2e-6 absolute (fp32 eval
 sum (q-x)^2 on unit-norm data vs the oracle's fp64).  Full-size (0.5 M x 768) checks use
 size-independent properties plus an oracle cross-check on a query subset.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -324,6 +326,58 @@ def test_index_save_load_and_database_extraction(tmp_path):
     li = keds_amd.FlatIndex.load(str(tmp_path / "db" / "cc_image_index.pt"))
     _, Iq, _ = li.search_device(ib[:2], 1)
     assert Iq[:, 0].tolist() == [0, 1]
+
+
+def test_database_extraction_against_oracle_and_sharded_build(tmp_path):
+    """f2 (README.md:8, eval_retrieval.py:253-286): the device-side database builder against the ORACLE --
+    rows equal to the oracle's normalised encode_image / encode_text of the same inputs within the embedding tolerance,
+    and a search over the built index returns the oracle's neighbours of the oracle's database -- then the per-rank
+    sharded build: two 'ranks' each encode their own row range, write shard files, and the shards loaded back answer a
+    query exactly like the single index (bit-identical distances and ids after the (distance, id) merge)."""
+    from tests.test_gpu_model import TINY
+    from keds_amd.index import merge_partials, shard_bounds
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    m = keds_amd.build_model(dict(sd), fp16=False).cuda()
+    rs = np.random.RandomState(3)
+    n = 200
+    images = torch.from_numpy(rs.standard_normal((n, 3, 56, 56)).astype(np.float32))
+    tokens = torch.from_numpy(np.stack([np.concatenate([[510], rs.randint(30, 200, size=5 + i % 20), [511], np.zeros(70 - i % 20)])
+                                        for i in range(n)]).astype(np.int64))
+    ib, tb = keds_amd.extract_feature_database(m, [images[i:i + 64].cuda() for i in range(0, n, 64)],
+                                               [tokens[i:i + 64].cuda() for i in range(0, n, 64)], out_dir=str(tmp_path / "one"))
+    want_i = O.l2_normalize(O.encode_image(sd, images))
+    want_t = O.l2_normalize(O.encode_text(sd, tokens))
+    for name, got, want in (("image", ib, want_i), ("text", tb, want_t)):
+        c = float((got.cpu() * want).sum(1).min())
+        r = float((got.cpu() - want).norm() / want.norm())
+        report(f"extract_feature_database.{name}", min_cosine=c, rel_l2=r)
+        assert c >= 0.9999 and r <= 1.5e-2
+    # (rows of the oracle's database are >= 0.16 apart; a perturbation of norm 0.02 keeps each query's neighbour decided)
+    q = O.l2_normalize(want_i[:7] + 0.002 * torch.from_numpy(rs.standard_normal((7, 128)).astype(np.float32)))
+    idx = keds_amd.FlatIndex.load(str(tmp_path / "one" / "cc_image_index.pt"))
+    _, I, _ = idx.search_device(q.cuda(), 1)
+    assert I[:, 0].tolist() == list(range(7))                     # the oracle's nearest row of every perturbed row is itself
+    # ---- two ranks build their shards independently
+    world = 2
+    shards = []
+    for r in range(world):
+        ii, ti = keds_amd.extract_feature_database_sharded(m, n, lambda a, b: images[a:b].cuda(), lambda a, b: tokens[a:b].cuda(),
+                                                           str(tmp_path / "sh"), rank=r, world=world, batch=48)
+        lo, hi = shard_bounds(n, world, r)
+        assert ii.row0 == lo and ii.ntotal == hi - lo and ti.ntotal == hi - lo
+        assert torch.equal(ii.rows, ib[lo:hi]) and torch.equal(ti.rows, tb[lo:hi])      # same kernels, batch independent
+    assert sorted(os.listdir(str(tmp_path / "sh"))) == ["cc_database_shards.json", "cc_image_index.shard0-of-2.pt",
+                                                         "cc_image_index.shard1-of-2.pt", "cc_text_index.shard0-of-2.pt",
+                                                         "cc_text_index.shard1-of-2.pt"]
+    parts = [keds_amd.load_database_shard(str(tmp_path / "sh"), r, world) for r in range(world)]
+    full = keds_amd.FlatIndex(128, "l2")
+    full.add(tb)
+    Df, If, _ = full.search_device(q.cuda(), 16)
+    Dp, Ip = zip(*[p[4].search_device(q.cuda(), 16)[:2] for p in parts])
+    Dm, Im = merge_partials(torch.stack(Dp).cpu(), torch.stack(Ip).cpu())
+    assert torch.equal(Im, If.cpu()) and torch.equal(Dm, Df.cpu())
+    with pytest.raises(RuntimeError):
+        keds_amd.load_database_shard(str(tmp_path / "sh"), 0, 4)
 
 
 def test_exact_ties_larger_than_k():

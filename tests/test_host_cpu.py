@@ -244,3 +244,39 @@ def test_sharded_search_exchange_gloo_world2():
             p.join(120)
         assert all(p.exitcode == 0 for p in procs)
         assert dict(out) == {0: True, 1: True}
+
+
+def test_sharded_database_build_partitions_rows_without_a_gpu(tmp_path, monkeypatch):
+    """Host logic of the per-rank database build (keds_amd.retrieval.extract_feature_database_sharded): every rank asks its
+    loaders for exactly its own row range, in batches, and the ranges tile the dataset.  The encoders and the device index
+    are stubbed (there is no CPU compute path); the file / manifest handling is the real code."""
+    import json
+    from keds_amd import retrieval
+    asked = []
+
+    class FakeIndex:
+        def __init__(self, d, metric="l2", device=None, row0=0):
+            self.d, self.row0, self.n = d, row0, 0
+        def add(self, x):
+            self.n += x.shape[0]
+        def save(self, path):
+            torch.save({"row0": self.row0, "n": self.n}, path)
+    monkeypatch.setattr(retrieval, "FlatIndex", FakeIndex)
+    n, world = 1000, 3
+    covered = []
+    for r in range(world):
+        def rows(a, b, r=r):
+            asked.append((r, a, b))
+            return torch.zeros(b - a, 4)
+        retrieval.extract_feature_database_sharded(None, n, rows, rows, str(tmp_path), rank=r, world=world, batch=128,
+                                                   encode_image=lambda x: torch.zeros(x.shape[0], 128),
+                                                   encode_text=lambda x: torch.zeros(x.shape[0], 128))
+        lo, hi = shard_bounds(n, world, r)
+        mine = [(a, b) for rr, a, b in asked if rr == r]
+        assert mine[0][0] == lo and mine[len(mine) // 2 - 1][1] == hi and all(b - a <= 128 for a, b in mine)
+        covered.append((lo, hi))
+        meta = torch.load(str(tmp_path / f"cc_text_index.shard{r}-of-{world}.pt"))
+        assert meta == {"row0": lo, "n": hi - lo}
+    assert covered[0][0] == 0 and covered[-1][1] == n and all(covered[i][1] == covered[i + 1][0] for i in range(world - 1))
+    man = json.load(open(str(tmp_path / "cc_database_shards.json")))
+    assert man["n_rows"] == n and man["world"] == world and man["bounds"] == [list(c) for c in covered]
