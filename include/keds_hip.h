@@ -167,6 +167,8 @@ int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery
                                        also the next GEMM's operand; aux = statistics as above (of the fp32 sums) or NULL */
 #define KEDS_EPI_LN_BIAS_BF16_H 10  /* KEDS_EPI_LN_BIAS_BF16 with fp16 operands: A = the fp16 residual stream, W' fp16 */
 #define KEDS_EPI_LN_QGELU_BF16_H 11 /* KEDS_EPI_LN_QGELU_BF16 with fp16 operands */
+#define KEDS_EPI_BIAS_BF16_HEADF32 12 /* out bf16 = acc + bias, and rows m < aux_i also as fp32 to ((float*)aux)[m*3N + n]: IM2TEXT's
+                                       * last layer writes the bf16 rows the CrossFormers read AND token slot 2 of [B,3,N] */
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W bf16 row-major (W is the nn.Linear
  * weight as stored).  N % 128 == 0, K % 64 == 0; rows of A / out up to the next multiple of
@@ -384,9 +386,20 @@ typedef struct {                                    /* IM2TEXT: dim_in -> middle
     const void* out_w; const float* out_b;          /* bf16 [dim_out, middle] */
 } keds_im2text_params;
 
+/* Launch-saving re-arrangement of a CrossFormer's weights (built once by keds_crossformer_fuse from the per-layer ones):
+ *  - k and v never change between the layers (model.py:98-101), so ALL layers' k / v projections are one GEMM:
+ *    wkv [layers*2*inner, dim] = rows {Wk_0, Wv_0, Wk_1, Wv_1, ...}, bkv likewise;
+ *  - layer l's output projection feeds only layer l+1's query projection (no residual, no norm, model.py:56-79), so the
+ *    two are one matrix: wqn[l] = Wq_l . Wo_{l-1} [inner, inner], bqn[l] = Wq_l bo_{l-1} + bq_l   (l >= 1). */
+typedef struct {
+    const void* wkv; const float* bkv;
+    const void* wqn[8]; const float* bqn[8];
+} keds_crossformer_fused;
+
 typedef struct {                                    /* CrossFormer: `layers` chained CrossAttention layers */
     int dim, heads, layers;                         /* dim_head = 64, inner = heads*64 */
     const keds_cross_layer_params* layer;           /* HOST array [layers] of device pointers */
+    const keds_crossformer_fused* fused;            /* HOST struct of device pointers, or NULL (layer-by-layer launches) */
 } keds_crossformer_params;
 
 typedef struct {
@@ -404,6 +417,11 @@ int keds_im2text_forward(const keds_im2text_params* p, const float* x, int rows,
 size_t keds_crossformer_workspace_bytes(const keds_crossformer_params* p, int B, int K);
 int keds_crossformer_forward(const keds_crossformer_params* p, const float* q, const float* k, const float* v,
                              int B, int K, float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* build `fused` (above) into a caller-owned device buffer of keds_crossformer_fused_bytes(p) bytes; layers <= 8 */
+size_t keds_crossformer_fused_bytes(const keds_crossformer_params* p);
+int keds_crossformer_fuse(const keds_crossformer_params* p, void* buffer, size_t buffer_bytes, keds_crossformer_fused* out,
+                          void* stream);
 
 size_t keds_knowledge_workspace_bytes(const keds_knowledge_params* p, int B, int K);
 /* one stream of eval_utils.py:661-672: q [B,dim] fp32, nbr_img / nbr_txt [B,K,dim] fp32 ->

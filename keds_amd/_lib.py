@@ -22,6 +22,7 @@ METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
 EPI_LN_BIAS_BF16_H, EPI_LN_QGELU_BF16_H = 10, 11
+EPI_BIAS_BF16_HEADF32 = 12
 FP8_EPI_BIAS_BF16, FP8_EPI_LN_BIAS_BF16, FP8_EPI_LN_QGELU_MX, FP8_EPI_RESID_STATS_MX, FP8_EPI_RESID_STATS_MX_H = range(5)
 PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
 SCAN_MAX_K = 128
@@ -61,8 +62,13 @@ class Im2TextParams(C.Structure):
                 ("out_w", vp), ("out_b", vp)]
 
 
+class CrossFormerFused(C.Structure):
+    _fields_ = [("wkv", vp), ("bkv", vp), ("wqn", vp * 8), ("bqn", vp * 8)]
+
+
 class CrossFormerParams(C.Structure):
-    _fields_ = [("dim", i32), ("heads", i32), ("layers", i32), ("layer", C.POINTER(CrossLayerParams))]
+    _fields_ = [("dim", i32), ("heads", i32), ("layers", i32), ("layer", C.POINTER(CrossLayerParams)),
+                ("fused", C.POINTER(CrossFormerFused))]
 
 
 class KnowledgeParams(C.Structure):
@@ -171,6 +177,8 @@ SIGNATURES = {
     "keds_im2text_forward": (i32, [C.POINTER(Im2TextParams), vp, i32, vp, vp, sz, vp]),
     "keds_crossformer_workspace_bytes": (sz, [C.POINTER(CrossFormerParams), i32, i32]),
     "keds_crossformer_forward": (i32, [C.POINTER(CrossFormerParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
+    "keds_crossformer_fused_bytes": (sz, [C.POINTER(CrossFormerParams)]),
+    "keds_crossformer_fuse": (i32, [C.POINTER(CrossFormerParams), vp, sz, C.POINTER(CrossFormerFused), vp]),
     "keds_knowledge_workspace_bytes": (sz, [C.POINTER(KnowledgeParams), i32, i32]),
     "keds_knowledge_run": (i32, [C.POINTER(KnowledgeParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
 }

@@ -53,10 +53,18 @@ __device__ __forceinline__ void epilogue_store(f32x4 v0, f32x4 v1, void* __restr
             v1[j] = fmaxf(v1[j], 0.f);
         }
     }
-    if constexpr (EPI == KEDS_EPI_BIAS_BF16 || EPI == KEDS_EPI_BIAS_QGELU_BF16 || EPI == KEDS_EPI_BIAS_RELU_BF16) {
+    if constexpr (EPI == KEDS_EPI_BIAS_BF16 || EPI == KEDS_EPI_BIAS_QGELU_BF16 || EPI == KEDS_EPI_BIAS_RELU_BF16 ||
+                  EPI == KEDS_EPI_BIAS_BF16_HEADF32) {
         bf16x8 o = bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
                           (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
         *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * ldc + n) = o;
+        if constexpr (EPI == KEDS_EPI_BIAS_BF16_HEADF32) {
+            if (m < aux_i) {                      // the first aux_i rows also in fp32, row stride 3N (token slot of [B,3,N])
+                float* t = const_cast<float*>(aux) + (size_t)m * 3 * N + n;
+                *reinterpret_cast<f32x4*>(t) = v0;
+                *reinterpret_cast<f32x4*>(t + 4) = v1;
+            }
+        }
     } else if constexpr (EPI == KEDS_EPI_BIAS_RESID_F32) {
         float* o = reinterpret_cast<float*>(out) + (size_t)m * ldc + n;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(o);
@@ -1023,7 +1031,8 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     // the 256^2 kernel runs one workgroup per CU: use it when its full tiles keep >= 85% of the CU-rounds busy (a single
     // round counts: 19,712 x 768 x 3072 runs at 1.13 PF on 231 tiles vs 0.96 on 924 tiles of 128^2); otherwise the
     // 128^2 kernel's finer tiles quantise better
-    const bool big_ok = big_tiles_ok(M, N, K) && lda == K && ldc == N && (EPI != KEDS_EPI_PATCH_F32 || M % pr::TM == 0);
+    const bool big_ok = big_tiles_ok(M, N, K) && lda == K && ldc == N && (EPI != KEDS_EPI_PATCH_F32 || M % pr::TM == 0) &&
+                        EPI != KEDS_EPI_BIAS_BF16_HEADF32;      // (its fp32 head rows are numbered from row 0 of the launch)
     if (!big_ok) return launch_small<EPI>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
     const int m_main = M / pr::TM * pr::TM;
     int rc = launch_big<EPI>(A, W, bias, out, m_main, N, K, aux, aux_i, aux2, st);
@@ -1094,6 +1103,9 @@ extern "C" int keds_gemm_bt_ex2(const void* A, int64_t lda, const void* W, const
             KEDS_REQUIRE(aux && aux2, "keds_gemm_bt: EPI_RESID_STATS needs aux = statistics and aux2 = bf16 copy");
             return launch_gemm<KEDS_EPI_RESID_STATS_F32>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
         KEDS_GEMM_CASE(KEDS_EPI_RESID_STATS_F16)
+        case KEDS_EPI_BIAS_BF16_HEADF32:
+            KEDS_REQUIRE(aux && aux_i >= 0, "keds_gemm_bt: EPI_BIAS_BF16_HEADF32 needs the fp32 head buffer and its row count");
+            return launch_gemm<KEDS_EPI_BIAS_BF16_HEADF32>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
         default: keds_set_error("keds_gemm_bt: unknown epilogue %d", epilogue); return KEDS_E_ARG;
     }
 #undef KEDS_GEMM_CASE

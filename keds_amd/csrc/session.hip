@@ -323,6 +323,7 @@ struct keds_knowledge {
     int device = 0;            // copied from the context: destroy must not touch a context that may already be gone
     Arena mem;
     std::vector<keds_cross_layer_params> fuse, cond;
+    keds_crossformer_fused fuse_f, cond_f;     // launch-saving weight re-arrangement (keds_hip.h)
     keds_knowledge_params p;
     GrowBuf ws;
 };
@@ -592,6 +593,7 @@ int load_crossformer(const Loader& L, const Weights& W, std::vector<keds_cross_l
     out->heads = inner / 64;
     out->layers = n;
     out->layer = layers.data();
+    out->fused = nullptr;
     return KEDS_OK;
 }
 }  // namespace
@@ -648,6 +650,22 @@ extern "C" int keds_knowledge_create(keds_ctx* ctx, const keds_tensor* im2text, 
         Loader L{W, k->mem, what};
         if ((rc = load_crossformer(L, W, k->cond, &k->p.cond))) return fail(rc);
     }
+    // same re-arrangement as the torch facade builds (keds_amd.CrossFormer.params): both then launch the same kernels on
+    // the same bits
+    for (int which = 0; which < 2; ++which) {
+        keds_crossformer_params* xp = which == 0 ? &k->p.fuse : &k->p.cond;
+        keds_crossformer_fused* xf = which == 0 ? &k->fuse_f : &k->cond_f;
+        if (xp->layers > 8) continue;
+        const size_t bytes = keds_crossformer_fused_bytes(xp);
+        void* buf = k->mem.alloc(bytes);
+        if (!buf) {
+            keds_set_error("%s: out of device memory", what);
+            return fail(KEDS_E_LAUNCH);
+        }
+        if ((rc = keds_crossformer_fuse(xp, buf, bytes, xf, nullptr))) return fail(rc);
+        xp->fused = xf;
+    }
+    HIP_TRY(hipStreamSynchronize(nullptr), what);
     *out = k;
     return KEDS_OK;
 }

@@ -527,7 +527,19 @@ class CrossFormer(nn.Module):
                 for k, v in t.items():
                     setattr(arr[i], k, ptr(v))
                 keep.append(t)
-            p = _lib.CrossFormerParams(self.dim, self.heads, self._num_layers, arr)
+            p = _lib.CrossFormerParams(self.dim, self.heads, self._num_layers, arr, None)
+            # launch-saving re-arrangement (keds_hip.h, keds_crossformer_fused): one k/v GEMM for all layers, and every
+            # later layer's query projection folded with the previous output projection
+            lib = load()
+            if self._num_layers <= 8 and os.environ.get("KEDS_KNOWLEDGE_UNFUSED", "0") != "1":
+                dev = self.cross_layers[0].to_q.weight.device
+                buf = torch.empty(int(lib.keds_crossformer_fused_bytes(C.byref(p))), dtype=torch.uint8, device=dev)
+                fused = _lib.CrossFormerFused()
+                check(lib.keds_crossformer_fuse(C.byref(p), ptr(buf), buf.numel(), C.byref(fused), stream()),
+                      "keds_crossformer_fuse")
+                torch.cuda.current_stream().synchronize()
+                p.fused = C.pointer(fused)
+                keep += [buf, fused]
             self._packed = (p, keep, arr)
         _lib.ensure_gemm_workspace(self.cross_layers[0].to_q.weight.device)
         return self._packed[0]
