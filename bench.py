@@ -40,7 +40,7 @@ PEAK_FP8_MEASURED_TFLOPS = 3400.0    # register-only v_mfma_scale_f32_16x16x128_
 PEAK_BF16_MEASURED_TFLOPS = 2060.0   # tools/micro/mfma_peak.hip on the gpurun MI355X
 PEAK_HBM_MEASURED_GBPS = 7150.0      # tools/micro/hbm_stream.hip (read-only)
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md
-PMC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def pmc_traffic(kernel_key, batch, rows, world):
