@@ -431,6 +431,54 @@ int keds_knowledge_run(const keds_knowledge_params* p, const float* q, const flo
                            const float* nbr_txt, int B, int K, float* tokens_out,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* =====================================================================================
+ * 9. Training step of the knowledge-injection modules: building blocks of the forward in training
+ *    mode, of the backward through IM2TEXT / CrossFormer / the FROZEN text tower, of the symmetric contrastive loss and
+ *    of AdamW (src/trainer.py:44-165, src/main.py:215-237).  The matrix products run on keds_gemm_bt* (dX = dY.W with
+ *    W^T as the operand, dW = dY^T.X with both operands transposed: keds_transpose_to_bf16); the host (keds_amd/train.py)
+ *    sequences the step, as the reference's Python does.  Gradients that feed a GEMM are bf16, the residual-stream
+ *    gradient, LayerNorm, softmax, loss and optimizer arithmetic fp32.
+ * ===================================================================================== */
+/* out bf16 [cols, ld_out] = transpose of src [rows, cols] (fp32 or bf16, row stride ld_src), columns rows..ld_out-1 zero */
+int keds_transpose_to_bf16(const void* src, int src_is_f32, int64_t ld_src, int rows, int cols, void* out, int ld_out, void* stream);
+/* out[c] (+)= sum_r x[r][c]: bias gradients (fixed summation order: reproducible) */
+int keds_colsum(const void* x, int x_is_f32, int64_t ld, int rows, int cols, float* out, int accumulate, void* stream);
+/* IM2TEXT hidden layer y = relu(dropout(z)) (model.py:112-116); mask uint8 (1 = keep; NULL = no dropout), scale = 1/(1-p) */
+int keds_dropout_mask(uint8_t* mask, int64_t n, uint64_t seed, float p, void* stream);
+int keds_dropout_relu_fwd(const void* z_bf16, const uint8_t* mask, float scale, void* y_bf16, int64_t n, void* stream);
+int keds_dropout_relu_bwd(const void* dy, int dy_is_f32, const void* z_bf16, const uint8_t* mask, float scale, void* dz_bf16,
+                          int64_t n, void* stream);
+/* QuickGELU with the pre-activation kept (model.py:300-302) */
+int keds_qgelu_fwd(const void* u_bf16, void* y_bf16, int64_t n, void* stream);
+int keds_qgelu_bwd(const void* dy_bf16, const void* u_bf16, void* du_bf16, int64_t n, void* stream);
+/* LayerNorm with saved statistics {mean, rstd} per row; rowmap (nullable): row r reads x[rowmap[r]] */
+int keds_ln_fwd_stats(const float* x, int64_t ld, const int32_t* rowmap, const float* gamma, const float* beta, void* y_bf16,
+                      float* stats, int rows, int dim, void* stream);
+/* dx[rowmap[r]] += dLN/dx (dy [rows, dim] compact fp32; gamma frozen: no parameter gradients); dx_bf16 (nullable): bf16 copy */
+int keds_ln_bwd(const float* dy, const float* x, int64_t ld, const int32_t* rowmap, const float* stats, const float* gamma,
+                float* dx, void* dx_bf16, int rows, int dim, void* stream);
+/* self-attention backward on the packed qkv buffer of keds_attention (S <= 80): dout bf16 [B*S, d] -> dqkv bf16 [B*S, 3d] */
+int keds_attention_bwd(const void* qkv, const void* dout, void* dqkv, int B, int S, int heads, int causal, void* stream);
+/* single-query cross-attention core (model.py:56-79) on projected bf16 rows Q [B, inner], K / V [B*K, inner], and backward */
+int keds_cross_core_fwd(const void* Q, const void* Kp, const void* Vp, void* out, int B, int K, int heads, void* stream);
+int keds_cross_core_bwd(const void* Q, const void* Kp, const void* Vp, const void* dout, void* dQ, void* dK, void* dV, int B,
+                        int K, int heads, void* stream);
+/* trainer.py:78-127: logits = scale * img_n . txt_n^T over N gathered rows (this rank's B_local first), loss = (CE rows + CE
+ * columns) / 2 -> loss[0] (device), dtxt_n [B_local, dim] = dloss / d txt_n of this rank's rows (remote rows carry no grad) */
+size_t keds_clip_loss_workspace_bytes(int N);
+int keds_clip_loss(const float* img_n, const float* txt_n, int N, int B_local, int dim, float scale, float* loss, float* dtxt_n,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* y = x / ||x||:  dx = (dy - y (y . dy)) / ||x|| */
+int keds_l2norm_bwd(const float* x, const float* dy, float* dx, int rows, int dim, void* stream);
+/* torch.optim.AdamW update of one flat parameter buffer (step counts from 1); the gradient is read as g * grad_scale
+ * (1 / world size after a SUM all-reduce) */
+int keds_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, int step, float grad_scale, void* stream);
+/* dst[map[r]] (+)= src[r]  /  dst[r] = src[map[r]]   (read-out rows, spliced token rows) */
+int keds_rows_scatter(const float* src, const int32_t* map, float* dst, int64_t ld_dst, int rows, int dim, int accumulate,
+                      void* stream);
+int keds_rows_gather(const float* src, int64_t ld_src, const int32_t* map, float* dst, int rows, int dim, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

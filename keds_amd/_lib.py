@@ -114,6 +114,25 @@ SIGNATURES = {
     "keds_abi_version": (i32, []),
     "keds_last_error": (C.c_char_p, []),
     "keds_numerics_guard_set": (i32, [vp]),
+    # ---- training building blocks (keds_hip.h section 9) ------------------------------------------
+    "keds_transpose_to_bf16": (i32, [vp, i32, i64, i32, i32, vp, i32, vp]),
+    "keds_colsum": (i32, [vp, i32, i64, i32, i32, vp, i32, vp]),
+    "keds_dropout_mask": (i32, [vp, i64, C.c_uint64, f32, vp]),
+    "keds_dropout_relu_fwd": (i32, [vp, vp, f32, vp, i64, vp]),
+    "keds_dropout_relu_bwd": (i32, [vp, i32, vp, vp, f32, vp, i64, vp]),
+    "keds_qgelu_fwd": (i32, [vp, vp, i64, vp]),
+    "keds_qgelu_bwd": (i32, [vp, vp, vp, i64, vp]),
+    "keds_ln_fwd_stats": (i32, [vp, i64, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "keds_ln_bwd": (i32, [vp, vp, i64, vp, vp, vp, vp, vp, i32, i32, vp]),
+    "keds_attention_bwd": (i32, [vp, vp, vp, i32, i32, i32, i32, vp]),
+    "keds_cross_core_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp]),
+    "keds_cross_core_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "keds_clip_loss_workspace_bytes": (sz, [i32]),
+    "keds_clip_loss": (i32, [vp, vp, i32, i32, i32, f32, vp, vp, vp, sz, vp]),
+    "keds_l2norm_bwd": (i32, [vp, vp, vp, i32, i32, vp]),
+    "keds_adamw_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "keds_rows_scatter": (i32, [vp, vp, vp, i64, i32, i32, i32, vp]),
+    "keds_rows_gather": (i32, [vp, i64, vp, vp, i32, i32, vp]),
     "keds_prof_enable": (i32, [i32]),
     "keds_prof_reset": (i32, []),
     "keds_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -667,3 +667,51 @@ def synth_recall_queries(tgt: np.ndarray, sigma: np.ndarray, start: int = 0, cou
         n = np.random.RandomState(70000 + j).standard_normal((3, res, res)).astype(np.float32)
         out[j - start] = g + float(sigma[j]) * n
     return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------
+# training step (src/trainer.py:44-165 get_loss_img2text_image), differentiable: torch autograd on this restatement is the
+# reference the HIP backward kernels are checked against (tests/test_gpu_train.py)
+# ----------------------------------------------------------------------------
+def im2text_train(sd: SD, x: Tensor, masks: Optional[Sequence[Tensor]], p_drop: float) -> Tensor:
+    """IM2TEXT.forward in TRAINING mode (src/model/model.py:112-116,120-123): Linear -> Dropout(p) -> ReLU per hidden
+    layer with the given keep-masks (1 = keep, scaled by 1/(1-p)), then fc_out."""
+    i = 0
+    x = x.float()
+    while f"layers.{i}.0.weight" in sd:
+        z = linear(x, sd[f"layers.{i}.0.weight"], sd[f"layers.{i}.0.bias"])
+        if masks is not None and p_drop > 0:
+            z = z * masks[i].to(z.dtype) / (1.0 - p_drop)
+        x = torch.relu(z)
+        i += 1
+    return linear(x, sd["fc_out.weight"], sd["fc_out.bias"])
+
+
+def training_loss(sd_clip: SD, sd_i2t: SD, sd_fuse: SD, sd_cond: SD, image_features: Tensor, nbr_img: Tensor,
+                  nbr_txt: Tensor, text: Tensor, split_ind: int, masks: Optional[Sequence[Tensor]] = None,
+                  p_drop: float = 0.1, other_img_n: Optional[Tensor] = None, other_txt_n: Optional[Tensor] = None) -> Tensor:
+    """src/trainer.py:44-127.  image_features [B,D] (precomputed, no gradient: :48-52), neighbours [B,K,D] as
+    get_retrieved_features returns them (:55-57); mapped = img2text(...) of the query and of both neighbour sets (:60-62,
+    one stacked call here so that one mask covers the rows [q; I; T]); fused / text_conditioned (:65-66); tokens
+    [fused, text_conditioned, mapped] (:70); text features through the FROZEN text tower -- with the evaluation splice
+    (model.py:808-851), see keds_amd/train.py for why; normalise (:80-81); logits = exp(logit_scale) * I . T^T with this
+    rank's rows first and the other ranks' (no gradient) behind (:88-112); loss = (CE_rows + CE_cols) / 2 (:113-116,148)."""
+    B, K, D = nbr_img.shape
+    rows = torch.cat([image_features.float(), nbr_img.reshape(B * K, D).float(), nbr_txt.reshape(B * K, D).float()])
+    mapped_all = im2text_train(sd_i2t, rows, masks, p_drop)
+    mapped, mi, mt = mapped_all[:B], mapped_all[B:B + B * K].reshape(B, K, -1), mapped_all[B + B * K:].reshape(B, K, -1)
+    fused = crossformer(sd_fuse, mapped.unsqueeze(1), mi, mi)
+    cond = crossformer(sd_cond, mapped.unsqueeze(1), mt, mt)
+    tokens = torch.cat([fused, cond, mapped.unsqueeze(1)], dim=1)
+    if text.dim() == 1:
+        text = text[None, :].repeat(B, 1)
+    tf = encode_text_img_retrieval(sd_clip, text, tokens, split_ind=split_ind, repeat=False)
+    img_n = image_features.float() / image_features.float().norm(dim=-1, keepdim=True)
+    txt_n = tf / tf.norm(dim=-1, keepdim=True)
+    if other_img_n is not None:
+        img_n = torch.cat([img_n, other_img_n.float()])
+        txt_n = torch.cat([txt_n, other_txt_n.float()])
+    logits = sd_clip["logit_scale"].float().exp() * img_n @ txt_n.t()
+    gt = torch.arange(logits.shape[0])
+    ce = torch.nn.functional.cross_entropy
+    return (ce(logits, gt) + ce(logits.t(), gt)) / 2

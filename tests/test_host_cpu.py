@@ -280,3 +280,34 @@ def test_sharded_database_build_partitions_rows_without_a_gpu(tmp_path, monkeypa
     assert covered[0][0] == 0 and covered[-1][1] == n and all(covered[i][1] == covered[i + 1][0] for i in range(world - 1))
     man = json.load(open(str(tmp_path / "cc_database_shards.json")))
     assert man["n_rows"] == n and man["world"] == world and man["bounds"] == [list(c) for c in covered]
+
+
+def _gather_worker(rank, world, port, out):
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        from keds_amd.train import gather_own_first
+        x = torch.full((3, 4), float(rank)) + torch.arange(3)[:, None] * 0.1
+        got = gather_own_first(x)
+        order = [rank] + [r for r in range(world) if r != rank]
+        want = torch.cat([torch.full((3, 4), float(r)) + torch.arange(3)[:, None] * 0.1 for r in order])
+        out[rank] = bool(torch.equal(got, want))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_negatives_gather_own_rows_first_gloo_world3():
+    """trainer.py:78-99: every rank contrasts against the features of all ranks with ITS OWN rows first (the loss targets
+    are arange); keds_amd.train.gather_own_first on a 3-rank gloo group."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        port = 29500 + (os.getpid() + 7) % 2000
+        procs = [ctx.Process(target=_gather_worker, args=(r, 3, port, out)) for r in range(3)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+        assert all(p.exitcode == 0 for p in procs)
+        assert dict(out) == {0: True, 1: True, 2: True}
