@@ -61,7 +61,9 @@ KedsSideLane* keds_side_lane() {
     if (g_lane_state[dev] == 0) {
         int least = 0, greatest = 0;           // the "greatest" priority is the numerically lowest value
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-        const bool ok = hipStreamCreateWithPriority(&g_lanes[dev].s, hipStreamNonBlocking, greatest) == hipSuccess;
+        bool ok = hipStreamCreateWithPriority(&g_lanes[dev].s, hipStreamNonBlocking, greatest) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&g_lanes[dev].fork, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&g_lanes[dev].join, hipEventDisableTiming) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         g_lane_state[dev] = ok ? 1 : -1;
     }

@@ -44,6 +44,8 @@ struct KedsProfScope {
 // or when the stream cannot be created: callers then run everything on their own stream.
 struct KedsSideLane {
     hipStream_t s;
+    hipEvent_t fork, join;      // created once with the lane (timing disabled): a stream wait binds to the event's record at
+                                // the time of the call, so re-recording them on the next tower pass is safe
 };
 KedsSideLane* keds_side_lane();
 bool keds_side_lane_enabled();

@@ -431,20 +431,14 @@ extern "C" int keds_knowledge_run(const keds_knowledge_params* p, const float* q
             return rc;
         const bf16_t* map_bf = (const bf16_t*)w.map_bf;
         KedsSideLane* lane = keds_side_lane();
-        hipEvent_t fork = nullptr, join = nullptr;
         hipStream_t s2 = st;
-        if (lane && hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess) {
+        if (lane) {
             s2 = lane->s;
-            if ((rc = keds_stream_order(st, fork, s2))) return rc;
-        } else {
-            (void)hipGetLastError();
+            if ((rc = keds_stream_order(st, lane->fork, s2))) return rc;
         }
         rc = xf_run_fused(&p->cond, map_bf, map_bf + (size_t)(B + BK) * dim, B, K, tokens_out + dim, 3LL * dim, w.xf2, s2);
         if (!rc) rc = xf_run_fused(&p->fuse, map_bf, map_bf + (size_t)B * dim, B, K, tokens_out, 3LL * dim, w.xf, st);
-        if (!rc && s2 != st) rc = keds_stream_order(s2, join, st);
-        if (fork) (void)hipEventDestroy(fork);
-        if (join) (void)hipEventDestroy(join);
+        if (!rc && s2 != st) rc = keds_stream_order(s2, lane->join, st);
         return rc;
     }
     if ((rc = keds_cast_bf16(q, rows, (int64_t)B * dim, stream))) return rc;

@@ -74,21 +74,14 @@ struct RowLanes {
         main = side = st;
         KedsSideLane* lane = want ? keds_side_lane() : nullptr;
         if (!lane) return KEDS_OK;
-        if (hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) {
-            (void)hipGetLastError();
-            return KEDS_OK;                                   // no events: one lane
-        }
         side = lane->s;
+        fork = lane->fork;                                    // the lane's own two events, created once (round 1 made and
+        join = lane->join;                                    // destroyed a pair on every tower call)
         split = true;
         return KEDS_OK;
     }
     int to_side() { return split ? keds_stream_order(main, fork, side) : KEDS_OK; }
     int to_main() { return split ? keds_stream_order(side, join, main) : KEDS_OK; }
-    ~RowLanes() {                                             // destroying a recorded event releases it when it completes
-        if (fork) (void)hipEventDestroy(fork);
-        if (join) (void)hipEventDestroy(join);
-    }
 };
 
 struct RowSpan {

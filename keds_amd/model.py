@@ -6,8 +6,9 @@ build_model :951, convert_weights :927), so reference checkpoints load unchanged
 (``main.py:330-341`` layout) and reference call sites (``eval_utils.py:610,652-695``,
 ``eval_retrieval.py:96-101``) run as written.  The modules here only HOLD parameters
 (torch.nn containers); every forward runs hand-written gfx950 kernels through
-``libkeds_hip.so`` -- bf16 MFMA GEMMs with fp32 accumulation, fp32 residual stream,
-fp32 LayerNorm/softmax statistics.  There is no PyTorch compute path and no CPU fallback:
+``libkeds_hip.so`` -- bf16 / fp16 MFMA GEMMs with fp32 accumulation, the residual stream of a tower kept in
+fp16 with LayerNorm folded into the GEMMs (fp32 stream + stand-alone LayerNorm in numerics mode "safe",
+selected automatically by the numerics guard), fp32 LayerNorm / softmax statistics.  There is no PyTorch compute path and no CPU fallback:
 calling a forward without the library or without a GPU raises RuntimeError.
 
 Out of scope: ModifiedResNet towers, `mid_feature`,
@@ -329,6 +330,9 @@ class CLIP(nn.Module):
         B = text.shape[0]
         if B == 0:
             return torch.empty((0, self.embed_dim), dtype=self.dtype, device=eng.device)
+        # nn.Embedding raises IndexError on an id outside the table (model.py:579); the gather kernel does not check
+        if int(text.min()) < 0 or int(text.max()) >= self.vocab_size:
+            raise IndexError(f"token id outside [0, {self.vocab_size})")
         tok = text.to(eng.device, dtype=torch.int32).contiguous()
         ro = readout.to(eng.device, dtype=torch.int32).contiguous()
         it = None if img_tokens is None else img_tokens.to(eng.device, dtype=torch.float32).contiguous()
