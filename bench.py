@@ -169,15 +169,19 @@ def main():
     # latency-bound collectives (one packed all-gather of the queries, one packed all-to-all of the partial lists;
     # preallocated buffers, keds_amd.index.PackedExchange) and its short merge / re-rank launches hide under the next
     # encoder pass instead of standing between two of them.
+    # (With one GPU there is no collective to hide, and a scan that shares the CUs with the next encoder pass reads at a lower
+    # rate for no gain: the search then stays on the encoder's stream.)
     xchg = PackedExchange() if use_dist else None
-    search_stream = torch.cuda.Stream(device=dev)
+    search_stream = torch.cuda.Stream(device=dev) if use_dist else torch.cuda.current_stream()
     comm_events = []                                            # (gather, scan, return) hipEvent quadruples of profiled steps
 
     def step(timed=False):
         q = model.encode_image(images, normalize=True)          # [B,768] on device
-        search_stream.wait_stream(torch.cuda.current_stream())
+        if use_dist:
+            search_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(search_stream):
-            q.record_stream(search_stream)
+            if use_dist:
+                q.record_stream(search_stream)
             ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (timed and use_dist) else None
             if ev:
                 ev[0].record()
@@ -287,7 +291,8 @@ def main():
                               # read-only stream over 4 GiB on this box: 7.15 TB/s (profiles/r01_microbench.txt)
                               "peak_measured": PEAK_HBM_MEASURED_GBPS, "frac_of_measured": scan_ach / PEAK_HBM_MEASURED_GBPS},
             "profiled_steps": prof_steps, "side_lane_rows": side_rows,
-            "search_overlap": "search of batch i on a second stream beside the encoder pass of batch i+1",
+            "search_overlap": ("search of batch i on a second stream beside the encoder pass of batch i+1" if use_dist
+                               else "none (one GPU: no collective to hide)"),
             "per_rank_search": per_rank,
             "stage_ms_per_step": {"gemm": gemm_ms / psteps, "attention": attn_ms / psteps, "layernorm": ln_ms / psteps,
                                   "scan": scan_ms / psteps, "other": other_ms / psteps},
