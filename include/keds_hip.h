@@ -244,6 +244,9 @@ int keds_layernorm(const float* x, int64_t x_stride, const float* gamma, const f
 
 /* timing-only ablation hook of the S > 96 attention kernel (0 = product path) */
 int keds_attention_debug(int variant);
+/* diagnostic: device buffer of B * heads * 64 uint64 that the stamped build (keds_attention_debug(64 + 8)) of the S = 257
+ * kernel fills with per-wave phase durations in shader cycles (tools/stamp_attn.py) */
+int keds_attention_stamp_buffer(void* buf);
 
 /* multi-head self attention core on a packed qkv buffer (nn.MultiheadAttention,
  * model.py:309,319-321): qkv bf16 [B*S, 3*d] (q | k | v, head h at columns h*64),

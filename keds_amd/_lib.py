@@ -167,6 +167,7 @@ SIGNATURES = {
     "keds_gemm_bt_ex": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "keds_layernorm": (i32, [vp, i64, vp, vp, vp, i32, i32, i32, vp]),
     "keds_attention_debug": (i32, [i32]),
+    "keds_attention_stamp_buffer": (i32, [vp]),
     "keds_attention_ex": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "keds_attention_mx": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, i32, vp]),
     "keds_attention": (i32, [vp, vp, i32, i32, i32, i32, vp]),

@@ -432,6 +432,375 @@ __global__ __launch_bounds__(256, 2) void attention_tail1_kernel(const bf16_t* _
     }
 }
 
+// ---- S = 257, non-causal, EIGHT waves per (batch, head) (round 2; the product kernel of the ViT-L/14 tower) ------------
+// The 4-wave kernels above run three serial phases per wave (all S^T tiles -> softmax over 128 score registers -> P.V) at two
+// waves per SIMD, and their ablations are additive: no staging -19 us, no QK^T -15, no exp -10, no PV -10 of 81 us -- nothing
+// overlaps.  The softmax is the largest term: on a 16-lane SIMD a wave64 VALU instruction holds the issue port 4 cycles
+// (v_exp_f32: 8), i.e. ~20 cycles per score register against 32 MFMA-pipe cycles per 16 of them.  This kernel trades the
+// register-resident score matrix for occupancy and lets the hardware interleave the phases of different waves:
+//   * 512 threads: wave w owns queries [32 w, 32 w + 32) and walks the 256 leading keys in eight 32-key tiles with
+//     v_mfma_f32_32x32x16_bf16 (half the issue slots per flop of the 16x16x32 form): S^T tile = K tile . Q^T (4 MFMAs, the query
+//     on the lane, 16 keys in registers), exp2 in place, P packed to bf16 IS the B operand of O^T += V^T tile . P^T (4 MFMAs).
+//     ~110 VGPRs -> four waves per SIMD (two workgroups per CU), so one wave's exp / pack / LDS reads run under another's MFMAs.
+//   * No running-max rescale.  The probabilities are taken relative to the row maximum of the FIRST key tile (m0): bf16 and
+//     fp32 keep their relative precision at any exponent, so exp2(s - m0) is as good as exp2(s - max) as long as it cannot
+//     overflow.  The lane tracks the true maximum on the side (v_max3, 1 cycle per score); if it exceeds m0 by more than 64
+//     (log2 units) for any query of the block -- it never does on real activations -- the block is recomputed once with the now
+//     known maximum.  Exact, branch-free in the common case.
+//   * K and V go to LDS by LDS-DMA (global_load_lds_dwordx4, 8 per wave, no staging registers, no LDS-write issue): both
+//     row-major [key][64] with a chunk swizzle applied on the SOURCE side; V^T fragments are read with ds_read_b64_tr_b16
+//     (hardware transpose), so no V^T image is built (the 8-byte V^T writes of the 4-wave kernels were 8-way bank conflicted).
+//   * key 256 is a rank-1 VALU update per block, query 256 one VALU row split over the eight waves after their blocks.
+namespace s257 {
+constexpr int K_OFF = 0, V_OFF = 32768, TAIL_OFF = 65536;    // tail: row 256's q | k | v (128 B each)
+constexpr int SC_OFF = TAIL_OFF + 384;                        // last query: f32 scores [264]
+constexpr int PART_OFF = SC_OFF + 264 * 4;                    // last query: per wave {max, sum, -, ..., partial output [64]}: 72 floats
+constexpr int CNT_OFF = PART_OFF + 8 * 72 * 4;                // last query: arrival counter
+constexpr int LDS = CNT_OFF + 16;                             // 69,296 B -> two workgroups per CU
+}  // namespace s257
+
+__device__ __forceinline__ float halves_max(float x) {
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float halves_sum(float x) {
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+// c + sum_j a[j] b[j] with v_dot2c_f32_bf16 (two products per instruction, fp32 accumulate)
+__device__ __forceinline__ float dot8(bf16x8 a, bf16x8 b, float c) {
+    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), c, false);
+    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), c, false);
+    c = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), c, false);
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), c, false);
+}
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ bf16x8 tr_pair(const char* lo, const char* hi) {
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lo);
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)hi);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 v = s16x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// all-VALU wave reductions (DPP within the 16-lane rows, permlane swaps across them); __shfl_xor is six LDS round trips
+#define KEDS_DPP_F(x, CTRL) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), (CTRL), 0xF, 0xF, false))
+__device__ __forceinline__ float wave_sum_v(float x) {
+    x += KEDS_DPP_F(x, 0xB1);     // lane ^ 1
+    x += KEDS_DPP_F(x, 0x4E);     // lane ^ 2
+    x += KEDS_DPP_F(x, 0x141);    // row_half_mirror: the other group of four
+    x += KEDS_DPP_F(x, 0x140);    // row_mirror: the other half of the row
+    return rows_sum(x);
+}
+__device__ __forceinline__ float wave_max_v(float x) {
+    x = fmaxf(x, KEDS_DPP_F(x, 0xB1));
+    x = fmaxf(x, KEDS_DPP_F(x, 0x4E));
+    x = fmaxf(x, KEDS_DPP_F(x, 0x141));
+    x = fmaxf(x, KEDS_DPP_F(x, 0x140));
+    return rows_max(x);
+}
+
+template <int DBG = 0>
+__global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                int heads, int q_limit,
+                                                                unsigned long long* __restrict__ stamp) {
+    using namespace s257;
+    constexpr int S = 257, LAST = 256;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] unsigned long long t_in = 0, t_staged = 0, t_lastq = 0, t_loop = 0;
+    if constexpr (DBG == 8) t_in = __builtin_amdgcn_s_memtime();
+    if constexpr (DBG == 6 || DBG == 7) {     // phase-shift experiment: half of the first-round workgroups start ~half a lifetime late
+        const bool late = DBG == 6 ? (blockIdx.x & 1) : ((blockIdx.x >> 8) & 1);
+        if (blockIdx.x < 512 && late) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < 12000ull) __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    const int b = blockIdx.x / heads, h = blockIdx.x % heads;
+    const int d = heads * DH;
+    const int ld = 3 * d;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const bf16_t* base = qkv + (size_t)b * S * ld + h * DH;
+    bf16_t* obase = out + (size_t)b * S * d + h * DH;
+    const float sl2 = 0.125f * 1.4426950408889634f;
+
+    // ---- row 256 (q, k, v: 3 x 128 B) through registers, this wave's 32 queries as B operands (k = head dims), then the
+    // 256 leading K and V rows by LDS-DMA: piece = 8 rows = 1 KiB = one wave-instruction; LDS slot (row, c) holds source
+    // chunk c ^ f(row).  Keys 0-127 are issued first and waited for alone: the first four key tiles run while 128-255 land.
+    bf16x8 trow = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    if (tid < 24) trow = *reinterpret_cast<const bf16x8*>(base + (size_t)LAST * ld + (tid >> 3) * d + (tid & 7) * 8);
+    bf16x8 qf[4];
+    {
+        const bf16_t* qp = base + (size_t)(32 * wave + r) * ld + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qp + 16 * ks);
+    }
+    if constexpr (DBG != 1) {
+        const int prow = lane >> 3, slot = lane & 7;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int piece = wave + 8 * i;
+            const int row = 8 * piece + prow;
+            const int fk = (row >> 1) & 7, fv = ((row >> 1) & 1) << 2;
+            const bf16_t* src = base + (size_t)row * ld;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + d + ((slot ^ fk) << 3)),
+                                             (__attribute__((address_space(3))) void*)(smem + K_OFF + piece * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * d + ((slot ^ fv) << 3)),
+                                             (__attribute__((address_space(3))) void*)(smem + V_OFF + piece * 1024), 16, 0, 0);
+        }
+    }
+    // tail image: [q row 256 | k row 256 | v row 256], 128 B each, unswizzled; the last-query arrival counter
+    if (tid < 24) *reinterpret_cast<bf16x8*>(smem + TAIL_OFF + tid * 16) = trow;
+    if (tid == 24) *reinterpret_cast<int*>(smem + CNT_OFF) = 0;
+    if constexpr (DBG != 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // everything older than the last four DMA pieces
+    __syncthreads();
+    if constexpr (DBG == 8) t_staged = __builtin_amdgcn_s_memtime();
+    const char* tq = smem + TAIL_OFF;
+    const char* tk = smem + TAIL_OFF + 128;
+    const char* tv = smem + TAIL_OFF + 256;
+
+    // ---- the last query row, without a barrier: wave w takes keys [32 w, 32 w + 32) (wave 0 also key 256) and leaves
+    // {its maximum, its sum, its P.V partial relative to that maximum} in LDS; the wave that arrives last (LDS counter)
+    // combines the eight partials.  (As a phase behind three barriers this row cost 5-6 k of a wave's 25-30 k cycles.)
+    auto last_query_partial = [&]() {
+        float* rec = reinterpret_cast<float*>(smem + PART_OFF) + wave * 72;      // [m, l, -, -, -, -, -, -, acc[64]]
+        const int key = 32 * wave + r;
+        const int fk = (key >> 1) & 7;
+        float sq = 0.f;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const int ch = 4 * hh + c4;
+            sq = dot8(*reinterpret_cast<const bf16x8*>(tq + ch * 16),
+                      *reinterpret_cast<const bf16x8*>(smem + K_OFF + key * 128 + ((ch ^ fk) << 4)), sq);
+        }
+        sq = halves_sum(sq);                                        // lanes r and r + 32: score of key 32 w + r
+        float s256 = -INFINITY;
+        if (wave == 0) {                                            // key 256: lanes 0-7 take one chunk each
+            const float t = lane < 8 ? dot8(*reinterpret_cast<const bf16x8*>(tq + (lane & 7) * 16),
+                                            *reinterpret_cast<const bf16x8*>(tk + (lane & 7) * 16), 0.f) : 0.f;
+            s256 = wave_sum_v(t);
+        }
+        const float mw = fmaxf(wave_max_v(sq), s256);
+        const float nmw = -mw * sl2;
+        const float pk = (float)(bf16_t)__builtin_amdgcn_exp2f(__builtin_fmaf(sq, sl2, nmw));   // bf16-rounded like the MFMA path's P
+        const float e256 = wave == 0 ? __builtin_amdgcn_exp2f(__builtin_fmaf(s256, sl2, nmw)) : 0.f;
+        const float lw = wave_sum_v(hh == 0 ? __builtin_amdgcn_exp2f(__builtin_fmaf(sq, sl2, nmw)) : 0.f) + e256;
+        // P.V over the wave's 32 keys: lane = (8-dim chunk ch, key subset sub): keys 32 w + sub + 8 i
+        const int ch = lane & 7, sub = lane >> 3;
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = sub + 8 * i;                              // key within the wave's slice = the lane that holds its p
+            const float p = __uint_as_float(__builtin_amdgcn_ds_bpermute(kk << 2, __float_as_uint(pk)));
+            const int key2 = 32 * wave + kk;
+            const int fv = ((key2 >> 1) & 1) << 2;
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + V_OFF + key2 * 128 + ((ch ^ fv) << 4));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += p * (float)v[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = acc[j];
+            x += KEDS_DPP_F(x, 0x128);                                     // row_ror:8 = lane ^ 8
+            acc[j] = rows_sum(x);                                          // lanes ^ 16, ^ 32
+        }
+        if (lane < 8) {
+            if (wave == 0) {
+                const bf16x8 v = *reinterpret_cast<const bf16x8*>(tv + ch * 16);
+                const float p = (float)(bf16_t)e256;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += p * (float)v[j];
+            }
+            *reinterpret_cast<f32x4*>(rec + 8 + 8 * ch) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(rec + 8 + 8 * ch + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+            if (lane == 0) *reinterpret_cast<f32x2*>(rec) = f32x2{mw, lw};
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        int arrived = 0;
+        if (lane == 0) arrived = __hip_atomic_fetch_add(reinterpret_cast<int*>(smem + CNT_OFF), 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        arrived = __builtin_amdgcn_readfirstlane(arrived);
+        if (arrived == 7) {                                          // every partial is in LDS: lane = head dim
+            const float* all = reinterpret_cast<const float*>(smem + PART_OFF);
+            float M = all[0];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) M = fmaxf(M, all[w * 72]);
+            float L = 0.f, o = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                const float f = __builtin_amdgcn_exp2f((all[w * 72] - M) * sl2);
+                L += all[w * 72 + 1] * f;
+                o += all[w * 72 + 8 + lane] * f;
+            }
+            obase[(size_t)LAST * d + lane] = (bf16_t)(o / L);
+        }
+    };
+
+    const int ql = q_limit < LAST ? q_limit : LAST;
+    const int nblk = DBG == 5 ? 0 : (ql + 31) >> 5;
+    const bool do_last = q_limit > LAST && DBG != 9;
+    if (wave < nblk) {
+        // lane-constant LDS offsets: K fragment of k-step ks (row r of the tile), V^T blocks of d-tile 0 / 1
+        const int fk = (r >> 1) & 7;
+        int ka[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ka[ks] = K_OFF + r * 128 + (((2 * ks + hh) ^ fk) << 4);
+        const int i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3, gi = (lane >> 4) & 1;
+        const int fq = (q4 >> 1) & 1;                                   // V swizzle: chunk bit 2 flips on rows 2, 3 (mod 4)
+        const int vrow = V_OFF + (4 * hh + q4) * 128 + (p4 & 1) * 8 + ((2 * gi + (p4 >> 1)) << 4);
+        const int vb0 = vrow + ((fq ? 4 : 0) << 4), vb1 = vrow + ((fq ? 0 : 4) << 4);
+
+        float mgiven = 0.f;
+        bool have = false;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            f32x16 o0, o1;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o0[i] = 0.f, o1[i] = 0.f;
+            float nm = 0.f, lsum = 0.f, mref = 0.f;
+            if (have) {            // recompute pass (rare): the exact row maximum first, scores only
+                float mrun = -INFINITY;
+#pragma unroll 1
+                for (int kt = 0; kt < 8; ++kt) {
+                    f32x16 sc;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks)
+                        sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(smem + ka[ks] + kt * 4096), qf[ks], sc, 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) mrun = fmaxf(mrun, sc[i]);
+                }
+                mgiven = fmaxf(halves_max(mrun), mgiven);       // mgiven came in as the last key's score
+            }
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                if (half == 1 && attempt == 0) {                           // keys 128-255 (kernel-uniform count of barriers:
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a recomputing wave does not come here again)
+                    __syncthreads();
+                    if constexpr (DBG == 8) t_lastq = __builtin_amdgcn_s_memtime();
+                    if (do_last) last_query_partial();
+                }
+                const char* kb = smem + half * 16384;
+                bf16x8 a[4];                                               // K fragments of the NEXT tile: read under the P.V MFMAs
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(kb + ka[ks]);
+                // four tiles unrolled: every LDS address is a lane constant + an immediate
+#pragma unroll
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    f32x16 sc;
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) sc[i] = 0.f;
+                    if constexpr (DBG != 2) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks], qf[ks], sc, 0, 0, 0);
+                    } else {
+                        sc[0] = (float)qf[k4][0] + (float)a[k4][0];
+                    }
+                    if (k4 == 0 && half == 0) {                            // the reference: first tile's row maximum
+                        float t = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+                        for (int i = 3; i < 15; i += 2) t = fmaxf(fmaxf(t, sc[i]), sc[i + 1]);
+                        t = fmaxf(t, sc[15]);
+                        mref = have ? mgiven : halves_max(t);
+                        nm = -mref * sl2;
+                    }
+                    if constexpr (DBG != 3) {
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[i], sl2, nm));
+                            lsum += e;
+                            sc[i] = e;
+                        }
+                    }
+                    const bf16x8 p0 = bf16x8{(bf16_t)sc[0], (bf16_t)sc[1], (bf16_t)sc[2], (bf16_t)sc[3],
+                                             (bf16_t)sc[4], (bf16_t)sc[5], (bf16_t)sc[6], (bf16_t)sc[7]};
+                    const bf16x8 p1 = bf16x8{(bf16_t)sc[8], (bf16_t)sc[9], (bf16_t)sc[10], (bf16_t)sc[11],
+                                             (bf16_t)sc[12], (bf16_t)sc[13], (bf16_t)sc[14], (bf16_t)sc[15]};
+                    if (k4 < 3) {
+#pragma unroll
+                        for (int ks = 0; ks < 4; ++ks) a[ks] = *reinterpret_cast<const bf16x8*>(kb + ka[ks] + (k4 + 1) * 4096);
+                    }
+                    if constexpr (DBG != 4) {
+                        const char* v0 = kb + vb0 + k4 * 4096;
+                        const char* v1 = kb + vb1 + k4 * 4096;
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(v0, v0 + 1024), p0, o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(v1, v1 + 1024), p0, o1, 0, 0, 0);
+                        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(v0 + 2048, v0 + 3072), p1, o0, 0, 0, 0);
+                        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_pair(v1 + 2048, v1 + 3072), p1, o1, 0, 0, 0);
+                    } else {
+                        o0[0] += (float)p0[0] + (float)p1[0];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                     // keep the tiles apart: hoisted reads spill at 128 VGPRs
+                }
+            }
+            if constexpr (DBG == 8) t_loop = __builtin_amdgcn_s_memtime();
+            // ---- the last key: score from this lane's 32 query dims, combined over the two halves
+            float ts = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) ts = dot8(qf[ks], *reinterpret_cast<const bf16x8*>(tk + (2 * ks + hh) * 16), ts);
+            ts = halves_sum(ts);
+            // Overflow check of the reference: every e <= the row sum, so a bounded sum bounds every probability and every
+            // P.V term; (ts - mref) covers the rank-1 key.  A NaN row fails the test too (recomputed once, stays NaN).
+            const float ltot = halves_sum(lsum);
+            const bool bad = !(ltot <= 0x1p80f) || !((ts - mref) * sl2 <= 64.0f);
+            if (!have && __builtin_amdgcn_ballot_w64(bad) != 0ull) {
+                mgiven = ts;
+                have = true;
+                continue;
+            }
+            const float et = __builtin_amdgcn_exp2f(__builtin_fmaf(ts, sl2, nm));
+            const float inv = 1.0f / (ltot + et);
+            const float tp = (float)(bf16_t)et;                         // rounded like the probabilities the MFMA path multiplies
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const bf16x4 va = *reinterpret_cast<const bf16x4*>(tv + (8 * g4 + 4 * hh) * 2);
+                const bf16x4 vb = *reinterpret_cast<const bf16x4*>(tv + (32 + 8 * g4 + 4 * hh) * 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o0[4 * g4 + j] += tp * (float)va[j];
+                    o1[4 * g4 + j] += tp * (float)vb[j];
+                }
+            }
+            const int query = 32 * wave + r;
+            if (query < q_limit) {
+                bf16_t* op = obase + (size_t)query * d + 4 * hh;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    *reinterpret_cast<bf16x4*>(op + 8 * g4) =
+                        bf16x4{(bf16_t)(o0[4 * g4] * inv), (bf16_t)(o0[4 * g4 + 1] * inv), (bf16_t)(o0[4 * g4 + 2] * inv),
+                               (bf16_t)(o0[4 * g4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(op + 32 + 8 * g4) =
+                        bf16x4{(bf16_t)(o1[4 * g4] * inv), (bf16_t)(o1[4 * g4 + 1] * inv), (bf16_t)(o1[4 * g4 + 2] * inv),
+                               (bf16_t)(o1[4 * g4 + 3] * inv)};
+                }
+            }
+            break;
+        }
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                               // the barrier in front of keys 128-255
+    }
+    if constexpr (DBG == 8) {
+        const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && stamp) {
+            unsigned long long* o = stamp + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = t_staged - t_in;     // row 256 + Q loads issued, K / V DMA landed, barrier
+            o[1] = t_lastq - t_staged;  // key tiles 0-3, wait for keys 128-255, barrier
+            o[2] = t_loop - t_lastq;    // last query partial + key tiles 4-7
+            o[3] = t_issued - t_loop;   // last key, normalisation, stores issued
+            o[4] = t_in;
+            o[5] = t_end;
+            o[6] = __builtin_amdgcn_s_getreg(63492);   // HW_ID: where the wave ran
+            o[7] = t_end - t_issued;    // store drain
+        }
+    }
+}
+
 int g_attn_debug = 0;   // timing-only ablations (ViT kernel)
 int g_attn_tail = 1;    // A/B hook: 0 routes S = 257 through the generic (padded) kernel
 
@@ -442,6 +811,37 @@ int launch_attn_tail1(const void* qkv, void* out, int B, int heads, int q_limit,
     KedsProfScope prof(KEDS_PROF_ATTN, st);
     attention_tail1_kernel<16><<<B * heads, 256, LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, heads, q_limit);
     return keds_check_launch("attention_tail1_kernel");
+}
+
+int g_attn_s257 = 1;    // A/B hook: 0 routes S = 257 through the 4-wave tail kernel
+
+unsigned long long* g_attn_stamp = nullptr;   // stamped build (code 8): 8 counters per wave, keds_attention_stamp_buffer
+int g_attn_s257_dbg = 0;   // timing-only ablations of the 8-wave kernel (keds_attention_debug bit 6 + code)
+
+template <int V>
+int launch_attn_s257_dbg(const void* qkv, void* out, int B, int heads, int q_limit, hipStream_t st) {
+    (void)hipFuncSetAttribute((const void*)attention_s257_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, s257::LDS);
+    attention_s257_kernel<V><<<B * heads, 512, s257::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, heads, q_limit, g_attn_stamp);
+    return keds_check_launch("attention_s257_kernel<dbg>");
+}
+
+int launch_attn_s257(const void* qkv, void* out, int B, int heads, int q_limit, hipStream_t st) {
+    switch (g_attn_s257_dbg) {
+        case 1: return launch_attn_s257_dbg<1>(qkv, out, B, heads, q_limit, st);
+        case 2: return launch_attn_s257_dbg<2>(qkv, out, B, heads, q_limit, st);
+        case 3: return launch_attn_s257_dbg<3>(qkv, out, B, heads, q_limit, st);
+        case 4: return launch_attn_s257_dbg<4>(qkv, out, B, heads, q_limit, st);
+        case 5: return launch_attn_s257_dbg<5>(qkv, out, B, heads, q_limit, st);
+        case 6: return launch_attn_s257_dbg<6>(qkv, out, B, heads, q_limit, st);
+        case 7: return launch_attn_s257_dbg<7>(qkv, out, B, heads, q_limit, st);
+        case 8: return launch_attn_s257_dbg<8>(qkv, out, B, heads, q_limit, st);
+        case 9: return launch_attn_s257_dbg<9>(qkv, out, B, heads, q_limit, st);
+        default: break;
+    }
+    if (int rc = keds_func_lds_once((const void*)attention_s257_kernel<0>, s257::LDS, "attention_s257_kernel")) return rc;
+    KedsProfScope prof(KEDS_PROF_ATTN, st);
+    attention_s257_kernel<0><<<B * heads, 512, s257::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, heads, q_limit, nullptr);
+    return keds_check_launch("attention_s257_kernel");
 }
 
 template <int NKT, bool CAUSAL, int NFULL>
@@ -476,9 +876,16 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit
 
 }  // namespace
 
+extern "C" int keds_attention_stamp_buffer(void* buf) {      // diagnostic: B * heads * 64 uint64 for keds_attention_debug(64 + 8)
+    g_attn_stamp = (unsigned long long*)buf;
+    return KEDS_OK;
+}
+
 extern "C" int keds_attention_debug(int variant) {
-    g_attn_debug = variant & 15;
+    g_attn_s257_dbg = (variant >> 6) & 1 ? (variant & 15) : 0;   // bit 6: the code applies to the 8-wave S = 257 kernel
+    g_attn_debug = (variant >> 6) & 1 ? 0 : (variant & 15);
     g_attn_tail = (variant >> 4) & 1 ? 0 : 1;      // bit 4: S = 257 through the generic kernel (A/B)
+    g_attn_s257 = (variant >> 5) & 1 ? 0 : 1;      // bit 5: S = 257 through the 4-wave tail kernel (A/B)
     return KEDS_OK;
 }
 
@@ -502,6 +909,7 @@ extern "C" int keds_attention_mx(const void* qkv, void* out, int B, int S, int h
     }
     if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
     if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
+    if (S == 257 && !q8 && g_attn_tail && g_attn_s257 && !g_attn_debug) return launch_attn_s257(qkv, out, B, heads, q_limit, st);
     if (S == 257 && !q8 && g_attn_tail && !g_attn_debug) return launch_attn_tail1(qkv, out, B, heads, q_limit, st);
     if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);   // ViT-L/14: 257 tokens
     return launch_attn<18, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);

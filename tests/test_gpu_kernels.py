@@ -174,6 +174,46 @@ def test_attention_257_tail_kernel_against_generic_and_reference():
     assert torch.equal(out1[first.cuda()].float().cpu(), tail[first])
 
 
+def test_attention_257_eight_wave_kernel():
+    """The product kernel for S = 257 (eight waves per (batch, head), 32-key tiles, probabilities relative to the first
+    tile's row maximum): against the fp32 reference no worse than the 4-wave kernels, q_limit forms (CLS only, a partial
+    block, all MFMA blocks without the last query; the dominant key's probability is 2^x rounded to bf16 here where a kernel
+    that subtracts the exact row maximum has an exact 1.0, hence the factor 1.3), and the recompute path -- rows whose maximum lies far above the first
+    tile's (here: > 64 in log2 units) are recomputed with the true maximum and still meet the tolerance."""
+    lib = _lib.load()
+    B, S, heads = 3, 257, 4
+    qkv = bf16_round(_rand((B * S, 3 * heads * 64), 29, std=1.5))
+    ref = _attn_ref(qkv, B, S, heads, False)
+    dev = qkv.cuda().to(torch.bfloat16)
+    new = ops.attention(dev, B, S, heads, False).float().cpu()
+    errs = {}
+    try:
+        for code, name in ((32, "tail4"), (16, "generic")):
+            lib.keds_attention_debug(code)
+            errs[name] = rel_l2(ops.attention(dev, B, S, heads, False).float().cpu(), ref)
+    finally:
+        lib.keds_attention_debug(0)
+    last = torch.arange(B) * S + 256
+    report("attention.s257_8wave", rel_l2=rel_l2(new, ref), last_query_rel_l2=rel_l2(new[last], ref[last]), **errs)
+    assert rel_l2(new, ref) <= 1.3 * max(errs.values()) and rel_l2(new[last], ref[last]) <= 1e-2
+    for ql in (1, 100, 256):
+        out = torch.full((B * S, heads * 64), 7.0, dtype=torch.bfloat16, device="cuda")
+        _lib.check(lib.keds_attention_ex(_lib.ptr(dev), _lib.ptr(out), B, S, heads, 0, ql, _lib.stream()), "attention q_limit")
+        out = out.float().cpu().reshape(B, S, -1)
+        assert torch.equal(out[:, :ql], new.reshape(B, S, -1)[:, :ql])
+        assert bool((out[:, ql:] == 7.0).all())                # rows past q_limit are not written
+    # recompute path: keys 32.. carry 40x larger K rows for head 1 of sample 0 -> row maxima ~500 raw score units above tile 0's
+    big = qkv.clone().reshape(B, S, 3, heads, 64)
+    big[0, 32:, 1, 1] *= 40.0
+    big[1, 256, 1, 2] *= 60.0                                  # only the LAST key is far above (rank-1 path decides)
+    big = bf16_round(big.reshape(B * S, -1))
+    ref2 = _attn_ref(big, B, S, heads, False)
+    out2 = ops.attention(big.cuda().to(torch.bfloat16), B, S, heads, False).float().cpu()
+    assert torch.isfinite(out2).all()
+    report("attention.s257_8wave.recompute", rel_l2=rel_l2(out2, ref2))
+    assert rel_l2(out2, ref2) <= 1e-2
+
+
 def test_attention_peaked_rows():
     """One dominant key per query (softmax ~ one-hot) and large logits: exercises the max subtraction."""
     B, S, heads = 1, 257, 2
