@@ -801,6 +801,15 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
     }
 }
 
+// NOTE (measured, round 2): a PERSISTENT form of the kernel above was built (two workgroups per CU walking the (batch, head)
+// items; the two 128-key halves of the LDS image as a ring: keys 0-127 of item i+1 requested behind the mid-item barrier of
+// item i, keys 128-255 behind the top barrier; row 256 by LDS-DMA; overflow handled per tile with a lazy online-softmax
+// rescale so that no item is revisited).  It aimed at the 8-9 k of a wave's 27 k cycles spent waiting for its item's rows
+// (PMC: waves parked 39 %, issue ports 60 % busy).  Correct, and 195 us against 70 us: at the 128-VGPR budget of four waves
+// per SIMD the item loop spills 36-110 registers (hoisted lane offsets, the next item's query fragments beside the output
+// tiles), and every spill reload is a vmcnt wait that, vmcnt being in-order, also waits for the LDS-DMA in flight -- the
+// prefetch it was built for.  Not kept; an assembly item loop is the way to do this.
+
 int g_attn_debug = 0;   // timing-only ablations (ViT kernel)
 int g_attn_tail = 1;    // A/B hook: 0 routes S = 257 through the generic (padded) kernel
 
