@@ -73,6 +73,9 @@ int keds_prof_read(int klass, double* total_ms, int64_t* launches);  /* synchron
 
 /* timing-only ablation hook of the D=768 scan kernel (0 = product path) */
 int keds_scan_debug(int variant);
+/* diagnostic: device buffer (>= 8 uint64 per query) that merge_pairs_kernel fills with s_memtime stamps of its phases
+ * (tools/stamp_merge.py); nullptr switches them off */
+int keds_merge_stamp_buffer(void* buf);
 
 /* bytes of the packed bf16 scan image for n rows of dimension dim (dim % 128 == 0); the image ends with a 128-byte
  * trailer holding max ||bf16(x)||, max ||x - bf16(x)||, max ||x|| over the rows (the search certificate's bounds) */

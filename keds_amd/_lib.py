@@ -137,6 +137,7 @@ SIGNATURES = {
     "keds_prof_reset": (i32, []),
     "keds_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(i64)]),
     "keds_scan_debug": (i32, [i32]),
+    "keds_merge_stamp_buffer": (i32, [vp]),
     "keds_index_packed_bytes": (sz, [i64, i32]),
     "keds_index_pack": (i32, [vp, i64, i32, i32, vp, vp]),
     "keds_index_pack_append": (i32, [vp, i64, i64, i32, i32, vp, vp]),

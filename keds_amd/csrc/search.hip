@@ -376,6 +376,10 @@ __device__ __forceinline__ unsigned wave_reduce_u32(unsigned x, Op op) {       /
     return op(b[0], b[1]);
 }
 
+__device__ unsigned long long* g_merge_stamp = nullptr;     // diagnostic (keds_merge_stamp_buffer): 8 stamps per block
+#define KEDS_MSTAMP(i)                                                                   \
+    if (mst && threadIdx.x == 0) mst[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();
+
 constexpr int MERGE_THREADS = 256;
 constexpr int MERGE_WAVES = MERGE_THREADS / 64;
 constexpr int MERGE_SLOTS = 4 * LISTK;    // pairs per segment at most (64)
@@ -391,9 +395,12 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsign
     __shared__ unsigned long long lp[MERGE_LDS_PAIRS];
     __shared__ unsigned s_red[4][MERGE_WAVES];
     __shared__ unsigned s_T, s_rem, s_out, s_eq;
+    __shared__ __attribute__((aligned(16))) unsigned hist[256];
     __shared__ int eq_idx[256];
     __shared__ float eq_val[256];
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned long long* mst = g_merge_stamp;
+    KEDS_MSTAMP(0)
     auto umax = [](unsigned a, unsigned b) { return a > b ? a : b; };
     auto umin = [](unsigned a, unsigned b) { return a < b ? a : b; };
     auto uadd = [](unsigned a, unsigned b) { return a + b; };
@@ -445,7 +452,9 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsign
         s_red[2][wv] = kmin;
         s_red[3][wv] = lastkey;
     }
+    KEDS_MSTAMP(1)
     __syncthreads();
+    KEDS_MSTAMP(2)
     unsigned V = 0, wbase = 0;
 #pragma unroll
     for (int w = 0; w < MERGE_WAVES; ++w) {
@@ -483,37 +492,56 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsign
         for (int j = 0; j < MERGE_SLOTS; ++j)
             if ((unsigned)j < cnt) lp[off + j] = pr[j];
         __syncthreads();
+        KEDS_MSTAMP(3)
         if (V > (unsigned)ncand) {
-            if (wv == 0) {
-                unsigned ck[MERGE_LDS_PAIRS / 64];
-                const int nj = (int)((V + 63u) >> 6);
-#pragma unroll
-                for (int j = 0; j < MERGE_LDS_PAIRS / 64; ++j)
-                    ck[j] = (j < nj && (unsigned)(lane + 64 * j) < V) ? (unsigned)(lp[lane + 64 * j] >> 32) : 0u;
-                // T = the ncand-th largest key: greedy bit by bit, largest T with count(key >= T) >= want
-#pragma unroll 1
-                for (int bit = top; bit >= 0; --bit) {
-                    const unsigned cand = prefix | (1u << bit);
-                    unsigned c2 = 0;
-#pragma unroll
-                    for (int j = 0; j < MERGE_LDS_PAIRS / 64; ++j)
-                        if (j < nj) c2 += ck[j] >= cand ? 1u : 0u;               // wave-uniform skip
-                    if (wave_reduce_u32(c2, uadd) >= want) prefix = cand;
+            // T = the want-th largest key by MSB-first radix selection, 8 bits per pass over the bits in which keys differ
+            // (scores of one query share their high bits: usually three passes): LDS histogram of the digit among the keys
+            // that match the prefix so far, then one wave walks the 256 bins from the top.  (A one-wave bisection over
+            // registers, one bit per step, took 57 k of this kernel's 76 k cycles.)
+            unsigned rem_l = want;                                     // how many keys are still to be taken at / below the prefix
+            unsigned pfx = 0;                                          // digits decided so far (the bits above `shift + 8`)
+            int shift = top >= 0 ? (top & ~7) : -8;                    // first digit that can differ (all keys equal: none)
+            if (top >= 0) pfx = shift >= 24 ? 0u : (kmax >> (shift + 8));
+            else pfx = kmax;
+            for (; shift >= 0; shift -= 8) {
+                hist[tid] = 0;
+                __syncthreads();
+                for (unsigned p2 = tid; p2 < V; p2 += MERGE_THREADS) {
+                    const unsigned k = (unsigned)(lp[p2] >> 32);
+                    const bool in = shift >= 24 ? true : (k >> (shift + 8)) == pfx;
+                    if (in) atomicAdd(&hist[(k >> shift) & 255u], 1u);
                 }
-                unsigned gtc = 0;
+                __syncthreads();
+                if (wv == 0) {
+                    const u32x4 h4 = *reinterpret_cast<const u32x4*>(&hist[4 * lane]);
+                    const unsigned tl = h4[0] + h4[1] + h4[2] + h4[3];
+                    unsigned suf = tl;                                 // inclusive suffix sum over the lanes (bins 4 lane ..)
 #pragma unroll
-                for (int j = 0; j < MERGE_LDS_PAIRS / 64; ++j) gtc += ck[j] > prefix ? 1u : 0u;
-                gtc = wave_reduce_u32(gtc, uadd);
-                if (lane == 0) {
-                    s_T = prefix;
-                    s_rem = want - gtc;
+                    for (int o = 1; o < 64; o <<= 1) {
+                        const unsigned dn = __shfl_down(suf, o, 64);
+                        if (lane + o < 64) suf += dn;
+                    }
+                    unsigned above = suf - tl;                         // keys in bins above this lane's four
+                    // the bin b with above(b) < rem <= above(b) + h[b]: exactly one (lane, bin)
+#pragma unroll
+                    for (int e = 3; e >= 0; --e) {
+                        if (above < rem_l && rem_l <= above + h4[e]) {
+                            s_T = (unsigned)(4 * lane + e);
+                            s_rem = rem_l - above;
+                        }
+                        above += h4[e];
+                    }
                 }
+                __syncthreads();
+                pfx = (pfx << 8) | s_T;
+                rem_l = s_rem;
             }
-            __syncthreads();
-            T = s_T;
-            rem = s_rem;
+            T = pfx;                                                   // all 32 bits decided: the want-th largest key
+            rem = rem_l;                                               // of the keys == T, this many are taken
         }
+        KEDS_MSTAMP(4)
         for (unsigned p2 = tid; p2 < V; p2 += MERGE_THREADS) take(lp[p2], T);
+        KEDS_MSTAMP(5)
     } else {
         // dense lists: block-wide bisection over the registers (two barriers per bit)
         auto block_sum = [&](unsigned x) -> unsigned {
@@ -560,6 +588,8 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsign
         cand_idx[q * ncand + o] = -1;
         cand_val[q * ncand + o] = -INFINITY;
     }
+    KEDS_MSTAMP(6)
+    if (mst && tid == 0) mst[(size_t)blockIdx.x * 8 + 7] = V;
     if (tid == 0) {
         if (thr_out) thr_out[q] = V > (unsigned)ncand ? key_float(T) : -INFINITY;
         if (sbound_out) {
@@ -1029,6 +1059,11 @@ bool dim_supported(int dim) { return dim == 128 || dim == 256 || dim == 512 || d
 size_t stage_bytes(int dim) { return (size_t)STAGE_KEYS * dim * 2 + 128; }
 
 }  // namespace
+
+extern "C" int keds_merge_stamp_buffer(void* buf) {     // diagnostic: >= 8 uint64 per query; nullptr switches the stamps off
+    unsigned long long* p = (unsigned long long*)buf;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_merge_stamp), &p, sizeof(p)) == hipSuccess ? KEDS_OK : KEDS_E_LAUNCH;
+}
 
 extern "C" int keds_scan_debug(int variant) {
     g_scan_debug = variant & 15;          // bits 0-3: timing-only ablation
