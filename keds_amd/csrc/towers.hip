@@ -66,6 +66,11 @@ TowerWs carve_tower(void* ws, int width, int seq, int B) {
 // 5.6 % of the step when it runs between the full-tile launches).  Rows only meet in the attention, so per block the
 // remainder chain (out-proj, fc, proj, next qkv) runs on the side lane while the caller's stream runs the same four GEMMs
 // on the full tiles: fork after the attention, join before the next one.
+// Measured in round 2 (bench step, 128 images): 21.85 ms with the side lane, 22.85 ms with the remainder launches between
+// the full-tile ones, 21.46 ms with the remainder rows not computed at all (timing only) -- the lane recovers 0.6 of the
+// 1.0 ms these 0.39 % of the rows cost.  A side workgroup cannot share a CU with a 256 x 256 tile (registers), so each one
+// displaces a tile of the kernel running beside it; forking the chain behind the out-proj launch instead of in front of it
+// (so that it runs under c_fc's eight rounds of tiles rather than out-proj's two) changes nothing measurable.
 struct RowLanes {
     hipStream_t main = nullptr, side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;

@@ -7,7 +7,7 @@ out = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
-        for key in ("gemm_bt_pair_kernel", "gemm_bt_kernel", "scan_topk_kernel<768, 16", "scan_topk_kernel<768, 4", "attention_tail1_kernel", "attention_kernel", "layernorm_kernel", "merge_pairs_kernel"):
+        for key in ("gemm_bt_pair_kernel", "gemm_bt_kernel", "scan_topk_kernel<768, 16", "scan_topk_kernel<768, 4", "attention_s257_kernel", "attention_tail1_kernel", "attention_kernel", "layernorm_kernel", "merge_pairs_kernel"):
             if key in name:
                 out[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {}
