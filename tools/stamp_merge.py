@@ -21,7 +21,7 @@ idx.search_device(q, 10)          # the buffer holds the LAST merge of the searc
 torch.cuda.synchronize()
 lib.keds_merge_stamp_buffer(None)
 st = buf.cpu().reshape(nq, 8).double()
-names = ["loads issued + landed, counts, wave scans", "first barrier", "pack into LDS + barrier", "bisection (one wave) + barrier", "collect", "ties + fillers"]
+names = ["loads issued + landed, counts, wave scans", "first barrier", "pack into LDS + barrier", "radix selection + barriers       ", "collect", "ties + fillers"]
 print("valid pairs per query: mean %.0f  max %.0f" % (st[:, 7].mean(), st[:, 7].max()))
 for i, nme in enumerate(names):
     v = st[:, i + 1] - st[:, i]
