@@ -809,6 +809,13 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
 // per SIMD the item loop spills 36-110 registers (hoisted lane offsets, the next item's query fragments beside the output
 // tiles), and every spill reload is a vmcnt wait that, vmcnt being in-order, also waits for the LDS-DMA in flight -- the
 // prefetch it was built for.  Not kept; an assembly item loop is the way to do this.
+// NOTE (measured, round 2): the "keys 0-127 first" wait of the kernel above is not what the hardware executes: __syncthreads()
+// is a workgroup-scope fence and drains vmcnt in front of the barrier, the compiler puts s_waitcnt vmcnt(0) in front of the
+// first ds_write behind an LDS-DMA and in front of the first ds_read_tr builtin (it cannot tell them from the DMA in flight),
+// and a plain query load is waited for with vmcnt(0) at its first use.  A build with raw s_barrier asm, row 256 by LDS-DMA,
+// inline-asm query loads and inline-asm transposed reads (so that tiles 0-3 really run under the DMA of keys 128-255) is
+// correct and SLOWER, 92 us against 70: the asm statements pin the schedule and spill 15 registers, and the wait for keys
+// 0-127 alone is as long as the wait for all 256 (10 k cycles: first-byte latency, not volume).  Not kept.
 
 int g_attn_debug = 0;   // timing-only ablations (ViT kernel)
 int g_attn_tail = 1;    // A/B hook: 0 routes S = 257 through the generic (padded) kernel
