@@ -769,12 +769,12 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
                 bf16_t* op = obase + (size_t)query * d + 4 * hh;
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    *reinterpret_cast<bf16x4*>(op + 8 * g4) =
-                        bf16x4{(bf16_t)(o0[4 * g4] * inv), (bf16_t)(o0[4 * g4 + 1] * inv), (bf16_t)(o0[4 * g4 + 2] * inv),
-                               (bf16_t)(o0[4 * g4 + 3] * inv)};
-                    *reinterpret_cast<bf16x4*>(op + 32 + 8 * g4) =
-                        bf16x4{(bf16_t)(o1[4 * g4] * inv), (bf16_t)(o1[4 * g4 + 1] * inv), (bf16_t)(o1[4 * g4 + 2] * inv),
-                               (bf16_t)(o1[4 * g4 + 3] * inv)};
+                    const bf16x4 w0 = bf16x4{(bf16_t)(o0[4 * g4] * inv), (bf16_t)(o0[4 * g4 + 1] * inv), (bf16_t)(o0[4 * g4 + 2] * inv),
+                                             (bf16_t)(o0[4 * g4 + 3] * inv)};
+                    const bf16x4 w1 = bf16x4{(bf16_t)(o1[4 * g4] * inv), (bf16_t)(o1[4 * g4 + 1] * inv), (bf16_t)(o1[4 * g4 + 2] * inv),
+                                             (bf16_t)(o1[4 * g4 + 3] * inv)};
+                    *reinterpret_cast<bf16x4*>(op + 8 * g4) = w0;       // (non-temporal 8-byte stores: +2.2 ms per step)
+                    *reinterpret_cast<bf16x4*>(op + 32 + 8 * g4) = w1;
                 }
             }
             break;

@@ -323,8 +323,13 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
                 continue;
             }
             const unsigned off = ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)nl) * 2u;
-            *reinterpret_cast<bf16x8*>(tile_out + off) = bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
-                                                                (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+            const bf16x8 ov = bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                                     (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+            // non-temporal: the tile is read next by another kernel, after 200+ MB of other traffic; keeping it out of the way
+            // of the operand panels in L2 is worth 0.55 ms of the 21.7 ms step (same-box A/B, round 2, tools/ab_nt.sh).  The same
+            // hint on the A-panel DMA costs 2.5 ms (the four tiles of an XCD that share a panel stop sharing it), on the
+            // fp16 residual stores it is neutral, on the attention kernel's 8-byte output stores it costs 2.2 ms.
+            __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(tile_out + off));
         }
     }
 }
@@ -367,9 +372,11 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
             if constexpr (DBG == 3 || DBG == 5) {
                 const f32x4 v = v0 + v1;
                 if (v[0] + v[1] + v[2] + v[3] == 12345.678f) reinterpret_cast<float*>(out)[0] = v[0];
-            } else
-                *reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u) =
-                    f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+            } else {
+                const f16x8 ov = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+                f16x8* dst = reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
+                *dst = ov;      // (a non-temporal store here is neutral: the stream is re-read by the very next GEMM)
+            }
             s += sum8(v0, v1);
             ss += sum8(v0 * v0, v1 * v1);
         }
