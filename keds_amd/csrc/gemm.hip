@@ -328,7 +328,8 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
             // non-temporal: the tile is read next by another kernel, after 200+ MB of other traffic; keeping it out of the way
             // of the operand panels in L2 is worth 0.55 ms of the 21.7 ms step (same-box A/B, round 2, tools/ab_nt.sh).  The same
             // hint on the A-panel DMA costs 2.5 ms (the four tiles of an XCD that share a panel stop sharing it), on the
-            // fp16 residual stores it is neutral, on the attention kernel's 8-byte output stores it costs 2.2 ms.
+            // fp16 residual stores it is neutral, on the attention kernel's 8-byte output stores it costs 2.2 ms, and on the bf16
+            // output of the MXFP8 kernel (gemm_fp8.hip) it costs 0.2 ms of that mode's 17.2 ms step.
             __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(tile_out + off));
         }
     }
