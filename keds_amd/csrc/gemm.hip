@@ -991,6 +991,17 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // 256^2 kernel; 15 % behind before that): 50 % more DMA bytes per flop and two barriers per K-tile cost more than the
 // hidden fixed costs return.
 
+// NOTE (measured, round 2): TWO tiles per workgroup, straight-line instead of a tile loop (tile A, then tile B = A + tiles/2
+// of the same walk order; behind A's K-loop one barrier, B's statistics loads and first two K-tiles requested, THEN A's
+// epilogue, so that B's whole prologue and the gap between workgroups lie under it; counted vmcnt(8 + 16) / (16 + 16) for
+// "B's K-tile 0 / statistics have landed"; a second side area and a private 8 KiB for the statistics pre-reduction: 144 KiB
+// of LDS).  With the lane constants of the DMA and of the fragment reads made opaque between the tiles (otherwise every
+// 64-bit piece address of tile A is kept for tile B in scratch) it compiles to 255 VGPRs and no spill, is bit-identical
+// -- and changes nothing: 20.54 / 20.58 ms per step against 20.55 / 20.57 (with the spills: +1.2 ms).  Hiding the 4-5 k
+// cycle prologue returns no time.  Together with the earlier findings (zero-filled operands run 19 % faster at identical
+// cycle counts; the only changes that paid this round removed memory traffic) this says the kernel is bound by what the
+// chip can power, not by its schedule: idle cycles removed come back as clock.  Not kept.
+
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
 int g_pair_stamp = 0;     // diagnostic: stamped build of the qkv instantiation (aux2 = stamp buffer)
 
