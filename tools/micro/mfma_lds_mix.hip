@@ -1,0 +1,117 @@
+// The 256x256 GEMM's K-step without its memory side: every wave reads its A / W fragments of a K-tile from LDS (24 ds_read_b128
+// per 64-K tile, the product kernel's addressing and swizzle) and multiplies them into 128 accumulator registers -- once with
+// v_mfma_f32_16x16x32_bf16 (the product kernel: 64 MFMAs per K-tile per wave, 8 issue cycles each) and once with
+// v_mfma_f32_32x32x16_bf16 (32 MFMAs of twice the work: half the issue slots and half the operand-register reads per flop).
+// Random data in LDS (the chip's clock under load depends on what toggles).  Answers: would the 32x32 form sustain more?
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int SHAPE>
+__global__ __launch_bounds__(512, 2) void mix_kernel(const uint4* __restrict__ src, float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];     // two operand buffers of 64 KiB: X | W each 32 KiB
+    for (int i = threadIdx.x; i < 131072 / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave & 3, wm = wave >> 2;
+    float s = 0.f;
+    if constexpr (SHAPE == 0) {
+        const int g = lane >> 4, c = lane & 15, f = (c >> 1) & 7;
+        const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
+        const int xrow = (128 * wm + c) * 128, wrow = 32768 + (64 * wn + c) * 128;
+        f32x4 acc[4][8];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int it = 0; it < iters; ++it) {
+            const char* b = smem + (it & 1) * 65536;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int slot = kk ? slot1 : slot0;
+                bf16x8 w[4], x[8];
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) w[ni] = *reinterpret_cast<const bf16x8*>(b + wrow + slot + ni * 2048);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) x[mi] = *reinterpret_cast<const bf16x8*>(b + xrow + slot + mi * 2048);
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], x[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) s += acc[ni][mi][0] + acc[ni][mi][3];
+    } else {
+        // 32x32x16: lane (r = lane & 31, h = lane >> 5) holds row r, k = 8 h .. 8 h + 7 of a 16-wide k-step
+        const int r = lane & 31, h = lane >> 5, f = (r >> 1) & 7;
+        const int xrow = (128 * wm + r) * 128, wrow = 32768 + (64 * wn + r) * 128;
+        f32x16 acc[2][4];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+            const char* b = smem + (it & 1) * 65536;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int slot = ((2 * ks + h) ^ f) << 4;
+                bf16x8 w[2], x[4];
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) w[ni] = *reinterpret_cast<const bf16x8*>(b + wrow + slot + ni * 4096);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) x[mi] = *reinterpret_cast<const bf16x8*>(b + xrow + slot + mi * 4096);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ni], x[mi], acc[ni][mi], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) s += acc[ni][mi][0] + acc[ni][mi][15];
+    }
+    if (s == 1.2345f) out[0] = s;
+}
+
+template <int SHAPE>
+void run(const char* name, const uint4* src, float* out) {
+    const int iters = 3000;
+    hipFuncSetAttribute((const void*)mix_kernel<SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    mix_kernel<SHAPE><<<256, 512, 131072>>>(src, out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    mix_kernel<SHAPE><<<256, 512, 131072>>>(src, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 256.0 * iters * 2.0 * 256 * 256 * 64;      // one 256 x 256 x 64 K-tile per iteration per workgroup
+    printf("%-52s %8.2f ms  %7.1f TFLOP/s  (%.0f cycles per K-tile at 2.0 GHz)\n", name, ms, flops / (ms * 1e-3) / 1e12,
+           ms * 1e-3 / iters * 2.0e9);
+}
+
+int main() {
+    uint4* src; float* out;
+    hipMalloc(&src, 131072); hipMalloc(&out, 64);
+    unsigned short* h = (unsigned short*)malloc(131072);
+    srand(1);
+    for (int i = 0; i < 65536; ++i) {            // random bf16 in roughly [-2, 2]
+        const float v = ((rand() & 0xFFFF) / 32768.0f - 1.0f) * 2.0f;
+        unsigned u; memcpy(&u, &v, 4); h[i] = (unsigned short)(u >> 16);
+    }
+    hipMemcpy(src, h, 131072, hipMemcpyHostToDevice);
+    for (int rep = 0; rep < 2; ++rep) {
+        run<0>("16x16x32: 24 ds_read_b128 + 64 MFMA per wave K-tile", src, out);
+        run<1>("32x32x16: 24 ds_read_b128 + 32 MFMA per wave K-tile", src, out);
+    }
+    return 0;
+}
