@@ -3,6 +3,8 @@
 // v_mfma_f32_16x16x32_bf16 (the product kernel: 64 MFMAs per K-tile per wave, 8 issue cycles each) and once with
 // v_mfma_f32_32x32x16_bf16 (32 MFMAs of twice the work: half the issue slots and half the operand-register reads per flop).
 // Random data in LDS (the chip's clock under load depends on what toggles).  Answers: would the 32x32 form sustain more?
+// Measured (round 2): 1.44-1.69 PFLOP/s for both forms (the register-only loop: 2.06); the plain-compiled four-wave
+// 128 x 128 layout below 1.20-1.23 (its 256 accumulators wander between AGPRs and VGPRs unless pinned: gemm.hip notes).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -83,6 +85,61 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const uint4* __restrict__ s
     if (s == 1.2345f) out[0] = s;
 }
 
+// the vendor-style layout: FOUR waves, 128 x 128 per wave (256 accumulator registers: one wave per SIMD, the whole 512-register
+// file), 32 fragment reads per wave per K-tile = 128 per CU instead of 192
+__global__ __launch_bounds__(256) void mix4_kernel(const uint4* __restrict__ src, float* out, int iters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < 131072 / 16; i += 256) reinterpret_cast<uint4*>(smem)[i] = src[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int g = lane >> 4, c = lane & 15, f = (c >> 1) & 7;
+    const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
+    const int xrow = (128 * wm + c) * 128, wrow = 32768 + (128 * wn + c) * 128;
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+        const char* b = smem + (it & 1) * 65536;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int slot = kk ? slot1 : slot0;
+            bf16x8 w[8], x[8];
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) w[ni] = *reinterpret_cast<const bf16x8*>(b + wrow + slot + ni * 2048);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) x[mi] = *reinterpret_cast<const bf16x8*>(b + xrow + slot + mi * 2048);
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 8; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], x[mi], acc[ni][mi], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int ni = 0; ni < 8; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) s += acc[ni][mi][0] + acc[ni][mi][3];
+    if (s == 1.2345f) out[0] = s;
+}
+
+void run4(const char* name, const uint4* src, float* out) {
+    const int iters = 3000;
+    hipFuncSetAttribute((const void*)mix4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    mix4_kernel<<<256, 256, 131072>>>(src, out, 100);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    mix4_kernel<<<256, 256, 131072>>>(src, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = 256.0 * iters * 2.0 * 256 * 256 * 64;
+    printf("%-52s %8.2f ms  %7.1f TFLOP/s  (%.0f cycles per K-tile at 2.0 GHz)\n", name, ms, flops / (ms * 1e-3) / 1e12,
+           ms * 1e-3 / iters * 2.0e9);
+}
+
 template <int SHAPE>
 void run(const char* name, const uint4* src, float* out) {
     const int iters = 3000;
@@ -112,6 +169,7 @@ int main() {
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("16x16x32: 24 ds_read_b128 + 64 MFMA per wave K-tile", src, out);
         run<1>("32x32x16: 24 ds_read_b128 + 32 MFMA per wave K-tile", src, out);
+        run4("4 waves x 128x128: 32 ds_read_b128 + 128 MFMA per wave", src, out);
     }
     return 0;
 }
