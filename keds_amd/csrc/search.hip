@@ -653,7 +653,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(const float* __restrict__ d
 //       + 2e-4 ||q~|| max||x~||  (fp32 accumulation of the MFMA chain: 768 adds x 2^-24 relative, 4x margin)
 //   so if the k-th best candidate's exact score t_k satisfies  t_k - eps(q) > sbound[q],  every outside row is strictly
 //   worse than k candidates: the result is the exact top-k, ties included.  Otherwise the query goes to the exact
-//   fallback (exact_chunk_kernel / exact_merge_kernel) with the pruning bound dk = the k-th candidate distance.
+//   fallback (exact_chunk_kernel, which also merges) with the pruning bound dk = the k-th candidate distance.
 // counters[0] = failed certificates of this launch set; status[0] / [1] += certified / fallback queries (nullable).
 __global__ __launch_bounds__(256) void certify_select_kernel(const int* __restrict__ cand_idx, const float* __restrict__ cand_d,
                                                              int ncand, int metric, int k, long long id_base,
@@ -719,6 +719,7 @@ __global__ __launch_bounds__(256) void certify_select_kernel(const int* __restri
             const int f = atomicAdd(counters, 1);
             fail_ids[f] = q;
             fslot[q] = f;
+            counters[8 + f] = 0;             // chunks of this query the exact pass has finished (its last one merges)
             dk[q] = nvalid >= k ? s_dk : (metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY);
             if (status) atomicAdd(status + 1, 1);
         }
@@ -730,6 +731,9 @@ __global__ __launch_bounds__(256) void certify_select_kernel(const int* __restri
 // rows from the fp32 matrix, keep the rows that are not worse than the pruning bound dk[q], rank them by (distance, id)
 // and write the best min(count, k) in order to plist[f][c][0..k).  Persistent blocks walk the items with the failed
 // queries fastest, so the blocks that run together stream the same rows (L2).  Exits at once when nothing failed.
+__device__ __noinline__ void exact_merge_query(int q, int f, int nchunks, int k, int metric, long long id_base,
+                                               const unsigned long long* __restrict__ plist, const int* __restrict__ pcnt,
+                                               float* __restrict__ D, long long* __restrict__ I);
 __device__ __forceinline__ unsigned long long exact_key(float d, int id, int metric) {
     const float kf = metric == KEDS_METRIC_L2 ? d : -d;            // smaller is better
     return ((unsigned long long)ord_key(kf) << 32) | (unsigned)id;
@@ -739,7 +743,9 @@ __global__ __launch_bounds__(256) void exact_chunk_kernel(const float* __restric
                                                           const float* __restrict__ qn, const int* __restrict__ counters,
                                                           const int* __restrict__ fail_ids, const float* __restrict__ dk,
                                                           int chunk_rows, int nchunks, int k,
-                                                          unsigned long long* __restrict__ plist, int* __restrict__ pcnt) {
+                                                          unsigned long long* __restrict__ plist, int* __restrict__ pcnt,
+                                                          int* __restrict__ done, long long id_base, float* __restrict__ Dq,
+                                                          long long* __restrict__ Iq) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int nfail = counters[0];
     if (nfail == 0) return;
@@ -789,18 +795,28 @@ __global__ __launch_bounds__(256) void exact_chunk_kernel(const float* __restric
             if (rank < k) out[rank] = me;
         }
         if (tid == 0) pcnt[(size_t)f * nchunks + c] = cnt < k ? cnt : k;
+        // the block that finishes the query's last chunk merges its lists (release / acquire through the counter)
+        __syncthreads();
+        if (tid == 0) {
+            __threadfence();
+            s_cnt = atomicAdd(&done[f], 1) == nchunks - 1 ? -1 : 0;
+        }
+        __syncthreads();
+        if (s_cnt == -1) {
+            __threadfence();
+            exact_merge_query(q, f, nchunks, k, metric, id_base, plist, pcnt, Dq, Iq);
+        }
     }
 }
 
 // Exact fallback, pass 2: one block per query whose certificate failed merges its chunk lists (each sorted) into the
 // final top-k: thread t owns the lists t, t + 256, ... and the block pops the smallest head k times.
-__global__ __launch_bounds__(256) void exact_merge_kernel(const int* __restrict__ fslot, int nchunks, int k, int metric,
-                                                          long long id_base, const unsigned long long* __restrict__ plist,
-                                                          const int* __restrict__ pcnt, float* __restrict__ D,
-                                                          long long* __restrict__ I) {
-    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int f = fslot[q];
-    if (f < 0) return;
+// Exact fallback, merge: the k best of a failed query's chunk lists (each sorted), by the block that finished the query's LAST
+// chunk (no second launch: a search that certifies every query -- the normal case -- pays one empty launch, not two).
+__device__ __noinline__ void exact_merge_query(int q, int f, int nchunks, int k, int metric, long long id_base,
+                                               const unsigned long long* __restrict__ plist, const int* __restrict__ pcnt,
+                                               float* __restrict__ D, long long* __restrict__ I) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int OWN = 8;                                 // lists per thread: nchunks <= 2048
     __shared__ unsigned long long s_best[4];
     __shared__ int s_who[4];
@@ -928,7 +944,7 @@ int device_cus() { return keds_device_cus(); }
 constexpr int MAXQB = 8;   // query blocks searched per launch set (1024 queries)
 constexpr size_t EXACT_BUDGET = (size_t)256 << 20;   // bytes of chunk lists the exact fallback may use
 
-// rows per chunk of the exact fallback: at most 2048 chunks (exact_merge_kernel: 8 lists per thread), chunk lists for
+// rows per chunk of the exact fallback: at most 2048 chunks (exact_merge_query: 8 lists per thread), chunk lists for
 // every query of a launch set within EXACT_BUDGET, and a survivor list that fits LDS (16384 rows = 128 KiB); 0 = impossible
 int exact_chunk_rows(int64_t n, int nq_set, int k) {
     for (int rows = 2048; rows <= 16384; rows *= 2) {
@@ -954,7 +970,7 @@ struct SearchWs {
     float* dk;       // [1024] pruning bound of the exact fallback
     int* fail_ids;   // [1024]
     int* fslot;      // [1024]
-    int* counters;   // [4]
+    int* counters;   // [8 + 1024]
     unsigned long long* plist;   // [nq_set, nchunks, k] exact fallback chunk lists
     int* pcnt;       // [nq_set, nchunks]
     int chunk_rows, nchunks;
@@ -989,7 +1005,7 @@ SearchWs carve(void* ws, int nq, int dim, int64_t n, int k) {
     w.dk = (float*)take(set * sizeof(float));
     w.fail_ids = (int*)take(set * sizeof(int));
     w.fslot = (int*)take(set * sizeof(int));
-    w.counters = (int*)take(256);
+    w.counters = (int*)take((8 + set) * sizeof(int));   // [0] failed certificates | [8 + f] finished chunks of fail slot f
     const int nq_set = nq < (int)set ? nq : (int)set;
     w.chunk_rows = exact_chunk_rows(n, nq_set, k);
     w.nchunks = w.chunk_rows ? (int)((n + w.chunk_rows - 1) / w.chunk_rows) : 0;
@@ -1211,10 +1227,8 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
             const size_t lds = (size_t)dim * 4 + (size_t)w.chunk_rows * 8;
             if ((rc = keds_func_lds_once((const void*)exact_chunk_kernel, (int)lds, "exact_chunk_kernel"))) return rc;
             exact_chunk_kernel<<<4 * cus, 256, lds, st>>>(db, n, dim, metric, qn, w.counters, w.fail_ids, w.dk, w.chunk_rows,
-                                                         w.nchunks, k, w.plist, w.pcnt);
+                                                         w.nchunks, k, w.plist, w.pcnt, w.counters + 8, (long long)id_base, Dq, Iq);
             if ((rc = keds_check_launch("exact_chunk_kernel"))) return rc;
-            exact_merge_kernel<<<nb, 256, 0, st>>>(w.fslot, w.nchunks, k, metric, (long long)id_base, w.plist, w.pcnt, Dq, Iq);
-            if ((rc = keds_check_launch("exact_merge_kernel"))) return rc;
         }
     }
     if (rows_out) {
