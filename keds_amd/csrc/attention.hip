@@ -764,18 +764,34 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
                     o1[4 * g4 + j] += tp * (float)vb[j];
                 }
             }
+            // 16-byte stores: lane (query r, half hh) holds dims 8 g + 4 hh + {0..3} of every 8-dim group g; the two halves swap
+            // the odd / even groups (v_permlane32_swap: the upper lanes of the first operand against the lower lanes of the
+            // second), after which hh = 0 owns the even groups whole and hh = 1 the odd ones
             const int query = 32 * wave + r;
-            if (query < q_limit) {
-                bf16_t* op = obase + (size_t)query * d + 4 * hh;
+            u32x4 st[4];
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    const bf16x4 w0 = bf16x4{(bf16_t)(o0[4 * g4] * inv), (bf16_t)(o0[4 * g4 + 1] * inv), (bf16_t)(o0[4 * g4 + 2] * inv),
-                                             (bf16_t)(o0[4 * g4 + 3] * inv)};
-                    const bf16x4 w1 = bf16x4{(bf16_t)(o1[4 * g4] * inv), (bf16_t)(o1[4 * g4 + 1] * inv), (bf16_t)(o1[4 * g4 + 2] * inv),
-                                             (bf16_t)(o1[4 * g4 + 3] * inv)};
-                    *reinterpret_cast<bf16x4*>(op + 8 * g4) = w0;       // (non-temporal 8-byte stores: +2.2 ms per step)
-                    *reinterpret_cast<bf16x4*>(op + 32 + 8 * g4) = w1;
+            for (int tile = 0; tile < 2; ++tile) {
+#pragma unroll
+                for (int pr2 = 0; pr2 < 2; ++pr2) {
+                    const int ge = 2 * pr2, go = 2 * pr2 + 1;
+                    const f32x16& o = tile ? o1 : o0;
+                    const bf16x4 pe = bf16x4{(bf16_t)(o[4 * ge] * inv), (bf16_t)(o[4 * ge + 1] * inv), (bf16_t)(o[4 * ge + 2] * inv),
+                                             (bf16_t)(o[4 * ge + 3] * inv)};
+                    const bf16x4 po = bf16x4{(bf16_t)(o[4 * go] * inv), (bf16_t)(o[4 * go + 1] * inv), (bf16_t)(o[4 * go + 2] * inv),
+                                             (bf16_t)(o[4 * go + 3] * inv)};
+                    const u32x2 ue = __builtin_bit_cast(u32x2, pe), uo = __builtin_bit_cast(u32x2, po);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(ue[0], uo[0], false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(ue[1], uo[1], false, false);
+                    st[2 * tile + pr2] = u32x4{s0[0], s1[0], s0[1], s1[1]};
                 }
+            }
+            if (query < q_limit) {
+                bf16_t* op = obase + (size_t)query * d + 8 * hh;            // hh = 0: groups 0, 2; hh = 1: groups 1, 3
+#pragma unroll
+                for (int tile = 0; tile < 2; ++tile)
+#pragma unroll
+                    for (int pr2 = 0; pr2 < 2; ++pr2)
+                        *reinterpret_cast<u32x4*>(op + 32 * tile + 16 * pr2) = st[2 * tile + pr2];
             }
             break;
         }
