@@ -500,10 +500,14 @@ __device__ __forceinline__ float wave_max_v(float x) {
     return rows_max(x);
 }
 
-template <int DBG = 0>
+// Q8 (fp8 towers): rows < q8_rows of the [B*S, d] output go out as MXFP8 (e4m3 + one e8m0 scale per 32 columns: q8 / s8
+// as in attention_kernel) INSTEAD of bf16; a 32-dim output tile of a query is exactly one MX block, held by two lanes.
+template <int DBG = 0, bool Q8 = false>
 __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                 int heads, int q_limit,
-                                                                unsigned long long* __restrict__ stamp) {
+                                                                unsigned long long* __restrict__ stamp,
+                                                                unsigned char* __restrict__ q8 = nullptr,
+                                                                unsigned char* __restrict__ s8 = nullptr, int q8_rows = 0) {
     using namespace s257;
     constexpr int S = 257, LAST = 256;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -635,7 +639,27 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
                 L += all[w * 72 + 1] * f;
                 o += all[w * 72 + 8 + lane] * f;
             }
-            obase[(size_t)LAST * d + lane] = (bf16_t)(o / L);
+            const float val = o / L;
+            const int row = b * S + LAST;
+            if (Q8 && row < q8_rows) {                               // lane = head dim: one MX block per 32-lane half
+                float amax = fabsf(val);
+                amax = fmaxf(amax, KEDS_DPP_F(amax, 0xB1));
+                amax = fmaxf(amax, KEDS_DPP_F(amax, 0x4E));
+                amax = fmaxf(amax, KEDS_DPP_F(amax, 0x141));
+                amax = fmaxf(amax, KEDS_DPP_F(amax, 0x140));
+                {
+                    auto a16 = __builtin_amdgcn_permlane16_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+                    amax = fmaxf(__uint_as_float(a16[0]), __uint_as_float(a16[1]));
+                }
+                const int e = mx_block_exp(amax);
+                const float inv2 = e == -127 ? 0.f : __uint_as_float((unsigned)(127 - e) << 23);
+                const float sv = fminf(fmaxf(val * inv2, -448.f), 448.f);
+                const unsigned pk = __builtin_amdgcn_cvt_pk_fp8_f32(sv, 0.f, 0u, false);
+                q8[(size_t)row * d + h * DH + lane] = (unsigned char)(pk & 0xFFu);
+                if ((lane & 31) == 0) s8[mx_scale_index((h * DH + lane) >> 5, row, q8_rows)] = (unsigned char)(e + 127);
+            } else {
+                obase[(size_t)LAST * d + lane] = (bf16_t)val;
+            }
         }
     };
 
@@ -768,6 +792,41 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
             // the odd / even groups (v_permlane32_swap: the upper lanes of the first operand against the lower lanes of the
             // second), after which hh = 0 owns the even groups whole and hh = 1 the odd ones
             const int query = 32 * wave + r;
+            if (Q8 && b * S + query < q8_rows) {      // (every row but the remainder rows of the tower's last half tile)
+                if (query < q_limit) {
+                    const int row = b * S + query;
+                    int ex[2];
+#pragma unroll
+                    for (int tile = 0; tile < 2; ++tile) {
+                        const f32x16& o = tile ? o1 : o0;
+                        float amax = 0.f;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) amax = fmaxf(amax, fabsf(o[i] * inv));
+                        amax = halves_max(amax);                           // the block's other 16 dims sit in lane r + 32
+                        const int e = mx_block_exp(amax);
+                        ex[tile] = e;
+                        const float inv2 = e == -127 ? 0.f : __uint_as_float((unsigned)(127 - e) << 23);
+                        unsigned dw[4];
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; ++g4) {
+                            float sv[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) sv[j] = fminf(fmaxf(o[4 * g4 + j] * inv * inv2, -448.f), 448.f);
+                            unsigned w2 = __builtin_amdgcn_cvt_pk_fp8_f32(sv[0], sv[1], 0u, false);
+                            dw[g4] = __builtin_amdgcn_cvt_pk_fp8_f32(sv[2], sv[3], w2, true);
+                        }
+                        // lane (r, hh) holds dims 8 g4 + 4 hh + {0..3}; after the swaps hh = 0 owns dims 0-15, hh = 1 dims 16-31
+                        const auto s02 = __builtin_amdgcn_permlane32_swap(dw[0], dw[2], false, false);
+                        const auto s13 = __builtin_amdgcn_permlane32_swap(dw[1], dw[3], false, false);
+                        *reinterpret_cast<u32x4*>(q8 + (size_t)row * d + h * DH + 32 * tile + 16 * hh) =
+                            u32x4{s02[0], s02[1], s13[0], s13[1]};
+                    }
+                    if (hh == 0)
+                        *reinterpret_cast<unsigned short*>(s8 + mx_scale_index((h * DH) >> 5, row, q8_rows)) =
+                            (unsigned short)((ex[0] + 127) | ((ex[1] + 127) << 8));
+                }
+                break;
+            }
             u32x4 st[4];
 #pragma unroll
             for (int tile = 0; tile < 2; ++tile) {
@@ -857,6 +916,15 @@ int launch_attn_s257_dbg(const void* qkv, void* out, int B, int heads, int q_lim
     return keds_check_launch("attention_s257_kernel<dbg>");
 }
 
+int launch_attn_s257_q8(const void* qkv, void* out, int B, int heads, int q_limit, void* q8, void* s8, int q8_rows,
+                        hipStream_t st) {
+    if (int rc = keds_func_lds_once((const void*)attention_s257_kernel<0, true>, s257::LDS, "attention_s257_kernel<q8>")) return rc;
+    KedsProfScope prof(KEDS_PROF_ATTN, st);
+    attention_s257_kernel<0, true><<<B * heads, 512, s257::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, heads, q_limit, nullptr,
+                                                                      (unsigned char*)q8, (unsigned char*)s8, q8_rows);
+    return keds_check_launch("attention_s257_kernel<q8>");
+}
+
 int launch_attn_s257(const void* qkv, void* out, int B, int heads, int q_limit, hipStream_t st) {
     switch (g_attn_s257_dbg) {
         case 1: return launch_attn_s257_dbg<1>(qkv, out, B, heads, q_limit, st);
@@ -942,6 +1010,8 @@ extern "C" int keds_attention_mx(const void* qkv, void* out, int B, int S, int h
     if (S <= 32) return launch_attn<2, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
     if (S <= 96) return launch_attn<6, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
     if (S == 257 && !q8 && g_attn_tail && g_attn_s257 && !g_attn_debug) return launch_attn_s257(qkv, out, B, heads, q_limit, st);
+    if (S == 257 && q8 && g_attn_tail && g_attn_s257 && !g_attn_debug && !g_attn_s257_dbg)
+        return launch_attn_s257_q8(qkv, out, B, heads, q_limit, q8, s8, q8_rows, st);
     if (S == 257 && !q8 && g_attn_tail && !g_attn_debug) return launch_attn_tail1(qkv, out, B, heads, q_limit, st);
     if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);   // ViT-L/14: 257 tokens
     return launch_attn<18, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
