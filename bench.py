@@ -111,6 +111,121 @@ def cpu_baseline(model, n_db, dim, k):
                       f"+ 128 queries x {rows}-row slice scaled to {n_db} rows ({t_q * 1e3:.2f} ms/query)"}
 
 
+def synth_tokens(batch, context_length=77, seed=4004, sot=49406, eot=49407, star=265):
+    """'a photo of * , <filler>' token rows: SOT 320 1125 539 * 267 filler... EOT 0..., the EOT column
+    varying per row in [8, 40]."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    out = np.zeros((batch, context_length), dtype=np.int64)
+    for b in range(batch):
+        e = 8 + int(rs.randint(0, 33))
+        row = [sot, 320, 1125, 539, star, 267] + list(rs.randint(300, 40000, size=e - 6)) + [eot]
+        out[b, :len(row)] = row
+    return torch.from_numpy(out)
+
+
+def cpu_baseline_dual(model, s_img, s_txt, n_db, dim):
+    """Oracle (CPU restatement, fp32 torch) of the dual-stream composed query on a bounded sample: 2 queries through
+    compose_query (ViT-L/14 + two knowledge streams + two text passes) against two 65,536-row database slices; the
+    two scans are scaled to n_db rows, the rest is per query."""
+    from oracle import keds_oracle as O
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 64)
+    torch.set_num_threads(threads)
+    sd = {k_: v.detach().float().cpu() for k_, v in model.state_dict().items()}
+    streams = []
+    for st in (s_img, s_txt):
+        streams.append(tuple({k_: v.detach().float().cpu() for k_, v in m.state_dict().items()}
+                             for m in (st.img2text, st.retrieval_fuse, st.text_condition)))
+    rows = 65536
+    g = torch.Generator().manual_seed(2)
+    ib = torch.nn.functional.normalize(torch.randn(rows, dim, generator=g), dim=1)
+    tb = torch.nn.functional.normalize(torch.randn(rows, dim, generator=g), dim=1)
+    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    tok = synth_tokens(2)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        O.compose_query(sd, streams[0], streams[1], img, tok, ib, tb)
+        t_all = (time.perf_counter() - t0) / 2
+        q = torch.nn.functional.normalize(torch.randn(128, dim, generator=torch.Generator().manual_seed(3)), dim=1)
+        t0 = time.perf_counter()
+        O.flat_l2_search_f32(ib, q, 16)
+        t_scan = (time.perf_counter() - t0) / 128                  # one database slice, per query
+    t_query = t_all + 2.0 * t_scan * (n_db / rows - 1.0)
+    return {"value": 1.0 / t_query, "unit": "queries/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle fp32, {threads} of {ncpu} host threads: 2 composed queries against two {rows}-row slices "
+                      f"({t_all:.2f} s/query), the two scans scaled to {n_db} rows (+{2.0 * t_scan * (n_db / rows - 1.0) * 1e3:.1f} ms/query)"}
+
+
+# Recall@k parity statement carried in every bench line (measured by tests/test_gpu_fullsize.py on the committed
+# reference fixture; the numbers of the final build are in profiles/r03_parity.json)
+RECALL_PARITY = ("Recall@{1,5,10,50,100} on the reference's ViT-L/14 1k-gallery fixture (256 queries, 1,280 (query, k) outcomes): "
+                 "equal to the reference CPU path except outcomes the reference itself decides by a score gap < 5e-4 "
+                 "(bf16 operand rounding; measured count in profiles/r03_parity.json)")
+
+
+def self_launch(gpus, argv):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a CHILD process
+    (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    <same arguments>`), relay its output and return its exit code.  Nothing in this parent has touched the GPU (no
+    torch.cuda call, no library load), it never execs, and rank 0's JSON line is printed as the LAST stdout line
+    whatever the ranks or RCCL print after it."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                                  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    if os.environ.get("KEDS_BENCH_LAUNCH_DRYRUN") == "1":       # tests: show what would be started, start nothing
+        print(json.dumps({"launch": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}), flush=True)
+        return 0
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    result = None
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith("{") and '"metric"' in s:
+            result = s                                          # held back: it must be the last line on stdout
+        else:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+    rc = proc.wait()
+    if result is not None:
+        print(result, flush=True)
+    return rc
+
+
+# text-tower GEMM work per token row (12 blocks of width 768 on every row; the read-out projection is per sequence)
+TEXT_MAC_PER_ROW = 12 * (768 * 2304 + 768 * 768 + 2 * 768 * 3072)
+
+
+def build_database(keds_amd, shard_bounds, N, D, world, rank, dev, seed, sharded):
+    """Seeded unit-norm rows, the same global stream on every rank; this rank keeps rows shard_bounds(N, world, rank)."""
+    lo, hi = shard_bounds(N, world, rank)
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    parts = []
+    for s in range(0, N, 65536):
+        blk = torch.randn(min(65536, N - s), D, generator=gen, device=dev)
+        a, b = max(lo, s), min(hi, s + blk.shape[0])
+        if a < b:
+            parts.append(torch.nn.functional.normalize(blk[a - s:b - s], dim=1))
+    rows = torch.cat(parts)
+    del parts
+    if sharded:
+        from keds_amd.index import ShardedFlatIndex
+        idx = ShardedFlatIndex(D, "l2", device=dev)
+        idx.n_global = N
+        idx.local = keds_amd.FlatIndex(D, "l2", device=dev, row0=lo)
+        idx.local.add(rows)
+        return idx, idx.local, lo, hi
+    idx = keds_amd.FlatIndex(D, "l2", device=dev, row0=lo)
+    idx.add(rows)
+    return idx, idx, lo, hi
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,8 +235,17 @@ def main():
     ap.add_argument("--db-rows", type=int, default=500000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["encode_search", "dual"], default="encode_search",
+                    help="encode_search = BASELINE configs 1-3, the headline (ViT-L/14 encode + top-10); dual = config 4: the "
+                         "dual-stream composed query (encode + 2 x top-16 with rows over two databases + 2 knowledge streams + "
+                         "2 text-tower passes + normalise / mixture)")
     ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
-                    help="fp8 = BASELINE config 5 (MXFP8 GEMM operands in the image tower); the headline metric is bf16")
+                    help="fp8 = BASELINE config 5 (MXFP8 GEMM operands in the towers; use with --db-rows 2000000); the headline "
+                         "metric is bf16")
+    ap.add_argument("--search-overlap", choices=["auto", "on", "off"], default=os.environ.get("KEDS_BENCH_OVERLAP", "auto"),
+                    help="N > 1, encode_search: run the search of batch i (its two collectives and short launches) on a second "
+                         "stream beside the encoder pass of batch i+1 (on), behind it on the encoder's stream (off), or time "
+                         "both in a pilot before the timed region and keep the faster (auto)")
     ap.add_argument("--prof-every", type=int, default=4, help="record the per-launch hipEvents on every N-th timed step")
     ap.add_argument("--prof-all", action="store_true", help="hipEvent pairs around every kernel class (default: only the "
                     "dominant GEMM class and the scan; the full breakdown costs ~1-2 %% of the step)")
@@ -131,8 +255,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the ranks as a child process before anything here touches the GPU
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -146,47 +273,52 @@ def main():
     from keds_amd.index import PackedExchange, shard_bounds
     _lib.load()                                                # fail loudly if the HIP library is missing
 
-    B, N, D, k = args.batch, args.db_rows, 768, args.k
+    dual = args.workload == "dual"
+    B, N, D = args.batch, args.db_rows, 768
+    k = 16 if dual else args.k                                 # the knowledge path takes the 16 nearest rows of each database
     model = random_clip(dev)
     if args.precision == "fp8":
         model.set_precision("fp8")
-    # synthetic database: seeded unit-norm rows; this rank keeps rows [lo, hi)
-    lo, hi = shard_bounds(N, world, rank)
-    gen = torch.Generator(device=dev).manual_seed(2002)
-    index = keds_amd.FlatIndex(D, "l2", device=dev, row0=lo)
-    chunk = 65536
-    parts = []
-    for s in range(0, N, chunk):                               # same global stream on every rank, keep own rows
-        blk = torch.randn(min(chunk, N - s), D, generator=gen, device=dev)
-        a, b = max(lo, s), min(hi, s + blk.shape[0])
-        if a < b:
-            parts.append(torch.nn.functional.normalize(blk[a - s:b - s], dim=1))
-    index.add(torch.cat(parts))
-    del parts
+    index, local_index, lo, hi = build_database(keds_amd, shard_bounds, N, D, world, rank, dev, 2002, dual and use_dist)
     images = torch.randn(B, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(1001 + rank), device=dev)
+    if dual:
+        index_t, _, _, _ = build_database(keds_amd, shard_bounds, N, D, world, rank, dev, 2003, use_dist)
+        database = [None, None, None, index, index_t]
 
-    # The search of batch i runs on its own stream behind batch i's encoder pass, beside batch i+1's: its two KB-sized,
-    # latency-bound collectives (one packed all-gather of the queries, one packed all-to-all of the partial lists;
-    # preallocated buffers, keds_amd.index.PackedExchange) and its short merge / re-rank launches hide under the next
-    # encoder pass instead of standing between two of them.
-    # (With one GPU there is no collective to hide, and a scan that shares the CUs with the next encoder pass reads at a lower
-    # rate for no gain: the search then stays on the encoder's stream.)
-    xchg = PackedExchange() if use_dist else None
-    search_stream = torch.cuda.Stream(device=dev) if use_dist else torch.cuda.current_stream()
+        def stream_modules(seed):
+            torch.manual_seed(seed)
+            a, b, c = keds_amd.make_stream_modules(model, middle_dim=512, n_layer=2, device=dev)
+            return keds_amd.KnowledgeStream(a, b, c)
+        s_img, s_txt = stream_modules(1), stream_modules(2)
+        tokens = synth_tokens(B).to(dev)
+
+    # encode_search, N > 1: the search of batch i can run on its own stream behind batch i's encoder pass, beside batch
+    # i+1's: its two KB-sized, latency-bound collectives (one packed all-gather of the queries, one packed all-to-all of the
+    # partial lists; preallocated buffers, keds_amd.index.PackedExchange) and its short merge / re-rank launches then hide
+    # under the next encoder pass instead of standing between two of them -- but a scan that shares the CUs with the next
+    # encoder pass reads at a lower rate and slows that pass down.  Which wins depends on the world size (collective
+    # latency) and is measured, not assumed: --search-overlap auto times both before the timed region.
+    # (With one GPU there is no collective to hide: the search stays on the encoder's stream.)
+    xchg = PackedExchange() if (use_dist and not dual) else None
+    main_stream = torch.cuda.current_stream()
+    side_stream = torch.cuda.Stream(device=dev) if xchg is not None else None
+    overlap = {"on": False}
     comm_events = []                                            # (gather, scan, return) hipEvent quadruples of profiled steps
     search_events = []                                          # hipEvent pairs around the whole local search of profiled steps
 
-    def step(timed=False):
+    def step_encode_search(timed=False):
         q = model.encode_image(images, normalize=True)          # [B,768] on device
-        if use_dist:
-            search_stream.wait_stream(torch.cuda.current_stream())
+        ovl = overlap["on"]
+        search_stream = side_stream if ovl else main_stream
+        if ovl:
+            search_stream.wait_stream(main_stream)
         with torch.cuda.stream(search_stream):
-            if use_dist:
+            if ovl:
                 q.record_stream(search_stream)
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (timed and use_dist) else None
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if (timed and xchg is not None) else None
             if ev:
                 ev[0].record()
-            allq = xchg.gather_queries(q) if use_dist else q
+            allq = xchg.gather_queries(q) if xchg is not None else q
             if ev:
                 ev[1].record()
             sev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if timed else None
@@ -198,12 +330,18 @@ def main():
                 search_events.append(sev)
             if ev:
                 ev[2].record()
-            if use_dist:
+            if xchg is not None:
                 Dk, Ik = xchg.return_partials(Dk, Ik, index.metric)
             if ev:
                 ev[3].record()
                 comm_events.append(ev)
         return Dk, Ik
+
+    def step_dual(timed=False):
+        out = keds_amd.compose_query_features(model, s_img, s_txt, images, tokens, database, id_split=265)
+        return out["mixture"], None
+
+    step = step_dual if dual else step_encode_search
 
     def fence():
         torch.cuda.synchronize()
@@ -211,7 +349,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_run(n):
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            step()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n * 1e3
+
     for _ in range(args.warmup):
+        step()
+    pilot = None
+    if xchg is not None:
+        if args.search_overlap == "auto":                       # untimed pilot: both placements, max over ranks, keep the faster
+            pilot = {}
+            for name, on in (("off", False), ("on", True), ("off2", False), ("on2", True)):
+                overlap["on"] = on
+                step()
+                pilot[name] = timed_run(6)
+            t_off, t_on = min(pilot["off"], pilot["off2"]), min(pilot["on"], pilot["on2"])
+            overlap["on"] = t_on < t_off
+            pilot = {"serial_ms_per_step": t_off, "overlapped_ms_per_step": t_on}
+        else:
+            overlap["on"] = args.search_overlap == "on"
         step()
     fence()
     _lib.prof_reset()
@@ -238,7 +401,7 @@ def main():
     elapsed = float(t.item())
 
     per_rank = None
-    if use_dist:                                                # what each rank's search costs, so a scaling run explains itself
+    if xchg is not None:                                        # what each rank's search costs, so a scaling run explains itself
         mine = [sum(e[i].elapsed_time(e[i + 1]) for e in comm_events) / max(len(comm_events), 1) * 1e3 for i in range(3)]
         gathered = [None] * world
         dist.all_gather_object(gathered, mine)
@@ -250,68 +413,97 @@ def main():
     attn_ms, attn_n = _lib.prof_read(_lib.PROF_ATTN)
     ln_ms, ln_n = _lib.prof_read(_lib.PROF_LN)
     other_ms, other_n = _lib.prof_read(_lib.PROF_OTHER)
+    gemm_work = _lib.prof_read_work(_lib.PROF_GEMM)            # 2*M*N*K summed over the launches that carried event pairs
 
     if rank == 0:
         steps = args.steps
         psteps = max(prof_steps, 1)                              # timed steps whose launches carried event pairs
-        gemm_flops = 2.0 * GEMM_MAC_PER_IMAGE * B * psteps     # this rank's GEMM launches on those steps
-        # rows the towers run on the side lane (B*257 mod 256 = 128 of 32,896): those launches overlap the main stream and
-        # carry no event pairs, so their flops leave the numerator as well
-        side_rows = _lib.load().keds_tower_side_rows(VITL["vision_width"], 257, B, int(args.precision == "fp8"))
-        if side_rows:
-            tower_mac = 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL
-            gemm_flops -= 2.0 * tower_mac * B * psteps * side_rows / (B * 257.0)
-        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         fp8 = args.precision == "fp8"
+        side_rows = _lib.load().keds_tower_side_rows(VITL["vision_width"], 257, B, int(fp8))
+        if dual:
+            # every GEMM launch of the step that carried an event pair (image tower, the 2B-row text-tower pass, IM2TEXT /
+            # CrossFormer GEMMs, read-outs) with its own 2*M*N*K, counted by the library at launch (keds_prof_read_work);
+            # side-lane launches carry neither events nor work
+            gemm_flops = gemm_work
+        else:
+            gemm_flops = 2.0 * GEMM_MAC_PER_IMAGE * B * psteps     # this rank's GEMM launches on those steps
+            # rows the towers run on the side lane (B*257 mod 256 = 128 of 32,896): those launches overlap the main stream
+            # and carry no event pairs, so their flops leave the numerator as well
+            if side_rows:
+                tower_mac = 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL
+                gemm_flops -= 2.0 * tower_mac * B * psteps * side_rows / (B * 257.0)
+        ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
         peak_tf = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS              # dense MFMA peak of the operand type
         peak_meas_tf = PEAK_FP8_MEASURED_TFLOPS if fp8 else PEAK_BF16_MEASURED_TFLOPS
-        # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B); a search issues two
-        # scan launches (threshold pass over the first 1/16 of the rows + the full candidate pass): both are charged
-        # to the time, only the single pass to the bytes
-        n_search = psteps * world                                # query blocks of 128 searched by this rank (profiled steps)
+        # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B), charged with the time of
+        # every scan launch the search issues
+        n_search = psteps * world * (2 if dual else 1)            # query blocks of 128 searched by this rank (profiled steps)
         scan_bytes = (hi - lo) * D * 2.0 * n_search
         scan_ach = scan_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-        # the WHOLE local search (query preparation, both scan passes, merges, re-rank, certificate + select, the exact-pass
-        # launches) against the same algorithmic bytes: what a caller of index.search pays per query block
-        whole_ms = sum(a.elapsed_time(b2) for a, b2 in search_events) / max(len(search_events), 1)
-        whole_ach = (hi - lo) * D * 2.0 * world / (whole_ms * 1e-3) / 1e9 if whole_ms > 0 else 0.0
+        # the WHOLE local search (query preparation, scan, merges, re-rank, certificate + select, the exact-pass launches)
+        # against the same algorithmic bytes: what a caller of index.search pays per query block
+        whole = None
+        if search_events:
+            whole_ms = sum(a.elapsed_time(b2) for a, b2 in search_events) / len(search_events)
+            whole_ach = (hi - lo) * D * 2.0 * world / (whole_ms * 1e-3) / 1e9 if whole_ms > 0 else 0.0
+            whole = {"ms": whole_ms, "query_blocks": world, "achieved": whole_ach, "frac": whole_ach / PEAK_HBM_GBPS}
+        if dual:
+            metric = "composed dual-stream queries/sec (ViT-L/14 encode + 2 x top-16 with rows + knowledge streams + 2 text passes)"
+            workload = ("dual-stream composed query, BASELINE config 4: ViT-L/14 encode_image (224x224 synthetic, random-init "
+                        "weights) + exact top-16 with row gather over TWO synthetic unit-norm %.1fM x 768 databases + 2 knowledge "
+                        "streams (IM2TEXT + 2 x CrossFormer) + 2 text-tower passes with pseudo-token splice + normalise / "
+                        "mixture" % (N / 1e6))
+            par = f"dp{world} encoders + knowledge path, {world}-way row-sharded scans, rows shipped with the partial lists"
+        else:
+            metric = "query-images/sec (encode+0.5M top-10) ViT-L/14"
+            workload = ("ViT-L/14 encode_image (224x224 synthetic, random-init weights) + exact top-%d over a synthetic "
+                        "unit-norm %.1fM x 768 database" % (k, N / 1e6))
+            par = f"dp{world} encoders + {world}-way row-sharded scan"
         out = {
-            "metric": "query-images/sec (encode+0.5M top-10) ViT-L/14",
+            "metric": metric,
             "value": world * B * steps / elapsed,
-            "unit": "query-images/sec",
+            "unit": "queries/sec" if dual else "query-images/sec",
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16/fp16 operands, fp32 accumulate" if args.precision == "bf16" else "fp8 (MXFP8 e4m3 operands, fp32 accumulate; config 5)", "data": "synthetic",
-            "config": {"workload": "ViT-L/14 encode_image (224x224 synthetic, random-init weights) + exact top-10 "
-                                   "over a synthetic unit-norm 0.5M x 768 database",
+            "dtype": "bf16/fp16 operands, fp32 accumulate" if not fp8 else "fp8 (MXFP8 e4m3 operands, fp32 accumulate; config 5)", "data": "synthetic",
+            "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "db_rows": N, "dim": D, "k": k,
-                       "db_shards": world, "parallelism": f"dp{world} encoders + {world}-way row-sharded scan"},
-            "roofline": {"kernel": ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane ViT GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
+                       "db_shards": world, "parallelism": par},
+            "roofline": {"kernel": ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
                          "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
-                         "traffic": None if fp8 else pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
-                         "over the 256x256 GEMM launches)", "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         "traffic": None if (fp8 or dual) else pmc_traffic("gemm_bt_pair_kernel", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
+                         "over the 256x256 GEMM launches; committed rocprofv3 --pmc passes of this workload, " + os.path.basename(PMC_FILE) + ")",
+                         "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
+                         "flops_counted_at_launch": gemm_work,
                          # practical ceiling of this chip, measured (profiles/r01_microbench.txt): a register-only
                          # v_mfma_f32_16x16x32_bf16 loop sustains 2.06 PFLOP/s (clock ~2.0 GHz under MFMA load)
                          "peak_measured": peak_meas_tf, "frac_of_measured": ach / peak_meas_tf},
             "roofline_scan": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_ach,
                               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": scan_ach / PEAK_HBM_GBPS,
-                              "traffic": pmc_traffic("scan_topk_kernel<768, 16", B, N, world),
+                              "traffic": None if dual else pmc_traffic("scan_topk_kernel<768, 16", B, N, world),
                               "algorithmic_bytes_per_search": (hi - lo) * D * 2.0,
                               "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1),
-                              "whole_search": {"ms": whole_ms, "query_blocks": world, "achieved": whole_ach,
-                                               "frac": whole_ach / PEAK_HBM_GBPS},
+                              "whole_search": whole,
                               # read-only stream over 4 GiB on this box: 7.15 TB/s (profiles/r01_microbench.txt)
                               "peak_measured": PEAK_HBM_MEASURED_GBPS, "frac_of_measured": scan_ach / PEAK_HBM_MEASURED_GBPS},
             "profiled_steps": prof_steps, "side_lane_rows": side_rows,
-            "search_overlap": ("search of batch i on a second stream beside the encoder pass of batch i+1" if use_dist
-                               else "none (one GPU: no collective to hide)"),
+            "search_overlap": ("n/a (dual: the knowledge path consumes the neighbours at once)" if dual else
+                               "none (one GPU: no collective to hide)" if xchg is None else
+                               ("search of batch i on a second stream beside the encoder pass of batch i+1" if overlap["on"]
+                                else "serial: search on the encoder's stream")),
+            "search_overlap_pilot": pilot,
             "per_rank_search": per_rank,
             "stage_ms_per_step": {"gemm": gemm_ms / psteps, "attention": attn_ms / psteps, "layernorm": ln_ms / psteps,
                                   "scan": scan_ms / psteps, "other": other_ms / psteps},
+            # Recall@k parity with the reference's CPU path on identical inputs (tests/test_gpu_fullsize.py, fixture
+            # recall_vitl14.npz: ViT-L/14, 1 k gallery, 256 queries x k in {1,5,10,50,100}); see profiles/r03_parity.json
+            "recall_parity": RECALL_PARITY,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not dual:
             out["cpu_baseline"] = cpu_baseline(model, N, D, k)
+        elif world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_dual(model, s_img, s_txt, N, D)
         try:                                   # RCCL writes its version banner through C stdio, which flushes at exit:
             import ctypes                      # push it out now so that the JSON line is the last line on stdout
             ctypes.CDLL(None).fflush(None)

@@ -56,6 +56,9 @@ int keds_numerics_guard_set(int32_t* device_flag);
 int keds_prof_enable(int on);                 /* 0 off; 1: event pair around every launch; else bit (k+1) = class k */
 int keds_prof_reset(void);
 int keds_prof_read(int klass, double* total_ms, int64_t* launches);  /* synchronises the events */
+/* algorithmic work of the launches that carried event pairs since the last reset: 2*M*N*K flops per GEMM launch
+ * (KEDS_PROF_GEMM; a patch-embedding GEMM counts its zero-padded K), scan-image bytes per scan launch (KEDS_PROF_SCAN) */
+int keds_prof_read_work(int klass, double* units);
 
 /* =====================================================================================
  * 1. Similarity + top-k  (replaces faiss.IndexFlatL2 + index_cpu_to_all_gpus + .add/.search,

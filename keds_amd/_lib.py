@@ -136,6 +136,7 @@ SIGNATURES = {
     "keds_prof_enable": (i32, [i32]),
     "keds_prof_reset": (i32, []),
     "keds_prof_read": (i32, [i32, C.POINTER(C.c_double), C.POINTER(i64)]),
+    "keds_prof_read_work": (i32, [i32, C.POINTER(C.c_double)]),
     "keds_scan_debug": (i32, [i32]),
     "keds_merge_stamp_buffer": (i32, [vp]),
     "keds_index_packed_bytes": (sz, [i64, i32]),
@@ -308,6 +309,13 @@ def prof_enable(on, classes=None) -> None:
 
 def prof_reset() -> None:
     check(load().keds_prof_reset(), "keds_prof_reset")
+
+
+def prof_read_work(klass: int) -> float:
+    """Algorithmic flops (PROF_GEMM) / scan-image bytes (PROF_SCAN) of the launches that carried event pairs."""
+    u = C.c_double(0)
+    check(load().keds_prof_read_work(klass, C.byref(u)), "keds_prof_read_work")
+    return u.value
 
 
 def prof_read(klass: int):

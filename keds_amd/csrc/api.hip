@@ -70,7 +70,12 @@ KedsSideLane* keds_side_lane() {
     return g_lane_state[dev] == 1 ? &g_lanes[dev] : nullptr;
 }
 
+// A stream wait binds to the event's most recent record AT THE TIME OF THE CALL, and the lane's two events are shared by
+// every caller on the device (keds_session.h allows different handles on different threads): record + wait are one
+// critical section, so no other thread's record of the same event can slip in between and re-aim this caller's wait.
 int keds_stream_order(hipStream_t from, hipEvent_t ev, hipStream_t to) {
+    static std::mutex order_mu;
+    std::lock_guard<std::mutex> g(order_mu);
     if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
         keds_set_error("stream ordering failed: %s", hipGetErrorString(hipGetLastError()));
         return KEDS_E_LAUNCH;
@@ -178,6 +183,7 @@ struct ProfState {
     unsigned mask = 0;   // bit k: record events for class k
     std::mutex mu;
     std::vector<EvPair> used[KEDS_PROF_NCLASS];
+    double work[KEDS_PROF_NCLASS] = {};
     std::vector<EvPair> pool;
 };
 ProfState& prof() {
@@ -212,6 +218,24 @@ KedsProfScope::~KedsProfScope() {
     (void)hipEventRecord(p.used[klass].back().b, stream);
 }
 
+void KedsProfScope::work(double units) {
+    if (!slot) return;
+    ProfState& p = prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    p.work[klass] += units;
+}
+
+extern "C" int keds_prof_read_work(int klass, double* units) {
+    if (klass < 0 || klass >= KEDS_PROF_NCLASS || !units) {
+        keds_set_error("keds_prof_read_work: bad argument");
+        return KEDS_E_ARG;
+    }
+    ProfState& p = prof();
+    std::lock_guard<std::mutex> g(p.mu);
+    *units = p.work[klass];
+    return KEDS_OK;
+}
+
 extern "C" int keds_prof_enable(int on) {
     // 0: off, 1: every class, otherwise a bit mask with bit (k+1) selecting class k (so 0b110 = GEMM + ATTN)
     prof().mask = on == 0 ? 0u : (on == 1 ? 0xFFFFFFFFu : ((unsigned)on >> 1));
@@ -224,6 +248,7 @@ extern "C" int keds_prof_reset(void) {
     for (int k = 0; k < KEDS_PROF_NCLASS; ++k) {
         for (auto& e : p.used[k]) p.pool.push_back(e);
         p.used[k].clear();
+        p.work[k] = 0;
     }
     return KEDS_OK;
 }

@@ -1048,6 +1048,7 @@ template <int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                 int aux_i, void* aux2, long long lda, long long ldc, hipStream_t st) {
     KedsProfScope prof(KEDS_PROF_GEMM, st);
+    prof.work(2.0 * M * N * K);
     // Large problems: full 256-row tiles go to the 256^2 kernel, the remainder rows (< 256) to the 128^2 one.
     // (ViT-L/14 at B=128: M = 32896 = 128*256 + 128, so 512..2048 big tiles = whole rounds on 256 CUs.)
     // the 256^2 kernel runs one workgroup per CU: use it when its full tiles keep >= 85% of the CU-rounds busy (a single

@@ -482,6 +482,7 @@ extern "C" int keds_gemm_mxfp8_ex(const void* Aq, const void* As, int m_pad, con
     KEDS_REQUIRE(m_pad >= M && n_pad >= N && m_pad % 4 == 0 && n_pad % 4 == 0, "keds_gemm_mxfp8: bad scale row padding");
     hipStream_t st = (hipStream_t)stream;
     KedsProfScope prof(KEDS_PROF_GEMM, st);
+    prof.work(2.0 * M * N * K);
 #define KEDS_FP8_GO(E, D) return launch_mxfp8<E, D>(Aq, As, m_pad, Wq, Ws, n_pad, bias, out, M, N, K, aux, aux2, qout, qscale, q_pad, st)
     switch (epilogue) {
         case KEDS_FP8_EPI_BIAS_BF16:

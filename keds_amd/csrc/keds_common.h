@@ -37,6 +37,7 @@ struct KedsProfScope {
     void* slot;
     KedsProfScope(int klass, hipStream_t s);
     ~KedsProfScope();
+    void work(double units);   // algorithmic flops (GEMM) / bytes (scan) of this launch; counted only if it carries events
 };
 
 // ---- side lane (host): a second, high-priority stream per device for the remainder-row chain of the towers ----------

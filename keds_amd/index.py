@@ -333,6 +333,54 @@ class PackedExchange:
             return ops.topk_merge_parts(Dq, Iq, metric)
         return merge_partials(Dq, Iq, metric)
 
+    def return_partials_rows(self, parts, metric: int = _lib.METRIC_L2):
+        """The knowledge path's form (SURVEY 8e option B): `parts` = [(D_p, I_p, rows_p), ...], one triple per DATABASE
+        searched with the same gathered queries (image and text database: two), D_p / I_p [world*B, k] and rows_p
+        [world*B, k, d] fp32 (this shard's rows of its partial winners).  ALL of it goes out in ONE all-to-all: per list
+        entry d + 3 int32 words (distance bits | id low | id high | the row), block r to rank r -- so the two databases'
+        partials and their rows share one message (6.3 MB per peer and database at B = 128, k = 16, d = 768) instead of
+        the six list-form collectives of round 2.  The owner then merges each database's `world` lists keyed on
+        (distance, id) and picks every winner's row from the part that supplied it.
+        Returns [(D [B,k], I [B,k], rows [B,k,d]), ...] for this rank's own queries."""
+        w = self.world
+        n, k = parts[0][0].shape
+        d = parts[0][2].shape[2]
+        B, P, E = n // w, len(parts), d + 3
+        shape = (w, P, B, k, E)
+        dev = parts[0][0].device
+        if getattr(self, "_rin", None) is None or self._rin.shape != shape or self._rin.device != dev:
+            self._rin = torch.empty(shape, dtype=torch.int32, device=dev)
+            self._rout = torch.empty(shape, dtype=torch.int32, device=dev)
+        rin = self._rin
+        for j, (D_p, I_p, rows_p) in enumerate(parts):
+            rin[:, j, :, :, 0] = D_p.contiguous().view(torch.int32).view(w, B, k)
+            rin[:, j, :, :, 1:3] = I_p.contiguous().view(torch.int32).view(w, B, k, 2)
+            rin[:, j, :, :, 3:] = rows_p.contiguous().view(torch.int32).view(w, B, k, d)
+        if dev.type == "cuda":
+            self.dist.all_to_all_single(self._rout, rin, group=self.group)       # block r <-> rank r
+            got = self._rout
+        else:
+            every = torch.empty((w * w,) + shape[1:], dtype=torch.int32)
+            self.dist.all_gather_into_tensor(every, rin, group=self.group)
+            got = every.view((w, w) + shape[1:])[:, self.rank].contiguous()
+        out = []
+        for j in range(P):
+            g = got[:, j]                                                          # [world, B, k, E]
+            Dq = g[..., 0].contiguous().view(torch.float32)
+            Iq = g[..., 1:3].contiguous().view(torch.int64).view(w, B, k)
+            if Dq.is_cuda:
+                D, I = ops.topk_merge_parts(Dq, Iq, metric)
+            else:
+                D, I = merge_partials(Dq, Iq, metric)
+            # provenance: ids are unique across shards, so the slot that holds id I[b,j] is the one that supplied it
+            flat_i = Iq.permute(1, 0, 2).reshape(B, w * k)
+            src = (flat_i[:, None, :] == I[:, :, None]).to(torch.int8).argmax(dim=2)           # [B, k]
+            flat_r = g[..., 3:].permute(1, 0, 2, 3).reshape(B, w * k, d)
+            rows = torch.gather(flat_r, 1, src[:, :, None].expand(B, k, d)).contiguous().view(torch.float32)
+            rows = torch.where((I >= 0)[:, :, None], rows, torch.zeros_like(rows))
+            out.append((D, I, rows))
+        return out
+
 
 class ShardedFlatIndex:
     """Row-sharded index: rank r owns rows shard_bounds(n, world, r).
@@ -388,10 +436,20 @@ class ShardedFlatIndex:
         """Data-parallel form: every rank passes ITS OWN B queries (same B everywhere) and gets (D, I, rows) for them:
         all-gather of the queries, local scan + gather on the shard, all-to-all of the partials with their rows, merge
         and row selection on the owner (`exchange_merge_gather`)."""
-        if self.world == 1:
-            return self.local.search_gather(q_local, k, normalize=normalize)
-        B = q_local.shape[0]
-        allq = [torch.empty_like(q_local) for _ in range(self.world)]
-        self.dist.all_gather(allq, q_local.contiguous(), group=self.group)
-        D_p, I_p, rows_p = self.local.search_gather(torch.cat(allq), k, normalize=normalize)
-        return exchange_merge_gather(D_p, I_p, rows_p, B, self.local.metric, self.group)
+        return ShardedFlatIndex.search_gather_many([self], q_local, k, normalize=normalize)[0]
+
+    @staticmethod
+    def search_gather_many(indices, q_local: torch.Tensor, k: int, normalize: bool = False):
+        """`search_gather` of the SAME queries against several row-sharded databases (the knowledge path searches the image
+        and the text database with one query batch, eval_utils.py:169-183): ONE all-gather of the queries, one local
+        scan + gather per database, ONE all-to-all carrying every database's partial lists with their rows
+        (`PackedExchange.return_partials_rows`).  Returns [(D, I, rows), ...] in the order of `indices`."""
+        first = indices[0]
+        if first.world == 1:
+            return [ix.local.search_gather(q_local, k, normalize=normalize) for ix in indices]
+        if first._xchg is None:
+            first._xchg = PackedExchange(first.group)
+        x = first._xchg
+        allq = x.gather_queries(q_local.to(first.local._dev(), dtype=torch.float32))
+        parts = [ix.local.search_gather(allq, k, normalize=normalize) for ix in indices]
+        return x.return_partials_rows(parts, first.local.metric)

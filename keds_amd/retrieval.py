@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from . import _lib, ops
-from .index import FlatIndex
+from .index import FlatIndex, ShardedFlatIndex
 from .model import CLIP, CrossFormer, IM2TEXT, KnowledgeStream
 
 
@@ -117,6 +117,10 @@ def get_retrieved_features(feature: torch.Tensor, database, args=None, topk: int
     The reference shuffles the image neighbours along K (a numerical no-op for attention over keys);
     here they stay in rank order."""
     image_index, text_index = database[3], database[4]
+    if isinstance(image_index, ShardedFlatIndex) and isinstance(text_index, ShardedFlatIndex):
+        # row-sharded databases: one query all-gather and one packed all-to-all for BOTH databases (SURVEY 8e)
+        (_, _, ti), (_, _, tt) = ShardedFlatIndex.search_gather_many([image_index, text_index], feature, topk, normalize=True)
+        return ti, tt
     _, _, ti = image_index.search_gather(feature, topk, normalize=True)
     _, _, tt = text_index.search_gather(feature, topk, normalize=True)
     return ti, tt

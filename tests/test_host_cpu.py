@@ -220,6 +220,17 @@ def _gloo_worker(rank, world, port, out):
         for _ in range(2):                                        # second round reuses the buffers
             D3, I3 = x.return_partials(dp, ip + lo, _lib.METRIC_L2)
             ok = ok and bool(torch.equal(I3, Ig2) and torch.allclose(D3, Dg2))
+        # the knowledge path's packed form: TWO databases' partial lists and their rows in ONE all-to-all
+        db2 = O.synth_database(3000, 64, seed=19)
+        dp2, ip2 = O.flat_l2_search(db2[lo:hi], qall, 16)
+        rows_p2 = db2[lo:hi][ip2.reshape(-1)].reshape(8, 16, 64)
+        Dg3, Ig3 = O.flat_l2_search(db2, mine_q, 16)
+        for _ in range(2):
+            (D4, I4, R4), (D5, I5, R5) = x.return_partials_rows([(dp, ip + lo, rows_p), (dp2, ip2 + lo, rows_p2)],
+                                                                _lib.METRIC_L2)
+            ok = ok and bool(torch.equal(I4, Ig2) and torch.equal(D4, D2) and torch.equal(R4, R2))
+            ok = ok and bool(torch.equal(I5, Ig3) and torch.allclose(D5, Dg3)
+                             and torch.equal(R5, db2[Ig3.reshape(-1)].reshape(4, 16, 64)))
         # evaluation glue: ragged per-rank gallery slices gathered in rank order, then the metric on the full matrices
         from keds_amd.retrieval import all_gather_features
         gal = O.synth_database(101, 64, seed=12)
@@ -311,3 +322,46 @@ def test_training_negatives_gather_own_rows_first_gloo_world3():
             p.join(120)
         assert all(p.exitcode == 0 for p in procs)
         assert dict(out) == {0: True, 1: True, 2: True}
+
+
+def test_bench_gpus_n_launches_its_own_ranks_before_touching_the_gpu():
+    """`python bench.py --gpus N` is the one command the scaling driver runs: outside torch.distributed.run the parent must
+    start `python -m torch.distributed.run ... bench.py <same args>` as a child (never exec, never after a GPU call) and
+    relay rank 0's JSON line as the last stdout line.  Dry run: the parent prints the argv / env it would start."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["KEDS_BENCH_LAUNCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    plan = json.loads(r.stdout.strip().splitlines()[-1])
+    argv = plan["launch"]
+    assert argv[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in argv and "--nnodes=1" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[-7:] == [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert plan["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the real thing with a stub in place of torch.distributed.run: the child's lines are relayed, the JSON line comes last,
+    # and the exit code is the child's
+    stub = os.path.join(root, "tests", "_stub_site")
+    os.makedirs(os.path.join(stub, "torch", "distributed"), exist_ok=True)
+    try:
+        open(os.path.join(stub, "torch", "__init__.py"), "w").write("")
+        open(os.path.join(stub, "torch", "distributed", "__init__.py"), "w").write("")
+        open(os.path.join(stub, "torch", "distributed", "run.py"), "w").write(
+            "import sys, os\n"
+            "assert '--nproc-per-node=2' in sys.argv and os.environ.get('WORLD_SIZE') is None\n"
+            "print('{\"metric\": \"m\", \"value\": 1}')\n"
+            "print('RCCL banner after the json line')\n"
+            "sys.exit(7)\n")
+        code = ("import sys, os; sys.argv = ['bench.py', '--gpus', '2']; import bench; "
+                "os.environ['PYTHONPATH'] = %r; sys.exit(bench.self_launch(2, ['--gpus', '2']))" % stub)
+        env2 = {k: v for k, v in env.items() if k != "KEDS_BENCH_LAUNCH_DRYRUN"}
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env2, capture_output=True, text=True, timeout=300)
+        lines = r.stdout.strip().splitlines()
+        assert r.returncode == 7 and lines[-1] == '{"metric": "m", "value": 1}' and "RCCL banner" in lines[0], (r.stdout, r.stderr)
+    finally:
+        import shutil
+        shutil.rmtree(stub, ignore_errors=True)
