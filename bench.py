@@ -266,6 +266,10 @@ def main():
     use_dist = world > 1 or os.environ.get("KEDS_BENCH_FORCE_DIST") == "1"   # the latter: 1-rank test of the RCCL path
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1:                                         # forced 1-rank group outside torch.distributed.run
+            for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
+                             ("MASTER_PORT", str(29500 + os.getpid() % 2000))):
+                os.environ.setdefault(key, val)
         dist.init_process_group("nccl", device_id=dev)         # "nccl" is RCCL on ROCm
 
     import keds_amd

@@ -30,7 +30,7 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 4
+#define KEDS_ABI_VERSION 5
 
 int keds_abi_version(void);
 const char* keds_last_error(void);
@@ -120,6 +120,21 @@ int keds_index_search_packed(const void* packed, const float* db, int64_t n, int
  * (multi-GPU: after the all-gather of per-shard results).  Keyed on (D, I). */
 int keds_topk_merge_parts(const float* D_parts, const int64_t* I_parts, int parts, int nq, int k,
                           int metric, float* D, int64_t* I, void* stream);
+
+/* Packed exchange of a data-parallel, row-sharded search (replaces the replicated Faiss index of
+ * src/eval_retrieval.py:289-298 and the two searches of src/eval_utils.py:169-183): every rank searched ITS shard for
+ * the B queries of EVERY rank and holds D_p / I_p [world*B, k] (+ rows_p [world*B, k, dim], the rows of its partial
+ * winners, when the caller needs the neighbours themselves).  keds_exchange_pack writes one message per peer,
+ *   send[w][b][j][E] int32,  E = 3: distance bits | id low | id high;  with rows E = 4 + dim: those, a pad word, the row
+ * (part w at send + w * w_stride words; w_stride >= B*k*E, a multiple of 4 with rows -- several databases share one
+ * buffer by interleaving their parts).  After ONE all-to-all (block w to rank w) keds_exchange_merge turns the received
+ * recv[w][b][j][E] (part w = what shard w found for MY query b) into this rank's D / I [B, k] keyed on (distance, id) --
+ * the order of a single-GPU search of the whole database -- and, with rows != NULL, the winners' rows [B, k, dim].
+ * world <= 64, world * k <= 4096, k <= KEDS_SCAN_MAX_K. */
+int keds_exchange_pack(const float* D_p, const int64_t* I_p, const float* rows_p /* nullable */, int world, int B, int k,
+                       int dim, int64_t w_stride, int32_t* send, void* stream);
+int keds_exchange_merge(const int32_t* recv, int world, int B, int k, int dim, int64_t w_stride, int metric,
+                        float* D, int64_t* I, float* rows /* nullable */, void* stream);
 
 /* out[i,:] = db[idx[i],:]  (idx < 0 gives zeros) */
 int keds_gather_rows(const float* db, int dim, const int64_t* idx, int64_t count, float* out, void* stream);

@@ -85,13 +85,20 @@ int keds_knowledge_forward(keds_knowledge* kn, const float* q, const float* nbr_
 int keds_index_create(keds_ctx* ctx, int dim, int metric /* KEDS_METRIC_* */, int storage /* KEDS_BF16 scan image;
                       the fp32 rows are always kept for the exact re-rank */, keds_index** out);
 int keds_index_destroy(keds_index* idx);
-/* append n fp32 rows (host or device); synchronous (copies + re-packs the scan image) */
+/* append n fp32 rows (host or device): the fp32 rows and the bf16 scan image live in buffers that grow geometrically,
+ * only the new rows are copied and packed (amortised O(rows added)); returns once `rows` may be reused.  A chunked build
+ * gives the same image, byte for byte, as one add of all rows.  Not to be called while a search of the SAME index is in
+ * flight on another stream (Faiss's rule as well). */
 int keds_index_add(keds_index* idx, const float* rows, int64_t n);
 int64_t keds_index_ntotal(const keds_index* idx);
+/* copy of the bf16 scan image (keds_hip.h: keds_index_packed_bytes(ntotal, dim) bytes, host or device destination): what a
+ * host stores next to the fp32 rows so that a later run needs no re-pack (the Python facade's FlatIndex.save does) */
+int keds_index_image(const keds_index* idx, void* packed_out, size_t bytes);
 /* global id of local row 0 (row-sharded databases; default 0) */
 int keds_index_set_base(keds_index* idx, int64_t row0);
 /* q fp32 [B,dim] (device) -> D fp32 [B,k] ascending squared L2 (descending dot for IP), I int64 [B,k],
- * rows_out nullable fp32 [B,k,dim] = the winners' rows (eval_utils.py:171-172).  k <= 16. */
+ * rows_out nullable fp32 [B,k,dim] = the winners' rows (eval_utils.py:171-172).  k <= 128 (KEDS_SCAN_MAX_K): exact, with
+ * a per-query certificate and an exact fp32 pass for the queries that fail it (keds_hip.h). */
 int keds_index_search(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* rows_out,
                       void* stream);
 
@@ -99,11 +106,15 @@ int keds_index_search(keds_index* idx, const void* q, int B, int k, float* D, in
 #define KEDS_COMM_ID_BYTES 128
 int keds_comm_unique_id(void* id_out /* KEDS_COMM_ID_BYTES, host */);          /* rank 0, then broadcast by the host */
 int keds_comm_init(keds_ctx* ctx, int rank, int world, const void* unique_id);
-/* every rank passes its own B queries (same B everywhere) and holds rows [row0, row0+ntotal) of the
- * database: all-gather queries -> local exact search of all B*world queries -> all-gather partial (D,I)
- * -> merge keyed on (D, id) -> this rank's B rows of the global result.  Bit-identical to a
- * single-GPU search of the whole database. */
-int keds_index_search_sharded(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* stream);
+/* Replaces the replicated multi-GPU Faiss index of src/eval_retrieval.py:289-298 and its two searches per query batch
+ * (src/eval_utils.py:169-183).  Every rank passes its own B queries (same B everywhere) and holds rows
+ * [row0, row0+ntotal) of the database: all-gather of the queries -> local exact search of all B*world queries -> ONE
+ * all-to-all of the packed partial lists (distance | id | the winner's row when rows_out != NULL), block w to rank w ->
+ * merge of this rank's B queries keyed on (distance, id).  k <= 128, world * k <= 4096.  D / I (/ rows_out [B,k,dim], the
+ * winners' fp32 rows fetched from the shards that own them) are bit-identical to a single-GPU search of the whole
+ * database. */
+int keds_index_search_sharded(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* rows_out /* nullable */,
+                              void* stream);
 
 /* ---- host-side BPE tokenizer (no GPU) ------------------------------------------------------
  * Replaces `tokenize` of src/third_party/open_clip/clip.py:191-227 with SimpleTokenizer (simple_tokenizer.py:62-132):

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 
 # ---- constants mirrored from keds_hip.h ------------------------------------------------------
-ABI_VERSION = 4
+ABI_VERSION = 5
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
@@ -109,7 +109,8 @@ SIGNATURES = {
     "keds_index_search": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
     "keds_comm_unique_id": (i32, [vp]),
     "keds_comm_init": (i32, [vp, i32, i32, vp]),
-    "keds_index_search_sharded": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "keds_index_image": (i32, [vp, vp, sz]),
+    "keds_index_search_sharded": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
     # ---- keds_hip.h (stateless) -----------------------------------------------------------------
     "keds_abi_version": (i32, []),
     "keds_last_error": (C.c_char_p, []),
@@ -147,6 +148,8 @@ SIGNATURES = {
     "keds_index_search_packed_ex": (i32, [vp, vp, i64, i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, sz, vp, vp]),
     "keds_index_search_packed": (i32, [vp, vp, i64, i32, i32, vp, i32, i32, i32, i64, vp, vp, vp, vp, sz, vp]),
     "keds_topk_merge_parts": (i32, [vp, vp, i32, i32, i32, i32, vp, vp, vp]),
+    "keds_exchange_pack": (i32, [vp, vp, vp, i32, i32, i32, i32, i64, vp, vp]),
+    "keds_exchange_merge": (i32, [vp, i32, i32, i32, i32, i64, i32, vp, vp, vp, vp]),
     "keds_gather_rows": (i32, [vp, i32, vp, i64, vp, vp]),
     "keds_rank_gallery_workspace_bytes": (sz, [i32, i32]),
     "keds_rank_gallery": (i32, [vp, i32, vp, i32, i32, vp, vp, sz, vp]),

@@ -401,6 +401,43 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
     }
 }
 
+// KEDS_EPI_RESID_STATS_F16 with the residual tile + bias fed in as the accumulators' INITIAL value (the kernel's prologue
+// loads the lane's 16 residual chunks ahead of the DMA pieces in the in-order vmcnt queue and converts them while K-tile 0
+// is in flight): the accumulator already holds x + b + sum, so the epilogue is round + store + statistics, with no load
+// in it (the 16 dependent residual loads per lane were ~9 k of this epilogue's 14.8 k cycles, round-2 stamps).
+__device__ __forceinline__ void pair_resid_epilogue_acc(f32x4 (&acc)[4][8], void* __restrict__ out, int m0, int n0, int N,
+                                                        int wm, int wn, int g, int c, keds_stat_t* __restrict__ stats,
+                                                        char* __restrict__ red) {
+    const int r0 = 128 * wm + c;
+    char* tile = reinterpret_cast<char*>(out) + ((size_t)m0 * N + n0) * 2;               // wave-uniform
+    const int nl = 64 * wn + 8 * g;
+    f32x2* rw = reinterpret_cast<f32x2*>(red) + wn * 256 + r0;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        float s = 0.f, ss = 0.f;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const f32x4 v0 = acc[2 * p][mi], v1 = acc[2 * p + 1][mi];
+            const f16x8 ov = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+            *reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u) = ov;
+            s += sum8(v0, v1);
+            ss += sum8(v0 * v0, v1 * v1);
+        }
+        s = rows_sum(s);                 // the four lanes (g = 0..3) that share the row hold this wave's 64 columns of it
+        ss = rows_sum(ss);
+        if (stats && g == 0) rw[16 * mi] = f32x2{s, ss};
+    }
+    if (stats) {                                                        // kernel-uniform
+        __syncthreads();
+        const int t = threadIdx.x;
+        if (t < 256) {
+            const f32x2* rr = reinterpret_cast<const f32x2*>(red) + t;
+            const f32x2 a = rr[0], b = rr[256], c2 = rr[512], d = rr[768];
+            keds_stat_add(stats + 2 * (size_t)(m0 + t), (a[0] + b[0]) + (c2[0] + d[0]), (a[1] + b[1]) + (c2[1] + d[1]));
+        }
+    }
+}
+
 template <int N>
 __device__ __forceinline__ void small_wait_barrier() {
     asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
@@ -722,7 +759,8 @@ constexpr int LDS_BYTES = SIDE_OFF + 4096;      // 132 KiB
 // 229 / 228 / 234 (spread / early pairs / all first).  The K-loop does not wait for the last DMA piece.
 // STAMP (diagnostic build of one instantiation, tools/stamp_gemm.py): s_memtime stamps around the prologue, every
 // K-tile's wait and barrier, the loop and the epilogue; aux2 then receives 8 counters per wave instead of its usual role.
-template <int EPI, int STAMP = 0>
+// RP (KEDS_EPI_RESID_STATS_F16 only): residual tile + bias as the accumulators' initial value (pair_resid_epilogue_acc)
+template <int EPI, int STAMP = 0, int RP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int M, int N, int K, int n_tiles,
@@ -790,10 +828,41 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     const int wrow = OP_BYTES + (64 * wn + c) * 128;               // + ni * 2048
 
     f32x4 acc[4][8];
+    constexpr bool RESID_IN = RP != 0 && EPI == KEDS_EPI_RESID_STATS_F16 && STAMP == 0;
+    if constexpr (!RESID_IN) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // RESID_IN: this lane's 16 residual chunks (rows 128 wm + c + 16 mi, columns 64 wn + 8 g + 32 p + 0..7 of the tile) and
+    // its 16 bias values, requested FIRST: vmcnt retires in order, so "everything older than the 16 DMA pieces" below is
+    // exactly these, and their latency overlaps the first K-tile's
+    [[maybe_unused]] u32x4 rres[2][8];
+    [[maybe_unused]] f32x4 rbias[2][2];
+    if constexpr (RESID_IN) {
+        const char* rtile = reinterpret_cast<const char*>(out) + ((size_t)m0 * N + n0) * 2;     // wave-uniform
+        const unsigned roff = ((unsigned)(128 * wm + c) * (unsigned)N + (unsigned)(64 * wn + 8 * g)) * 2u;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const unsigned o = roff + ((unsigned)(16 * mi) * (unsigned)N + 32u * p) * 2u;
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rres[p][mi]) : "v"(o), "s"(rtile) : "memory");
+            }
+        if (bias) {                                                                           // kernel-uniform
+            const float* btile = bias + n0;
+            const unsigned boff = (unsigned)(64 * wn + 8 * g) * 4u;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rbias[p][0]) : "v"(boff + 128u * p), "s"(btile) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(rbias[p][1]) : "v"(boff + 128u * p + 16u), "s"(btile) : "memory");
+            }
+        } else {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) rbias[p][0] = rbias[p][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     const int np = K / TK;                                         // >= 2
     // LN epilogues: one row's statistics (threads 0-255) or one column's bias' / column sum (threads 256-511) per thread,
@@ -813,7 +882,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
             asm volatile("global_load_dword %0, %1, off" : "=v"(pc) : "v"(cp) : "memory");
         }
     }
-    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16 && !RESID_IN) {
         if (tid >= 256 && bias) {
             const float* bp = bias + n0 + tid - 256;
             asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
@@ -824,7 +893,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     for (int q = 0; q < 8; ++q) issue(0, q);
 #pragma unroll
     for (int q = 0; q < 8; ++q) issue(1, q);
-    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pb)::"memory");
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16 && !RESID_IN) asm volatile("s_waitcnt vmcnt(16)" : "+v"(pb)::"memory");
+    if constexpr (RESID_IN) {
+        // everything older than the 16 DMA pieces has landed: x + b becomes the accumulators' initial value while K-tile 0
+        // (requested above) is still in flight
+        asm volatile("s_waitcnt vmcnt(16)"
+                     : "+v"(rres[0][0]), "+v"(rres[0][1]), "+v"(rres[0][2]), "+v"(rres[0][3]), "+v"(rres[0][4]), "+v"(rres[0][5]),
+                       "+v"(rres[0][6]), "+v"(rres[0][7]), "+v"(rres[1][0]), "+v"(rres[1][1]), "+v"(rres[1][2]), "+v"(rres[1][3]),
+                       "+v"(rres[1][4]), "+v"(rres[1][5]), "+v"(rres[1][6]), "+v"(rres[1][7]), "+v"(rbias[0][0]), "+v"(rbias[0][1]),
+                       "+v"(rbias[1][0]), "+v"(rbias[1][1])
+                     :
+                     : "memory");
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) {
+                const f16x8 q = __builtin_bit_cast(f16x8, rres[p][mi]);
+                acc[2 * p][mi] = f32x4{(float)q[0], (float)q[1], (float)q[2], (float)q[3]} + rbias[p][0];
+                acc[2 * p + 1][mi] = f32x4{(float)q[4], (float)q[5], (float)q[6], (float)q[7]} + rbias[p][1];
+            }
+    }
     if constexpr (epi_is_ln(EPI)) {
         // everything older than the 16 DMA pieces has landed
         asm volatile("s_waitcnt vmcnt(16)" : "+v"(st_raw), "+v"(pb), "+v"(pc)::"memory");
@@ -844,9 +932,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
             *reinterpret_cast<float*>(smem + SIDE_OFF + 3072 + (tid - 256) * 4) = pc;
         }
     }
-    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {            // bias slice of the tile (zeros without a bias) -> side area
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16 && !RESID_IN) {   // bias slice of the tile (zeros without a bias) -> side area
         if (tid >= 256) *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + (tid - 256) * 4) = pb;
     }
+    if constexpr (RESID_IN) __builtin_amdgcn_sched_barrier(0);    // the conversions above stay in front of the wait for K-tile 0
     asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     unsigned long long t_loop0 = 0;
     if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
@@ -950,6 +1039,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     }
     if constexpr (epi_is_ln(EPI))
         pair_ln_epilogue<EPI, 0>(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c, aux2);
+    else if constexpr (RESID_IN)
+        pair_resid_epilogue_acc(acc, out, m0, n0, N, wm, wn, g, c, reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)),
+                                smem + (np & 1) * PBUF_BYTES);
     else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)
         pair_resid_epilogue(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c,
                             reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)), smem + (np & 1) * PBUF_BYTES);
@@ -1003,6 +1095,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // chip can power, not by its schedule: idle cycles removed come back as clock.  Not kept.
 
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
+// fp16-residual GEMMs: residual + bias as the accumulators' initial value instead of 16 loads per lane in the epilogue (round 3,
+// asked for by the round-2 review).  Built, bit-compatible within the fp32 addition order, and SLOWER in a same-process
+// interleaved A/B (tools/ab_resid_prologue.py, 7 rounds x 20 launches, medians): out-proj 75.5 vs 73.0 us, c_proj 232.4 vs
+// 229.0 us -- the 20 extra loads per lane in front of the first K-tile's DMA pieces delay the K-loop's start by more than the
+// epilogue saves (the loads themselves were never the epilogue's cost: round-2 note above).  Off; bit 10 of
+// keds_gemm_force_small's argument turns it on for an A/B.
+int g_resid_prologue = 0;
 int g_pair_stamp = 0;     // diagnostic: stamped build of the qkv instantiation (aux2 = stamp buffer)
 
 template <int EPI>
@@ -1030,6 +1129,14 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         }
     }
     const int m_tiles = M / pr::TM, n_tiles = N / pr::TN;         // M is a multiple of 256 here
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        if (g_resid_prologue) {
+            if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI, 0, 1>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
+            gemm_bt_pair_kernel<EPI, 0, 1><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>(
+                (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles, aux, aux_i, aux2, keds_numerics_guard());
+            return keds_check_launch("gemm_bt_pair_kernel");
+        }
+    }
     gemm_bt_pair_kernel<EPI><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
                                                                             M, N, K, n_tiles, aux, aux_i, aux2,
                                                                             keds_numerics_guard());
@@ -1087,6 +1194,7 @@ extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
+    g_resid_prologue = (on >> 10) & 1;  // bit 10: fp16-residual GEMMs take residual + bias as the accumulators' initial value (A/B)
     g_pair_stamp = (on >> 12) & 7;      // bits 12-14: stamped diagnostic build of the qkv / residual GEMMs (2: no statistics loads, 3: no stores, 4: no atomics, 5: no residual traffic at all)
     return KEDS_OK;
 }

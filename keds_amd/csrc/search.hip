@@ -1278,6 +1278,138 @@ extern "C" int keds_topk_merge_parts(const float* D_parts, const int64_t* I_part
     return keds_check_launch("merge_parts_kernel");
 }
 
+// ---- packed exchange of a row-sharded search: one message per peer ----------------------------------
+// A partial list entry travels as E = 3 int32 words: distance bits | id low | id high -- or, with the winner's fp32 row,
+// E = 4 + dim: the same three, one pad word (rows stay 16-byte aligned), the row.
+// send[w][b][j][E] (part w starts at w * w_stride words) = this shard's list entry j for query b of rank w.
+__global__ __launch_bounds__(256) void exchange_pack_kernel(const float* __restrict__ Dp, const long long* __restrict__ Ip,
+                                                            const float* __restrict__ Rp, int B, int k, int dim, int E,
+                                                            long long w_stride, int* __restrict__ send) {
+    const int list = blockIdx.x;                                  // w * B + b
+    const int w = list / B, b = list - w * B;
+    int* dst = send + (size_t)w * w_stride + (size_t)b * k * E;
+    const float* d = Dp + (size_t)list * k;
+    const long long* ids = Ip + (size_t)list * k;
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+        const long long id = ids[j];
+        dst[(size_t)j * E + 0] = __float_as_int(d[j]);
+        dst[(size_t)j * E + 1] = (int)(unsigned)(id & 0xFFFFFFFFll);
+        dst[(size_t)j * E + 2] = (int)(id >> 32);
+    }
+    if (Rp) {
+        const f32x4* r = reinterpret_cast<const f32x4*>(Rp + (size_t)list * k * dim);
+        const int per = dim >> 2;
+        for (int i = threadIdx.x; i < k * per; i += blockDim.x) {
+            const int j = i / per, c = i - j * per;
+            *reinterpret_cast<f32x4*>(dst + (size_t)j * E + 4 + 4 * c) = r[i];
+        }
+        for (int j = threadIdx.x; j < k; j += blockDim.x) dst[(size_t)j * E + 3] = 0;
+    }
+}
+
+constexpr int XCHG_MAX_ENTRIES = 4096;                            // world * k entries of one query in LDS
+
+__device__ __forceinline__ unsigned ordered_key(float v) {      // unsigned order == float order (-0 folded into +0)
+    const unsigned u = __float_as_uint(v + 0.0f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// recv[w][b][j][E] (part w = what shard w found for MY query b) -> the k best keyed on (distance, id) + their rows.
+// Every list is sorted by (key, id) with its invalid entries (id < 0) at the tail, and ids are unique across shards, so an
+// entry's place in the merged order is its own position + the number of smaller entries in every other list (binary search).
+__global__ __launch_bounds__(256) void exchange_merge_kernel(const int* __restrict__ recv, int world, int B, int k, int E,
+                                                             long long w_stride, int metric, float* __restrict__ D,
+                                                             long long* __restrict__ I, float* __restrict__ rows, int dim) {
+    __shared__ unsigned keys[XCHG_MAX_ENTRIES];
+    __shared__ long long ids[XCHG_MAX_ENTRIES];
+    __shared__ int nvalid[64];
+    __shared__ int src[KEDS_SCAN_MAX_K];
+    __shared__ int total;
+    const int b = blockIdx.x, t = threadIdx.x, n = world * k;
+    if (t < world) nvalid[t] = 0;
+    if (t == 0) total = 0;
+    for (int r = t; r < k; r += blockDim.x) src[r] = -1;
+    __syncthreads();
+    for (int e = t; e < n; e += blockDim.x) {
+        const int w = e / k, j = e - w * k;
+        const int* p = recv + (size_t)w * w_stride + ((size_t)b * k + j) * E;
+        const float d = __int_as_float(p[0]);
+        const long long id = ((long long)p[2] << 32) | (unsigned)p[1];
+        keys[e] = ordered_key(metric == KEDS_METRIC_L2 ? d : -d);
+        ids[e] = id;
+        if (id >= 0) atomicAdd(&nvalid[w], 1);
+    }
+    __syncthreads();
+    for (int e = t; e < n; e += blockDim.x) {
+        const int w = e / k, j = e - w * k;
+        if (j >= nvalid[w]) continue;
+        const unsigned key = keys[e];
+        const long long id = ids[e];
+        int rank = j;
+        for (int o = 0; o < world; ++o) {
+            if (o == w) continue;
+            int lo = 0, hi = nvalid[o];                           // first entry of list o that is NOT smaller than (key, id)
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                const unsigned km = keys[o * k + mid];
+                if (km < key || (km == key && ids[o * k + mid] < id)) lo = mid + 1;
+                else hi = mid;
+            }
+            rank += lo;
+        }
+        if (rank < k) {
+            const int* p = recv + (size_t)w * w_stride + ((size_t)b * k + j) * E;
+            D[(size_t)b * k + rank] = __int_as_float(p[0]);
+            I[(size_t)b * k + rank] = id;
+            src[rank] = e;
+        }
+        if (j == 0) atomicAdd(&total, nvalid[w]);
+    }
+    __syncthreads();
+    for (int r = total + t; r < k; r += blockDim.x) {           // fewer than k valid entries in all shards together
+        D[(size_t)b * k + r] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+        I[(size_t)b * k + r] = -1;
+    }
+    if (rows) {
+        const int per = dim >> 2;
+        for (int i = t; i < k * per; i += blockDim.x) {
+            const int r = i / per, c = i - r * per;
+            const int e = src[r];
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e >= 0) {
+                const int w = e / k, j = e - w * k;
+                v = *reinterpret_cast<const f32x4*>(recv + (size_t)w * w_stride + ((size_t)b * k + j) * E + 4 + 4 * c);
+            }
+            *reinterpret_cast<f32x4*>(rows + ((size_t)b * k + r) * dim + 4 * c) = v;
+        }
+    }
+}
+
+extern "C" int keds_exchange_pack(const float* D_p, const int64_t* I_p, const float* rows_p, int world, int B, int k, int dim,
+                                  int64_t w_stride, int32_t* send, void* stream) {
+    KEDS_REQUIRE(D_p && I_p && send && world >= 1 && B > 0 && k > 0, "keds_exchange_pack: bad argument");
+    KEDS_REQUIRE(!rows_p || (dim > 0 && dim % 4 == 0), "keds_exchange_pack: rows need dim %% 4 == 0");
+    const int E = rows_p ? dim + 4 : 3;
+    KEDS_REQUIRE(w_stride >= (int64_t)B * k * E && (!rows_p || w_stride % 4 == 0), "keds_exchange_pack: bad w_stride");
+    exchange_pack_kernel<<<world * B, 256, 0, (hipStream_t)stream>>>(D_p, (const long long*)I_p, rows_p, B, k, dim, E,
+                                                                    (long long)w_stride, send);
+    return keds_check_launch("exchange_pack_kernel");
+}
+
+extern "C" int keds_exchange_merge(const int32_t* recv, int world, int B, int k, int dim, int64_t w_stride, int metric,
+                                   float* D, int64_t* I, float* rows, void* stream) {
+    KEDS_REQUIRE(recv && D && I && world >= 1 && world <= 64 && B > 0 && k > 0 && k <= KEDS_SCAN_MAX_K,
+                 "keds_exchange_merge: bad argument");
+    KEDS_REQUIRE((long)world * k <= XCHG_MAX_ENTRIES, "keds_exchange_merge: world * k = %ld exceeds %d", (long)world * k,
+                 XCHG_MAX_ENTRIES);
+    KEDS_REQUIRE(!rows || (dim > 0 && dim % 4 == 0), "keds_exchange_merge: rows need dim %% 4 == 0");
+    const int E = rows ? dim + 4 : 3;
+    KEDS_REQUIRE(w_stride >= (int64_t)B * k * E && (!rows || (w_stride % 4 == 0)), "keds_exchange_merge: bad w_stride");
+    exchange_merge_kernel<<<B, 256, 0, (hipStream_t)stream>>>(recv, world, B, k, E, (long long)w_stride, metric, D,
+                                                             (long long*)I, rows, dim);
+    return keds_check_launch("exchange_merge_kernel");
+}
+
 extern "C" int keds_gather_rows(const float* db, int dim, const int64_t* idx, int64_t count, float* out,
                                 void* stream) {
     KEDS_REQUIRE(db && idx && out && count > 0, "keds_gather_rows: bad argument");

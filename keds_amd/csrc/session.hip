@@ -259,6 +259,11 @@ struct Rccl {
     int (*CommInitRank)(void**, int, CommId, int) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+    int (*AllToAll)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;      // RCCL extension (optional)
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl g_rccl;
@@ -279,8 +284,15 @@ int rccl_load() {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
     r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+    r.AllToAll = (decltype(r.AllToAll))dlsym(h, "ncclAllToAll");
+    r.Send = (decltype(r.Send))dlsym(h, "ncclSend");
+    r.Recv = (decltype(r.Recv))dlsym(h, "ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))dlsym(h, "ncclGroupStart");
+    r.GroupEnd = (decltype(r.GroupEnd))dlsym(h, "ncclGroupEnd");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
     KEDS_REQUIRE(r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather, "keds_comm: librccl lacks a symbol");
+    KEDS_REQUIRE(r.AllToAll || (r.Send && r.Recv && r.GroupStart && r.GroupEnd),
+                 "keds_comm: librccl has neither ncclAllToAll nor ncclSend / ncclRecv");
     g_rccl = r;
     return KEDS_OK;
 }
@@ -332,7 +344,7 @@ struct keds_index {
     keds_ctx* ctx;
     int device = 0;            // copied from the context: destroy must not touch a context that may already be gone
     int dim, metric;
-    int64_t n = 0, row0 = 0;
+    int64_t n = 0, row0 = 0, cap = 0;     // cap: rows the two buffers below are sized for (grows geometrically)
     float* rows = nullptr;
     void* packed = nullptr;
     GrowBuf ws, xws;
@@ -726,40 +738,57 @@ extern "C" int keds_index_set_base(keds_index* idx, int64_t row0) {
 }
 
 extern "C" int keds_index_add(keds_index* idx, const float* rows, int64_t n) {
+    // Appends in place (the Python facade's FlatIndex.add does the same): the fp32 rows and the scan image live in buffers
+    // that grow geometrically, only the new rows are copied and only the new 32-row stages are packed
+    // (keds_index_pack_append) -- amortised O(rows added), where round 2 re-allocated, re-copied and re-packed the whole
+    // database and synchronised the device twice on every call (O(N^2) over a chunked build).  Work is enqueued on the
+    // null stream; the call returns once the caller's `rows` have been consumed (pageable host copies are synchronous,
+    // device sources are waited for with one stream synchronisation).
     const char* what = "keds_index_add";
     KEDS_REQUIRE(idx && rows && n > 0, "%s: bad argument", what);
     int rc = use_device(idx->ctx, what);
     if (rc) return rc;
-    HIP_TRY(hipDeviceSynchronize(), what);          // searches in flight still read the old buffers
     const int64_t total = idx->n + n;
     const size_t row_bytes = (size_t)idx->dim * sizeof(float);
-    float* grown = nullptr;
-    HIP_TRY(hipMalloc((void**)&grown, (size_t)total * row_bytes), what);
-    hipError_t e = hipSuccess;
-    if (idx->n) e = hipMemcpy(grown, idx->rows, (size_t)idx->n * row_bytes, hipMemcpyDeviceToDevice);
-    if (e == hipSuccess) e = hipMemcpy(grown + (size_t)idx->n * idx->dim, rows, (size_t)n * row_bytes, hipMemcpyDefault);
-    void* packed = nullptr;
-    if (e == hipSuccess) e = hipMalloc(&packed, keds_index_packed_bytes(total, idx->dim));
-    if (e != hipSuccess) {
-        (void)hipFree(grown);
-        keds_set_error("%s: %s", what, hipGetErrorString(e));
-        return KEDS_E_LAUNCH;
+    if (total > idx->cap) {
+        // growth (log N times over a build): new buffers, the old rows and image stages copied across; hipFree of the old
+        // pair waits for the searches still reading them
+        const int64_t cap = total > 2 * idx->cap ? total : 2 * idx->cap;
+        float* grown = nullptr;
+        void* packed = nullptr;
+        HIP_TRY(hipMalloc((void**)&grown, (size_t)cap * row_bytes), what);
+        hipError_t e = hipMalloc(&packed, keds_index_packed_bytes(cap, idx->dim));
+        if (e == hipSuccess && idx->n)
+            e = hipMemcpyAsync(grown, idx->rows, (size_t)idx->n * row_bytes, hipMemcpyDeviceToDevice, nullptr);
+        if (e == hipSuccess && idx->n)       // whole stages of the old image; the stage idx->n falls into is rewritten below
+            e = hipMemcpyAsync(packed, idx->packed, keds_index_packed_bytes(idx->n, idx->dim), hipMemcpyDeviceToDevice, nullptr);
+        if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+        if (e != hipSuccess) {
+            (void)hipFree(grown);
+            if (packed) (void)hipFree(packed);
+            keds_set_error("%s: %s", what, hipGetErrorString(e));
+            return KEDS_E_LAUNCH;
+        }
+        if (idx->rows) (void)hipFree(idx->rows);
+        if (idx->packed) (void)hipFree(idx->packed);
+        idx->rows = grown;
+        idx->packed = packed;
+        idx->cap = cap;
     }
-    rc = keds_index_pack(grown, total, idx->dim, idx->metric, packed, nullptr);
-    if (rc == KEDS_OK && hipDeviceSynchronize() != hipSuccess) {
-        keds_set_error("%s: packing failed", what);
-        rc = KEDS_E_LAUNCH;
-    }
-    if (rc) {
-        (void)hipFree(grown);
-        (void)hipFree(packed);
-        return rc;
-    }
-    if (idx->rows) (void)hipFree(idx->rows);
-    if (idx->packed) (void)hipFree(idx->packed);
-    idx->rows = grown;
-    idx->packed = packed;
+    HIP_TRY(hipMemcpyAsync(idx->rows + (size_t)idx->n * idx->dim, rows, (size_t)n * row_bytes, hipMemcpyDefault, nullptr), what);
+    if ((rc = keds_index_pack_append(idx->rows, idx->n, total, idx->dim, idx->metric, idx->packed, nullptr))) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr), what);       // `rows` may be reused by the caller; the image is complete
     idx->n = total;
+    return KEDS_OK;
+}
+
+extern "C" int keds_index_image(const keds_index* idx, void* packed_out, size_t bytes) {
+    const char* what = "keds_index_image";
+    KEDS_REQUIRE(idx && packed_out, "%s: bad argument", what);
+    KEDS_REQUIRE(idx->n > 0, "%s: the index is empty", what);
+    KEDS_REQUIRE(bytes >= keds_index_packed_bytes(idx->n, idx->dim), "%s: buffer smaller than keds_index_packed_bytes(ntotal, dim)", what);
+    HIP_TRY(hipSetDevice(idx->device), what);
+    HIP_TRY(hipMemcpy(packed_out, idx->packed, keds_index_packed_bytes(idx->n, idx->dim), hipMemcpyDefault), what);
     return KEDS_OK;
 }
 
@@ -809,37 +838,53 @@ extern "C" int keds_comm_init(keds_ctx* ctx, int rank, int world, const void* un
     return KEDS_OK;
 }
 
-extern "C" int keds_index_search_sharded(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* stream) {
+extern "C" int keds_index_search_sharded(keds_index* idx, const void* q, int B, int k, float* D, int64_t* I, void* rows_out,
+                                         void* stream) {
+    // all-gather of the queries -> local exact search (+ row gather) of all B*world queries -> ONE all-to-all of the packed
+    // partial lists (keds_exchange_pack: block w = what this shard found for rank w's queries, with the winners' rows when
+    // rows_out is given: SURVEY 8e option B) -> merge of this rank's B queries keyed on (distance, id) (keds_exchange_merge).
+    // Two collectives and k <= KEDS_SCAN_MAX_K, like the torch-hosted PackedExchange (round 2: three all-gathers, every
+    // rank merged every query, k <= 16, no rows).
     const char* what = "keds_index_search_sharded";
-    KEDS_REQUIRE(idx && q && D && I && B > 0 && k >= 1 && k <= KEDS_SCAN_LIST, "%s: bad argument", what);
+    KEDS_REQUIRE(idx && q && D && I && B > 0 && k >= 1 && k <= KEDS_SCAN_MAX_K, "%s: bad argument", what);
     keds_ctx* ctx = idx->ctx;
     hipStream_t st = (hipStream_t)stream;
     const int W = ctx->world;
-    if (W == 1 && !ctx->comm) return index_search_local(idx, (const float*)q, B, k, D, I, nullptr, st, what);
+    if (W == 1 && !ctx->comm) return index_search_local(idx, (const float*)q, B, k, D, I, (float*)rows_out, st, what);
     KEDS_REQUIRE(ctx->comm != nullptr, "%s: call keds_comm_init first", what);
-    const int nq = B * W;
-    // exchange buffers: q_all [nq,dim] f32 | Dp [nq,k] f32 | Ip [nq,k] i64 | Dg [W,nq,k] | Ig [W,nq,k] | Dm | Im
-    const size_t qb = keds_align_up((size_t)nq * idx->dim * 4, 256), db = keds_align_up((size_t)nq * k * 4, 256),
-                 ib = keds_align_up((size_t)nq * k * 8, 256);
-    int rc = idx->xws.reserve(qb + 2 * (db + ib) + (size_t)W * (db + ib), st, what);
+    KEDS_REQUIRE((long)W * k <= 4096, "%s: world * k = %ld exceeds 4096", what, (long)W * k);
+    const int nq = B * W, dim = idx->dim;
+    const int E = rows_out ? dim + 4 : 3;
+    const size_t part = (size_t)B * k * E;                                   // int32 words per peer
+    // exchange buffers: q_all [nq,dim] f32 | Dp [nq,k] f32 | Ip [nq,k] i64 | Rp [nq,k,dim] f32 | send [W][part] | recv [W][part]
+    const size_t qb = keds_align_up((size_t)nq * dim * 4, 256), db = keds_align_up((size_t)nq * k * 4, 256),
+                 ib = keds_align_up((size_t)nq * k * 8, 256), rb = rows_out ? keds_align_up((size_t)nq * k * dim * 4, 256) : 0,
+                 xb = keds_align_up((size_t)W * part * 4, 256);
+    int rc = idx->xws.reserve(qb + db + ib + rb + 2 * xb, st, what);
     if (rc) return rc;
     char* p = (char*)idx->xws.p;
     float* q_all = (float*)p;
     float* Dp = (float*)(p + qb);
     int64_t* Ip = (int64_t*)(p + qb + db);
-    float* Dm = (float*)(p + qb + db + ib);
-    int64_t* Im = (int64_t*)(p + qb + 2 * db + ib);
-    char* g = p + qb + 2 * (db + ib);
-    float* Dg = (float*)g;
-    int64_t* Ig = (int64_t*)(g + (size_t)W * db);
-    const size_t dpart = (size_t)nq * k * 4, ipart = (size_t)nq * k * 8;
-    if ((rc = rccl_check(g_rccl.AllGather(q, q_all, (size_t)B * idx->dim * 4, /*ncclInt8*/ 0, ctx->comm, st), what))) return rc;
-    if ((rc = index_search_local(idx, q_all, nq, k, Dp, Ip, nullptr, st, what))) return rc;
-    // the gathered parts must be dense [W, nq, k]: gather with the exact part size (no padding between ranks)
-    if ((rc = rccl_check(g_rccl.AllGather(Dp, Dg, dpart, 0, ctx->comm, st), what))) return rc;
-    if ((rc = rccl_check(g_rccl.AllGather(Ip, Ig, ipart, 0, ctx->comm, st), what))) return rc;
-    if ((rc = keds_topk_merge_parts(Dg, Ig, W, nq, k, idx->metric, Dm, Im, stream))) return rc;
-    HIP_TRY(hipMemcpyAsync(D, Dm + (size_t)ctx->rank * B * k, (size_t)B * k * 4, hipMemcpyDeviceToDevice, st), what);
-    HIP_TRY(hipMemcpyAsync(I, Im + (size_t)ctx->rank * B * k, (size_t)B * k * 8, hipMemcpyDeviceToDevice, st), what);
-    return KEDS_OK;
+    float* Rp = rows_out ? (float*)(p + qb + db + ib) : nullptr;
+    int32_t* send = (int32_t*)(p + qb + db + ib + rb);
+    int32_t* recv = (int32_t*)(p + qb + db + ib + rb + xb);
+    if ((rc = rccl_check(g_rccl.AllGather(q, q_all, (size_t)B * dim * 4, /*ncclInt8*/ 0, ctx->comm, st), what))) return rc;
+    if ((rc = index_search_local(idx, q_all, nq, k, Dp, Ip, Rp, st, what))) return rc;
+    if ((rc = keds_exchange_pack(Dp, Ip, Rp, W, B, k, dim, (int64_t)part, send, stream))) return rc;
+    if (g_rccl.AllToAll) {
+        if ((rc = rccl_check(g_rccl.AllToAll(send, recv, part, /*ncclInt32*/ 2, ctx->comm, st), what))) return rc;
+    } else {
+        if ((rc = rccl_check(g_rccl.GroupStart(), what))) return rc;
+        for (int w = 0; w < W; ++w) {
+            int e1 = g_rccl.Send(send + (size_t)w * part, part, 2, w, ctx->comm, st);
+            int e2 = g_rccl.Recv(recv + (size_t)w * part, part, 2, w, ctx->comm, st);
+            if (e1 || e2) {
+                (void)g_rccl.GroupEnd();
+                return rccl_check(e1 ? e1 : e2, what);
+            }
+        }
+        if ((rc = rccl_check(g_rccl.GroupEnd(), what))) return rc;
+    }
+    return keds_exchange_merge(recv, W, B, k, dim, (int64_t)part, idx->metric, D, I, (float*)rows_out, stream);
 }

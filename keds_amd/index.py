@@ -318,26 +318,26 @@ class PackedExchange:
             self._pin = torch.empty(shape, dtype=torch.int32, device=D_p.device)
             self._pout = torch.empty(shape, dtype=torch.int32, device=D_p.device)
         pin = self._pin
-        pin[..., 0] = D_p.contiguous().view(torch.int32).view(w, B, k)
-        pin[..., 1:] = I_p.contiguous().view(torch.int32).view(w, B, k, 2)
-        if D_p.is_cuda:
+        if D_p.is_cuda:                                           # pack kernel -> all-to-all -> merge kernel: 3 launches
+            ops.exchange_pack(D_p.contiguous(), I_p.contiguous(), None, w, pin, B * k * 3)
             self.dist.all_to_all_single(self._pout, pin, group=self.group)       # block r <-> rank r
-            got = self._pout
-        else:
-            every = torch.empty((w * w, B, k, 3), dtype=torch.int32)              # concatenated along dim 0
-            self.dist.all_gather_into_tensor(every, pin, group=self.group)
-            got = every.view(w, w, B, k, 3)[:, self.rank].contiguous()
+            D, I, _ = ops.exchange_merge(self._pout, w, B, k, 0, B * k * 3, metric, False)
+            return D, I
+        pin[..., 0] = D_p.contiguous().view(torch.int32).view(w, B, k)           # CPU tensors: the gloo tests of this logic
+        pin[..., 1:] = I_p.contiguous().view(torch.int32).view(w, B, k, 2)
+        every = torch.empty((w * w, B, k, 3), dtype=torch.int32)                  # concatenated along dim 0
+        self.dist.all_gather_into_tensor(every, pin, group=self.group)
+        got = every.view(w, w, B, k, 3)[:, self.rank].contiguous()
         Dq = got[..., 0].contiguous().view(torch.float32)                          # [world, B, k]: part s = shard s's list
         Iq = got[..., 1:].contiguous().view(torch.int64).view(w, B, k)
-        if Dq.is_cuda:
-            return ops.topk_merge_parts(Dq, Iq, metric)
         return merge_partials(Dq, Iq, metric)
 
     def return_partials_rows(self, parts, metric: int = _lib.METRIC_L2):
         """The knowledge path's form (SURVEY 8e option B): `parts` = [(D_p, I_p, rows_p), ...], one triple per DATABASE
         searched with the same gathered queries (image and text database: two), D_p / I_p [world*B, k] and rows_p
         [world*B, k, d] fp32 (this shard's rows of its partial winners).  ALL of it goes out in ONE all-to-all: per list
-        entry d + 3 int32 words (distance bits | id low | id high | the row), block r to rank r -- so the two databases'
+        entry d + 4 int32 words (distance bits | id low | id high | pad | the row; keds_hip.h, keds_exchange_pack), block r
+        to rank r -- so the two databases'
         partials and their rows share one message (6.3 MB per peer and database at B = 128, k = 16, d = 768) instead of
         the six list-form collectives of round 2.  The owner then merges each database's `world` lists keyed on
         (distance, id) and picks every winner's row from the part that supplied it.
@@ -345,24 +345,26 @@ class PackedExchange:
         w = self.world
         n, k = parts[0][0].shape
         d = parts[0][2].shape[2]
-        B, P, E = n // w, len(parts), d + 3
+        B, P, E = n // w, len(parts), d + 4                       # entry: distance | id low | id high | pad | row
         shape = (w, P, B, k, E)
         dev = parts[0][0].device
         if getattr(self, "_rin", None) is None or self._rin.shape != shape or self._rin.device != dev:
-            self._rin = torch.empty(shape, dtype=torch.int32, device=dev)
+            self._rin = torch.zeros(shape, dtype=torch.int32, device=dev)
             self._rout = torch.empty(shape, dtype=torch.int32, device=dev)
         rin = self._rin
+        if dev.type == "cuda":                                    # pack kernels -> ONE all-to-all -> merge kernels
+            stride = P * B * k * E
+            for j, (D_p, I_p, rows_p) in enumerate(parts):
+                ops.exchange_pack(D_p.contiguous(), I_p.contiguous(), rows_p.contiguous(), w, rin[0, j], stride)
+            self.dist.all_to_all_single(self._rout, rin, group=self.group)       # block r <-> rank r
+            return [ops.exchange_merge(self._rout[0, j], w, B, k, d, stride, metric, True) for j in range(P)]
         for j, (D_p, I_p, rows_p) in enumerate(parts):
             rin[:, j, :, :, 0] = D_p.contiguous().view(torch.int32).view(w, B, k)
             rin[:, j, :, :, 1:3] = I_p.contiguous().view(torch.int32).view(w, B, k, 2)
-            rin[:, j, :, :, 3:] = rows_p.contiguous().view(torch.int32).view(w, B, k, d)
-        if dev.type == "cuda":
-            self.dist.all_to_all_single(self._rout, rin, group=self.group)       # block r <-> rank r
-            got = self._rout
-        else:
-            every = torch.empty((w * w,) + shape[1:], dtype=torch.int32)
-            self.dist.all_gather_into_tensor(every, rin, group=self.group)
-            got = every.view((w, w) + shape[1:])[:, self.rank].contiguous()
+            rin[:, j, :, :, 4:] = rows_p.contiguous().view(torch.int32).view(w, B, k, d)
+        every = torch.empty((w * w,) + shape[1:], dtype=torch.int32)
+        self.dist.all_gather_into_tensor(every, rin, group=self.group)
+        got = every.view((w, w) + shape[1:])[:, self.rank].contiguous()
         out = []
         for j in range(P):
             g = got[:, j]                                                          # [world, B, k, E]
@@ -375,7 +377,7 @@ class PackedExchange:
             # provenance: ids are unique across shards, so the slot that holds id I[b,j] is the one that supplied it
             flat_i = Iq.permute(1, 0, 2).reshape(B, w * k)
             src = (flat_i[:, None, :] == I[:, :, None]).to(torch.int8).argmax(dim=2)           # [B, k]
-            flat_r = g[..., 3:].permute(1, 0, 2, 3).reshape(B, w * k, d)
+            flat_r = g[..., 4:].permute(1, 0, 2, 3).reshape(B, w * k, d)
             rows = torch.gather(flat_r, 1, src[:, :, None].expand(B, k, d)).contiguous().view(torch.float32)
             rows = torch.where((I >= 0)[:, :, None], rows, torch.zeros_like(rows))
             out.append((D, I, rows))

@@ -265,3 +265,23 @@ def topk_merge_parts(D_parts: torch.Tensor, I_parts: torch.Tensor, metric: int):
     check(load().keds_topk_merge_parts(ptr(D_parts), ptr(I_parts),
                                        parts, nq, k, metric, ptr(D), ptr(I), stream()), "keds_topk_merge_parts")
     return D, I
+
+
+def exchange_pack(D_p: torch.Tensor, I_p: torch.Tensor, rows_p: Optional[torch.Tensor], world: int, send: torch.Tensor,
+                  w_stride: int) -> None:
+    """Partial lists (+ rows) of a sharded search -> one int32 message per peer (keds_hip.h, keds_exchange_pack).
+    `send` may be a view into a buffer shared by several databases (w_stride = words between consecutive parts)."""
+    n, k = D_p.shape
+    dim = 0 if rows_p is None else rows_p.shape[2]
+    check(load().keds_exchange_pack(ptr(D_p), ptr(I_p), ptr(rows_p), world, n // world, k, dim, int(w_stride), ptr(send),
+                                    stream()), "keds_exchange_pack")
+
+
+def exchange_merge(recv: torch.Tensor, world: int, B: int, k: int, dim: int, w_stride: int, metric: int, with_rows: bool):
+    """Received parts -> (D [B,k], I [B,k], rows [B,k,dim] or None) keyed on (distance, id) (keds_exchange_merge)."""
+    D = torch.empty((B, k), dtype=torch.float32, device=recv.device)
+    I = torch.empty((B, k), dtype=torch.int64, device=recv.device)
+    rows = torch.empty((B, k, dim), dtype=torch.float32, device=recv.device) if with_rows else None
+    check(load().keds_exchange_merge(ptr(recv), world, B, k, dim if with_rows else 0, int(w_stride), metric, ptr(D), ptr(I),
+                                     ptr(rows), stream()), "keds_exchange_merge")
+    return D, I, rows

@@ -176,15 +176,22 @@ class Index(_Handle):
             raise ValueError(f"expected [n,{self.dim}] rows")
         check(load().keds_index_add(self.h, rows.data_ptr(), rows.shape[0]), "keds_index_add")
 
+    def scan_image(self) -> torch.Tensor:
+        """Copy of the bf16 scan image (uint8 device tensor, keds_index_packed_bytes(ntotal, dim) bytes)."""
+        n = load().keds_index_packed_bytes(self.ntotal, self.dim)
+        out = torch.empty(n, dtype=torch.uint8, device="cuda")
+        check(load().keds_index_image(self.h, ptr(out), n), "keds_index_image")
+        return out
+
     def search(self, q: torch.Tensor, k: int, gather: bool = False, sharded: bool = False):
         q = q.float().contiguous()
         B = q.shape[0]
         D = torch.empty((B, k), dtype=torch.float32, device=q.device)
         I = torch.empty((B, k), dtype=torch.int64, device=q.device)
-        if sharded:
-            check(load().keds_index_search_sharded(self.h, ptr(q), B, k, ptr(D), ptr(I), stream()),
-                  "keds_index_search_sharded")
-            return D, I
         rows = torch.empty((B, k, self.dim), dtype=torch.float32, device=q.device) if gather else None
+        if sharded:
+            check(load().keds_index_search_sharded(self.h, ptr(q), B, k, ptr(D), ptr(I), ptr(rows), stream()),
+                  "keds_index_search_sharded")
+            return (D, I, rows) if gather else (D, I)
         check(load().keds_index_search(self.h, ptr(q), B, k, ptr(D), ptr(I), ptr(rows), stream()), "keds_index_search")
         return (D, I, rows) if gather else (D, I)

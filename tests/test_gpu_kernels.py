@@ -362,7 +362,8 @@ def test_gemm_layernorm_epilogues_equal_layernorm_then_linear(M, N, K, epi, dt):
     assert rel_l2(out[:M], full) <= (5e-3 if f16 else 1.2e-2)       # fp16 operands carry 3 more mantissa bits
 
 
-@pytest.mark.parametrize("M,N,K", [(300, 128, 256), (33024 + 128, 1024, 1024), (128, 1024, 4096), (2000, 768, 3072)])
+@pytest.mark.parametrize("M,N,K", [(300, 128, 256), (33024 + 128, 1024, 1024), (128, 1024, 4096), (2000, 768, 3072),
+                                   (16384 + 64, 1024, 4096)])
 def test_gemm_residual_stats_epilogue_fp16_stream(M, N, K):
     """KEDS_EPI_RESID_STATS_F16: x (fp16, in place) = round(x + a W^T + b) with the sum in fp32, and the per-row
     {sum, sum sq} of the fp32 sums; statistics may be NULL (last block)."""
@@ -392,6 +393,22 @@ def test_gemm_residual_stats_epilogue_fp16_stream(M, N, K):
     _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x2), N, M, N, K,
                                     _lib.EPI_RESID_STATS_F16, None, 0, None, _lib.stream()), "gemm resid f16 2")
     assert torch.equal(x2, x)
+    # A/B variant of the 256^2 kernel (bit 10): x + b fed in as the accumulators' initial value instead of being loaded in
+    # the epilogue -- only the order of the fp32 additions differs: same reference, same tolerance, and a missing bias is
+    # zeros in both
+    lib.keds_gemm_force_small(1 << 10)
+    try:
+        x3 = x0.clone()
+        _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x3), N, M, N, K,
+                                        _lib.EPI_RESID_STATS_F16, None, 0, None, _lib.stream()), "gemm resid f16 3")
+    finally:
+        lib.keds_gemm_force_small(0)
+    assert max_abs(x3[:M].float(), want.half().float()) <= float(want.abs().max()) * 2.0 ** -10
+    assert rel_l2(x3[:M].float(), x[:M].float()) <= 4e-4
+    x4 = x0.clone()
+    _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), None, _lib.ptr(x4), N, M, N, K,
+                                    _lib.EPI_RESID_STATS_F16, None, 0, None, _lib.stream()), "gemm resid f16 4")
+    assert rel_l2(x4[:M].float(), want - b) <= 4e-4
 
 
 @pytest.mark.parametrize("M,N,K", [(300, 128, 256), (33024 + 128, 1024, 1024), (128, 1024, 4096), (2000, 768, 3072)])

@@ -161,9 +161,129 @@ def test_sharded_search_through_rccl_single_rank():
         assert torch.equal(D, D1) and torch.equal(I, I1)
         Do, Io = O.flat_l2_search(db, q.cpu(), 10)
         assert torch.equal(I.cpu(), Io + 1000)
+        # round 3: k up to 128 and the winners' rows shipped with the partial lists (packed all-to-all + owner merge)
+        D3, I3, R3 = idx.search(q, 101, gather=True, sharded=True)
+        D4, I4, R4 = idx.search(q, 101, gather=True)
+        assert torch.equal(D3, D4) and torch.equal(I3, I4) and torch.equal(R3, R4)
+        Do, Io = O.flat_l2_search(db, q.cpu(), 101)
+        assert torch.equal(I3.cpu(), Io + 1000)
+        assert torch.equal(R3.cpu(), db[Io.reshape(-1)].reshape(20, 101, dim))
         idx.close()
     finally:
         c.close()
+
+
+def test_exchange_pack_merge_kernels_emulate_three_shards():
+    """keds_exchange_pack / keds_exchange_merge (the two kernels around the all-to-all of a sharded search) on one GPU: three
+    shards' partial lists for 2 x 3 ranks' queries are packed, the blocks addressed to rank r are laid side by side as the
+    all-to-all would deliver them, and the merge must reproduce the single-index search -- ids, distances, rows, ties on
+    the smaller id, fewer than k valid entries."""
+    from keds_amd import ops
+    from keds_amd.index import shard_bounds
+    n, dim, B, k, W = 3000, 128, 5, 16, 3
+    db = O.synth_database(n, dim, seed=21)
+    db[1500] = db[7]                                             # an exact duplicate on another shard: tie -> smaller id
+    qall = O.synth_database(W * B, dim, seed=22)
+    qall[0] = db[7]
+    whole = keds_amd.FlatIndex(dim)
+    whole.add(db)
+    Dw, Iw, Rw = whole.search_gather(qall.cuda(), k)
+    shards = []
+    for r in range(W):
+        lo, hi = shard_bounds(n, W, r)
+        ix = keds_amd.FlatIndex(dim, row0=lo)
+        ix.add(db[lo:hi])
+        shards.append(ix)
+    for with_rows in (True, False):
+        E = dim + 4 if with_rows else 3
+        sends = []
+        for ix in shards:
+            Dp, Ip, Rp = ix.search_gather(qall.cuda(), k)
+            send = torch.zeros((W, B, k, E), dtype=torch.int32, device="cuda")
+            ops.exchange_pack(Dp, Ip, Rp if with_rows else None, W, send, B * k * E)
+            sends.append(send)
+        for r in range(W):                                       # rank r receives block r of every shard
+            recv = torch.stack([sends[s][r] for s in range(W)]).contiguous()
+            D, I, R = ops.exchange_merge(recv, W, B, k, dim, B * k * E, _lib.METRIC_L2, with_rows)
+            assert torch.equal(I, Iw[r * B:(r + 1) * B]) and torch.equal(D, Dw[r * B:(r + 1) * B])
+            if with_rows:
+                assert torch.equal(R, Rw[r * B:(r + 1) * B])
+    assert Iw[0, 0].item() == 7 and Iw[0, 1].item() == 1500
+    # fewer valid entries than k: a 40-row database split three ways, k = 16 per shard list but only 40 rows in all
+    small = db[:40].clone()
+    parts = []
+    for r in range(W):
+        lo, hi = shard_bounds(40, W, r)
+        if hi > lo:
+            ix = keds_amd.FlatIndex(dim, row0=lo)
+            ix.add(small[lo:hi])
+            parts.append(ix.search_gather(qall[:B].cuda(), 16))
+    Wn = len(parts)
+    recv = torch.zeros((Wn, B, 16, dim + 4), dtype=torch.int32, device="cuda")
+    for j, (Dp, Ip, Rp) in enumerate(parts):
+        ops.exchange_pack(Dp, Ip, Rp, 1, recv[j], B * 16 * (dim + 4))
+    D, I, R = ops.exchange_merge(recv, Wn, B, 16, dim, B * 16 * (dim + 4), _lib.METRIC_L2, True)
+    Do, Io = O.flat_l2_search(small, qall[:B], 16)
+    assert torch.equal(I.cpu(), Io) and max_abs(D, Do) <= 2e-6
+
+
+def test_index_handle_chunked_add_is_byte_identical_to_one_add(ctx):
+    """keds_index_add appends in place (geometric capacity, only the new stages packed): a build in ragged chunks must give
+    the same scan image and the same results, bit for bit, as one add of all rows -- including chunks that end inside a
+    32-row stage and growth steps that move the buffers."""
+    n, dim = 7001, 256
+    db = O.synth_database(n, dim, seed=31)
+    q = O.synth_database(9, dim, seed=32).cuda()
+    one = session.Index(ctx, dim)
+    one.add(db.numpy())
+    many = session.Index(ctx, dim)
+    cuts = [0, 1, 31, 32, 33, 500, 513, 2048, 2049, 4097, 7000, 7001]
+    for a, b in zip(cuts, cuts[1:]):
+        many.add(db[a:b].cuda() if (a % 2) else db[a:b].numpy())
+    assert many.ntotal == one.ntotal == n
+    for k in (1, 16, 101):
+        D1, I1, R1 = one.search(q, k, gather=True)
+        D2, I2, R2 = many.search(q, k, gather=True)
+        assert torch.equal(D1, D2) and torch.equal(I1, I2) and torch.equal(R1, R2)
+    ref = keds_amd.FlatIndex(dim)
+    ref.add(db)
+    img1, img2 = one.scan_image(), many.scan_image()
+    assert torch.equal(img1, img2) and torch.equal(img1, ref.packed)
+    one.close(); many.close()
+
+
+def test_two_threads_two_handles_one_device_share_the_side_lane(tiny):
+    """keds_session.h allows different handles on different threads.  The towers' side lane (remainder-row chain on a second
+    stream) has ONE fork / join event pair per device: record + wait must be atomic per caller, or one thread's wait binds
+    to the other's record and its remainder rows read unfinished data (round-2 advisor finding).  Two threads, two ViT
+    handles, each on its own stream, many passes: every output must equal the single-threaded one."""
+    import threading
+    g, sd, m = tiny
+    c = session.Context(0)
+    vits = [session.Vit(c, {k: v.numpy() for k, v in sd.items()}) for _ in range(2)]
+    rs = np.random.RandomState(5)
+    imgs = [torch.from_numpy(rs.standard_normal((37, 3, 56, 56)).astype(np.float32)).cuda() for _ in range(2)]
+    want = [vits[i].forward(imgs[i]).clone() for i in range(2)]
+    torch.cuda.synchronize()
+    bad = [0, 0]
+
+    def work(i):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for _ in range(60):
+                y = vits[i].forward(imgs[i])
+                st.synchronize()
+                if not torch.equal(y, want[i]):
+                    bad[i] += 1
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert bad == [0, 0]
+    for v in vits:
+        v.close()
+    c.close()
 
 
 def test_handle_lifetimes_and_batch_sequences(tiny):

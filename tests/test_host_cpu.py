@@ -48,7 +48,7 @@ def test_session_abi_fails_loudly_without_a_gpu():
     assert lib.keds_vit_create(None, None, 0, _lib.DT_BF16, C.byref(h)) == -1
     assert lib.keds_index_create(None, 768, 0, _lib.DT_BF16, C.byref(h)) == -1 and "null context" in _lib.last_error()
     assert lib.keds_index_ntotal(None) == -1
-    assert lib.keds_index_search_sharded(None, None, 0, 0, None, None, None) == -1
+    assert lib.keds_index_search_sharded(None, None, 0, 0, None, None, None, None) == -1
 
 
 def test_size_queries_need_no_gpu():
