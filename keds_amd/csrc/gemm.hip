@@ -11,6 +11,8 @@
 // bank-conflict free, and W rows are permuted at staging time so a lane's two n-tiles are adjacent.
 #include "keds_common.h"
 #include <math.h>
+#include <cstdlib>
+#include "gemm_quad_gen.h"
 
 namespace {
 
@@ -338,7 +340,8 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
 // KEDS_EPI_RESID_STATS_F16 in the 256^2 kernel: the same simplifications (every row valid, uniform tile base + 32-bit lane
 // offsets for the read-modify-write of the fp16 stream, bias slice from the LDS side area), all 16 loads of the lane issued
 // before the first is used.
-template <int DBG = 0>   // stamped diagnostic build only: 3 = no stores, 4 = no statistics atomics, 5 = neither (and no loads)
+// REDUCE = false (4-wave kernel: a wave runs this once per 64-column half): leave the partial sums in `red`, the caller adds them
+template <int DBG = 0, bool REDUCE = true>   // DBG, stamped diagnostic build only: 3 = no stores, 4 = no statistics atomics, 5 = neither (and no loads)
 __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const char* __restrict__ side, void* __restrict__ out,
                                                     int m0, int n0, int N, int wm, int wn, int g, int c,
                                                     keds_stat_t* __restrict__ stats, char* __restrict__ red) {
@@ -388,7 +391,7 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
         } else if (stats && g == 0)
             rw[16 * mi] = f32x2{s, ss};
     }
-    if constexpr (DBG != 4 && DBG != 5) {
+    if constexpr (DBG != 4 && DBG != 5 && REDUCE) {
         if (stats) {                                                    // kernel-uniform
             __syncthreads();
             const int t = threadIdx.x;
@@ -814,6 +817,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     const unsigned woff = (unsigned)perm_w(R0) * (unsigned)K * 2u + sch * 16;
     const unsigned rstride = 64u * (unsigned)K * 2u;              // 64 rows further down
     // DMA piece q (0..7: X pieces 0..3 then W pieces 0..3) of K-tile p
+#ifndef KEDS_PAIR_BUFFER_DMA
+#define KEDS_PAIR_BUFFER_DMA 1
+#endif
+#if KEDS_PAIR_BUFFER_DMA
+    // buffer form of the LDS-DMA (round 3): lane offset in ONE loop-invariant VGPR per operand, piece / K-tile offset in an
+    // SGPR -- no vector add per piece (8 per wave and K-tile before) on an issue port that the K-loop saturates
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xt), 0, 0x7FFFFFFF, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wt), 0, 0x7FFFFFFF, 0x00020000);
+    auto issue = [&](int p, int q) {
+        const int i = q & 3;
+        char* dst = smem + (p & 1) * PBUF_BYTES + (q < 4 ? 0 : OP_BYTES) + (wave + 8 * i) * 1024;
+        const unsigned so = i * rstride + (unsigned)p * (TK * 2);
+        if (q < 4)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff, so, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, woff, so, 0, 0);
+    };
+#else
     auto issue = [&](int p, int q) {
         const int i = q & 3;
         const char* src = q < 4 ? xt + (xoff + i * rstride + (unsigned)p * (TK * 2)) : wt + (woff + i * rstride + (unsigned)p * (TK * 2));
@@ -821,6 +842,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
     };
+#endif
     // ---- fragment offsets inside a buffer for K-step kk (0/1) of the tile
     const int f = (c >> 1) & 7;
     const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
@@ -1049,6 +1071,299 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
 }
 
+// ---- 256 x 256 x 64 tiles on FOUR waves (round 3) ---------------------------------------------------------------------
+// The vendor BLAS is 20 % ahead of the 8-wave kernel above on the c_fc / c_proj shapes with a plain epilogue (same box,
+// random data, tools/micro/vendor_gemm.py: fc 1,174 vs 969, proj 1,438 vs 1,199, 8192^3 1,526 vs 1,390 TFLOP/s), and
+// rocprofv3 names what it runs: a 256-thread workgroup per 256 x 256 x 64 tile -- one wave per SIMD, 128 x 128 outputs per
+// wave, 256 accumulators in AGPRs, 16 + 16 fragment registers per K-step.  Per K-tile that is 32 ds_read_b128 per wave
+// (128 KB of LDS reads per workgroup against 192 KB for eight 128 x 64 waves: a fragment feeds 8 MFMAs instead of 4 or 8),
+// no second wave competing for the SIMD's matrix pipe and issue port, and four instead of eight parties at the barrier.
+// Same HBM -> LDS image, staging (LDS-DMA, one counted wait + barrier per K-tile), tile walk and epilogues as the 8-wave
+// kernel: wave (wm, wn2) owns rows [128 wm, +128) x columns [128 wn2, +128) = the 8-wave kernel's wave columns 2 wn2 and
+// 2 wn2 + 1 ("halves" h = 0, 1 below).
+// The 256 accumulators are NOT C++ values: left to the register allocator (MFMA builtin, "+a" pins, physical-register
+// pins -- all three built) they are renamed around the loop's back edge at a cost of 590-1,000 v_accvgpr moves per K-tile,
+// or spilled.  They live in fixed AGPRs that only the literal-register inline asm of gemm_quad_gen.h touches
+// (tools/gen_gemm_quad.py): zero-fill, one asm statement per MFMA (fragments come in as ordinary "v" operands, so the
+// compiler still places the s_waitcnt lgkmcnt for its own ds_reads), read-back per 64-column half for the C++ epilogues.
+// Fragments are fully double-buffered (a ds_read never targets a register an MFMA issued less than a K-step ago reads), and
+// program order IS issue order: a sched_barrier closes every group of four MFMAs + one LDS read (+ one DMA piece).
+// DEEP: the DMA pieces of K-tile p+2 are requested a K-step EARLIER.  A wave reads all 16 fragments of K-step (p, 1) behind
+// the first 16 MFMAs of K-step (p, 0); one more barrier a third of the way through that step says every wave has tile p in
+// registers, its LDS buffer is free, and the 16 pieces of tile p+2 go out under the rest of the step -- 1.35 K-tiles before
+// their wait (a counted vmcnt(16): the pieces of tile p+2 stay in flight) instead of 1.0.  For operands that stream from HBM
+// (c_proj: A is the 268 MB MLP hidden matrix, read once; the 8-wave kernel spends 15 % of that K-loop in vmcnt waits).
+template <int EPI, int DEEP = 0, int STAMP = 0>
+__global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias, void* __restrict__ out,
+                                                              int M, int N, int K, int n_tiles,
+                                                              const float* __restrict__ aux, int aux_i,
+                                                              void* __restrict__ aux2, int* __restrict__ guard) {
+    using namespace pr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] unsigned long long t_entry = 0, t_loop0 = 0;
+    // stamped diagnostic builds 2..8 (timing only, results wrong): STAMP - 1 = bit mask of what the steady-state K-loop leaves
+    // out -- 1: the DMA pieces, 2: the fragment reads, 4: the per-K-tile wait + barrier
+    constexpr int DBG = STAMP > 1 ? STAMP - 1 : 0;
+    if constexpr (STAMP) t_entry = __builtin_amdgcn_s_memtime();
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    const int m_tiles = gridDim.x / n_tiles;
+    if ((m_tiles & 7) == 0 && (n_tiles & 3) == 0) {              // same 8 x 4 supertiles per XCD, m fastest (see above)
+        const int grp = bid >> 5, within = bid & 31;
+        const int grows = m_tiles >> 3;
+        const int gn = grp / grows, gm = grp - gn * grows;
+        tm = gm * 8 + (within & 7);
+        tn = gn * 4 + (within >> 3);
+    } else {
+        tm = bid / n_tiles;
+        tn = bid - tm * n_tiles;
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn2 = wave & 1, wm = wave >> 1;
+    const int g = lane >> 4, c = lane & 15;
+
+    // ---- staging: piece j (8 LDS rows = 1 KiB) of an operand; this wave owns pieces wave + 4 i (rows + 32 i), i < 8
+    const int R0 = 8 * wave + (lane >> 3);                        // 0..31
+    const int sch = (lane & 7) ^ swz_f(R0);                        // swz_f(R0 + 32 i) == swz_f(R0)
+    const char* xt = reinterpret_cast<const char*>(X + (size_t)m0 * K);
+    const char* wt = reinterpret_cast<const char*>(W + (size_t)n0 * K);
+    const unsigned xoff = (unsigned)R0 * (unsigned)K * 2u + sch * 16;
+    const unsigned woff = (unsigned)perm_w(R0) * (unsigned)K * 2u + sch * 16;   // perm_w(R0 + 32 i) == perm_w(R0) + 32 i
+    const unsigned rstride = 32u * (unsigned)K * 2u;              // 32 rows further down
+    // LDS-DMA in its buffer form (`buffer_load_dwordx4 v_lane, s[rsrc], s_off offen lds`): the lane part of the address is
+    // ONE loop-invariant VGPR per operand, the piece / K-tile part a scalar -- no vector add per piece (the global_load_lds
+    // form of the 8-wave kernel spends one v_add per piece: 32 vector-issue slots per K-tile on a SIMD whose issue port is
+    // what the K-loop is bound by, see the stamps in DESIGN.md section 5)
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xt), 0, 0x7FFFFFFF, 0x00020000);
+    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wt), 0, 0x7FFFFFFF, 0x00020000);
+    auto issue = [&](int p, int q) {                               // DMA piece q (0..15: X pieces 0..7, W pieces 0..7) of K-tile p
+        const int i = q & 7;
+        char* dst = smem + (p & 1) * PBUF_BYTES + (q < 8 ? 0 : OP_BYTES) + (wave + 4 * i) * 1024;
+        const unsigned so = i * rstride + (unsigned)p * (TK * 2);
+        if (q < 8)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff, so, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, woff, so, 0, 0);
+    };
+    const int f = (c >> 1) & 7;
+    const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
+    const int xrow = (128 * wm + c) * 128;                         // + mi * 2048
+    const int wrow = OP_BYTES + (128 * wn2 + c) * 128;             // + j * 2048, j = 4 h + ni
+
+    KEDS_QUAD_ZERO_ALL
+
+    const int np = K / TK;                                         // >= 2
+    // LN epilogues: row t's statistics and column t's bias' / column sum per thread, fetched BEFORE the DMA pieces
+    [[maybe_unused]] u32x4 st_raw = u32x4{0, 0, 0, 0};
+    [[maybe_unused]] float pb = 0.f, pc = 0.f;
+    if constexpr (epi_is_ln(EPI)) {
+        const keds_stat_t* sp = reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)(m0 + tid);
+        const float* bp = bias + n0 + tid;
+        const float* cp = bp + N;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st_raw) : "v"(sp) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pc) : "v"(cp) : "memory");
+    }
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        if (bias) {
+            const float* bp = bias + n0 + tid;
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue(0, q);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) issue(1, q);
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        asm volatile("s_waitcnt vmcnt(32)" : "+v"(pb)::"memory");
+        *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + tid * 4) = pb;
+    }
+    if constexpr (epi_is_ln(EPI)) {
+        asm volatile("s_waitcnt vmcnt(32)" : "+v"(st_raw), "+v"(pb), "+v"(pc)::"memory");
+        float rs, nm;
+        ln_coeff_from((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0]),
+                      (keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]), 1.0f / (float)K, rs, nm,
+                      n0 == 0 ? guard : nullptr);
+        *reinterpret_cast<f32x2*>(smem + SIDE_OFF + tid * 8) = f32x2{rs, nm};
+        *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + tid * 4) = pb;
+        *reinterpret_cast<float*>(smem + SIDE_OFF + 3072 + tid * 4) = pc;
+    }
+    asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
+    bf16x8 xa[8], wa[8], xb[8], wb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(smem + wrow + slot0 + j * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(smem + xrow + slot0 + mi * 2048);
+
+    // One K-step: 64 MFMAs from (xc, wc); the 16 fragment reads of the NEXT K-step go to (xn, wn_) from buffer `nb` at chunk
+    // offset `nslot`; with ISSUE the 16 DMA pieces of K-tile `ip` follow.  Group mi = X fragment mi against the eight W
+    // fragments, in two halves of four MFMAs with one LDS read (and one DMA piece) behind each: the wave is alone on its
+    // SIMD, so what stands between two MFMAs issues in the 16 cycles the matrix pipe is busy with the first.
+#define KEDS_QMFMA(j, mi, wc, xc)                                                                              \
+    if constexpr (epi_f16(EPI)) { KEDS_QUAD_MFMA_##j##_##mi("v_mfma_f32_16x16x32_f16", wc[j], xc[mi]) }        \
+    else { KEDS_QUAD_MFMA_##j##_##mi("v_mfma_f32_16x16x32_bf16", wc[j], xc[mi]) }
+// (all 16 fragment reads of the next K-step sit in the FIRST half of the step, two behind each group of four MFMAs: the step
+// that consumes them opens with s_waitcnt lgkmcnt(0), and a read issued four MFMAs before that wait stalls the only wave
+// of the SIMD for its whole LDS latency)
+// group g = eight MFMAs.  KEDS_QUAD_ORDER 0: X fragment g against the eight W fragments (SrcB constant, SrcA cycling);
+// 1: W fragment g against the eight X fragments (SrcA constant over eight MFMAs, the order the vendor's kernel issues in)
+#ifndef KEDS_QUAD_ORDER
+#define KEDS_QUAD_ORDER 1
+#endif
+#if KEDS_QUAD_ORDER == 0
+#define KEDS_QG4A(g_, wc, xc) KEDS_QMFMA(0, g_, wc, xc) KEDS_QMFMA(1, g_, wc, xc) KEDS_QMFMA(2, g_, wc, xc) KEDS_QMFMA(3, g_, wc, xc)
+#define KEDS_QG4B(g_, wc, xc) KEDS_QMFMA(4, g_, wc, xc) KEDS_QMFMA(5, g_, wc, xc) KEDS_QMFMA(6, g_, wc, xc) KEDS_QMFMA(7, g_, wc, xc)
+#else
+#define KEDS_QG4A(g_, wc, xc) KEDS_QMFMA(g_, 0, wc, xc) KEDS_QMFMA(g_, 1, wc, xc) KEDS_QMFMA(g_, 2, wc, xc) KEDS_QMFMA(g_, 3, wc, xc)
+#define KEDS_QG4B(g_, wc, xc) KEDS_QMFMA(g_, 4, wc, xc) KEDS_QMFMA(g_, 5, wc, xc) KEDS_QMFMA(g_, 6, wc, xc) KEDS_QMFMA(g_, 7, wc, xc)
+#endif
+#define KEDS_QUAD_GROUP(mi, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                   \
+    KEDS_QG4A(mi, wc, xc)                                                                                      \
+    if constexpr (PREFETCH && (mi) < 4 && !(DBG & 2)) {                                                        \
+        wn_[2 * (mi)] = *reinterpret_cast<const bf16x8*>((nb) + wrow + (nslot) + (2 * (mi)) * 2048);           \
+        wn_[2 * (mi) + 1] = *reinterpret_cast<const bf16x8*>((nb) + wrow + (nslot) + (2 * (mi) + 1) * 2048);   \
+    }                                                                                                          \
+    if constexpr (ISSUE && !(DBG & 1)) issue((ip), 2 * mi);                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+    KEDS_QG4B(mi, wc, xc)                                                                                      \
+    if constexpr (PREFETCH && (mi) < 4 && !(DBG & 2)) {                                                        \
+        xn[2 * (mi)] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + (2 * (mi)) * 2048);            \
+        xn[2 * (mi) + 1] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + (2 * (mi) + 1) * 2048);    \
+    }                                                                                                          \
+    if constexpr (ISSUE && !(DBG & 1)) issue((ip), 2 * mi + 1);                                                \
+    __builtin_amdgcn_sched_barrier(0);
+#define KEDS_QUAD_STEP(xc, wc, xn, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                                  \
+    {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if constexpr (SYNC && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        KEDS_QUAD_GROUP(0, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+        KEDS_QUAD_GROUP(1, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+        KEDS_QUAD_GROUP(2, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+        KEDS_QUAD_GROUP(3, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+        KEDS_QUAD_GROUP(4, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+        KEDS_QUAD_GROUP(5, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+        KEDS_QUAD_GROUP(6, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+        KEDS_QUAD_GROUP(7, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
+    }
+
+    // DEEP form of K-step (p, 0) with tile p+2 to request: all 16 fragment reads of (p, 1) behind the first 16 MFMAs, eight
+    // plain MFMAs while they return, "buffer free" barrier, then the 16 DMA pieces under the remaining 40 MFMAs.
+#define KEDS_QD_HALF_(ja, jb, jc, jd, mi, xc, wc, R0_, R1_, R2_, R3_)                                          \
+    KEDS_QMFMA(ja, mi, wc, xc) R0_ KEDS_QMFMA(jb, mi, wc, xc) R1_                                              \
+    KEDS_QMFMA(jc, mi, wc, xc) R2_ KEDS_QMFMA(jd, mi, wc, xc) R3_                                              \
+    __builtin_amdgcn_sched_barrier(0);
+#define KEDS_QD_HALF_0(mi, xc, wc, R0_, R1_, R2_, R3_) KEDS_QD_HALF_(0, 1, 2, 3, mi, xc, wc, R0_, R1_, R2_, R3_)
+#define KEDS_QD_HALF_4(mi, xc, wc, R0_, R1_, R2_, R3_) KEDS_QD_HALF_(4, 5, 6, 7, mi, xc, wc, R0_, R1_, R2_, R3_)
+#define KEDS_QD_HALF(j0, mi, xc, wc, R0_, R1_, R2_, R3_) KEDS_QD_HALF_##j0(mi, xc, wc, R0_, R1_, R2_, R3_)
+#define KEDS_QD_RW(j) wb[j] = *reinterpret_cast<const bf16x8*>(cb + wrow + slot1 + (j) * 2048);
+#define KEDS_QD_RX(j) xb[j] = *reinterpret_cast<const bf16x8*>(cb + xrow + slot1 + (j) * 2048);
+#define KEDS_QD_I(q) issue(p + 2, q);
+    int p = 0;
+    for (; p + 2 < np; ++p) {                                      // steady state: tile p+2 exists
+        const char* cb = smem + (p & 1) * PBUF_BYTES;               // buffer of tile p
+        const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;         // buffer of tile p+1
+        if constexpr (DEEP) {
+            __builtin_amdgcn_sched_barrier(0);
+            KEDS_QD_HALF(0, 0, xa, wa, KEDS_QD_RW(0), KEDS_QD_RW(1), KEDS_QD_RW(2), KEDS_QD_RW(3))
+            KEDS_QD_HALF(4, 0, xa, wa, KEDS_QD_RW(4), KEDS_QD_RW(5), KEDS_QD_RW(6), KEDS_QD_RW(7))
+            KEDS_QD_HALF(0, 1, xa, wa, KEDS_QD_RX(0), KEDS_QD_RX(1), KEDS_QD_RX(2), KEDS_QD_RX(3))
+            KEDS_QD_HALF(4, 1, xa, wa, KEDS_QD_RX(4), KEDS_QD_RX(5), KEDS_QD_RX(6), KEDS_QD_RX(7))
+            KEDS_QD_HALF(0, 2, xa, wa, , , , )
+            KEDS_QD_HALF(4, 2, xa, wa, , , , )
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave holds tile p in registers
+            __builtin_amdgcn_sched_barrier(0);
+            KEDS_QD_HALF(0, 3, xa, wa, KEDS_QD_I(0), , KEDS_QD_I(1), )
+            KEDS_QD_HALF(4, 3, xa, wa, KEDS_QD_I(2), , KEDS_QD_I(3), )
+            KEDS_QD_HALF(0, 4, xa, wa, KEDS_QD_I(4), , KEDS_QD_I(5), )
+            KEDS_QD_HALF(4, 4, xa, wa, KEDS_QD_I(6), , KEDS_QD_I(7), )
+            KEDS_QD_HALF(0, 5, xa, wa, KEDS_QD_I(8), , KEDS_QD_I(9), )
+            KEDS_QD_HALF(4, 5, xa, wa, KEDS_QD_I(10), , KEDS_QD_I(11), )
+            KEDS_QD_HALF(0, 6, xa, wa, KEDS_QD_I(12), , , )
+            KEDS_QD_HALF(4, 6, xa, wa, KEDS_QD_I(13), , , )
+            KEDS_QD_HALF(0, 7, xa, wa, KEDS_QD_I(14), , , )
+            KEDS_QD_HALF(4, 7, xa, wa, KEDS_QD_I(15), , , )
+            // K-step (p, 1): tile p+1 has landed for every wave (the 16 pieces of tile p+2 stay in flight)
+            asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+            KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, false, false, 0, true)
+        } else {
+            KEDS_QUAD_STEP(xa, wa, xb, wb, cb, slot1, false, false, 0, true)          // K-step 2p
+            KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, true, true, p + 2, true)       // K-step 2p+1
+        }
+    }
+#undef KEDS_QD_HALF
+#undef KEDS_QD_HALF_
+#undef KEDS_QD_HALF_0
+#undef KEDS_QD_HALF_4
+#undef KEDS_QD_RW
+#undef KEDS_QD_RX
+#undef KEDS_QD_I
+    {                                                              // tile np-2: nothing left to issue
+        const char* cb = smem + (p & 1) * PBUF_BYTES;
+        const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;
+        KEDS_QUAD_STEP(xa, wa, xb, wb, cb, slot1, false, false, 0, true)
+        KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, true, false, 0, true)
+        KEDS_QUAD_STEP(xa, wa, xb, wb, ob, slot1, false, false, 0, true)          // tile np-1
+        KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, false, false, 0, false)
+    }
+#undef KEDS_QUAD_STEP
+#undef KEDS_QUAD_GROUP
+#undef KEDS_QMFMA
+
+    // ---- epilogues: the 8-wave kernel's, once per 64-column half (wave column 2 wn2 + h) read back from its AGPRs
+    [[maybe_unused]] unsigned long long t_loop1 = 0;
+    if constexpr (STAMP) t_loop1 = __builtin_amdgcn_s_memtime();
+    [[maybe_unused]] void* stamp_out = aux2;
+    if constexpr (STAMP) aux2 = nullptr;                              // (stamped build: aux2 carries the stamp buffer)
+    KEDS_QUAD_DRAIN
+    f32x4 av[4][8];
+    [[maybe_unused]] keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
+    [[maybe_unused]] char* red = smem + (np & 1) * PBUF_BYTES;
+#define KEDS_QUAD_EPI(h)                                                                                               \
+    if constexpr (epi_is_ln(EPI))                                                                                      \
+        pair_ln_epilogue<EPI, 0>(av, smem + SIDE_OFF, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2);                    \
+    else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)                                                                \
+        pair_resid_epilogue<0, false>(av, smem + SIDE_OFF, out, m0, n0, N, wm, 2 * wn2 + h, g, c, stats, red);         \
+    else                                                                                                               \
+        tile_epilogue<EPI, 8>(av, bias, out, m0 + 128 * wm + c, M, n0 + 64 * (2 * wn2 + h) + 8 * g, N, K, aux, aux_i, aux2, N, g == 0);
+    KEDS_QUAD_READ_HALF0(av)
+    KEDS_QUAD_EPI(0)
+    __builtin_amdgcn_sched_barrier(0);
+    KEDS_QUAD_READ_HALF1(av)
+    KEDS_QUAD_EPI(1)
+#undef KEDS_QUAD_EPI
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+        if (stats) {                                                    // kernel-uniform
+            __syncthreads();
+            const f32x2* rr = reinterpret_cast<const f32x2*>(red) + tid;
+            const f32x2 a = rr[0], b = rr[256], c2 = rr[512], d = rr[768];
+            keds_stat_add(stats + 2 * (size_t)(m0 + tid), (a[0] + b[0]) + (c2[0] + d[0]), (a[1] + b[1]) + (c2[1] + d[1]));
+        }
+    }
+    if constexpr (STAMP) {                                           // same record layout as the 8-wave kernel's stamped build
+        const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+            unsigned long long* o = reinterpret_cast<unsigned long long*>(stamp_out) + ((size_t)blockIdx.x * 8 + wave) * 8;
+            o[0] = t_loop0 - t_entry;
+            o[1] = t_loop1 - t_loop0;
+            o[2] = t_issued - t_loop1;
+            o[3] = 0;
+            o[4] = 0;
+            o[5] = t_end - t_issued;
+            o[6] = t_entry;
+            o[7] = t_end;
+            unsigned long long* o2 = reinterpret_cast<unsigned long long*>(stamp_out) + (size_t)gridDim.x * 64 + (size_t)blockIdx.x * 8 + wave;
+            *o2 = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+        }
+    }
+}
+
 // NOTE (measured twice in round 1): a PERSISTENT form of this kernel does not pay.  Second attempt, with the fp16 residual
 // stream and the LDS-staged LN epilogue in place: one workgroup per CU walks its tiles; before the LAST K-step of a tile
 // (all LDS reads complete, one extra barrier) it issues the next tile's first two K-tiles, so the prologue (in-kernel
@@ -1095,6 +1410,26 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // chip can power, not by its schedule: idle cycles removed come back as clock.  Not kept.
 
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
+// 256^2 tiles on the 4-wave kernel: -1 = by shape (quad_by_shape), 0 = never, 1 = always, 2 = always, early-DMA form
+// (bits 11-12 of keds_gemm_force_small's argument force 1 / 2; KEDS_GEMM_QUAD=0/1 in the environment overrides the default)
+int g_quad = -1;
+int quad_env() {
+    static int v = -2;
+    if (v == -2) {
+        const char* e = getenv("KEDS_GEMM_QUAD");
+        v = e && e[0] ? atoi(e) : -1;
+    }
+    return v;
+}
+// Same-process A/B on the ViT-L/14 shapes (tools/ab_quad.py, medians of 5 x 20 launches, round 3): the 4-wave kernel wins
+// where the K-loop dominates the tile (qkv +2.8 %, c_proj +3.5 %) and loses where the epilogue does (out-proj -4 %: one wave
+// per SIMD runs the whole read-modify-write epilogue with nothing beside it; c_fc -0.5 %).
+template <int EPI>
+bool quad_by_shape(int N, int K) {
+    if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_LN_BIAS_BF16) return K >= 512;
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) return K >= 2048;
+    return false;
+}
 // fp16-residual GEMMs: residual + bias as the accumulators' initial value instead of 16 loads per lane in the epilogue (round 3,
 // asked for by the round-2 review).  Built, bit-compatible within the fp32 addition order, and SLOWER in a same-process
 // interleaved A/B (tools/ab_resid_prologue.py, 7 rounds x 20 launches, medians): out-proj 75.5 vs 73.0 us, c_proj 232.4 vs
@@ -1109,6 +1444,32 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
                int aux_i, void* aux2, hipStream_t st) {
     if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
     if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_RESID_STATS_F16) {
+        if (g_pair_stamp && g_quad > 0) {                                // stamped build of the 4-wave kernel
+            const dim3 grid((M / pr::TM) * (N / pr::TN));
+            if (g_quad == 2) {
+                (void)keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 1, 1>, pr::LDS_BYTES, "gemm_bt_quad_kernel<stamp>");
+                gemm_bt_quad_kernel<EPI, 1, 1><<<grid, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
+                                                                               N / pr::TN, aux, aux_i, aux2, nullptr);
+            } else {
+#define KEDS_QSTAMP(V)                                                                                              \
+    {                                                                                                              \
+        (void)keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 0, V>, pr::LDS_BYTES, "gemm_bt_quad_kernel<stamp>"); \
+        gemm_bt_quad_kernel<EPI, 0, V><<<grid, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, \
+                                                                         N / pr::TN, aux, aux_i, aux2, nullptr);    \
+    }
+                switch (g_pair_stamp) {
+                    case 2: KEDS_QSTAMP(2) break;
+                    case 3: KEDS_QSTAMP(3) break;
+                    case 4: KEDS_QSTAMP(4) break;
+                    case 5: KEDS_QSTAMP(5) break;
+                    case 6: KEDS_QSTAMP(6) break;
+                    case 7: KEDS_QSTAMP(8) break;
+                    default: KEDS_QSTAMP(1) break;
+                }
+#undef KEDS_QSTAMP
+            }
+            return keds_check_launch("gemm_bt_quad_kernel<stamp>");
+        }
         if (g_pair_stamp) {
             const dim3 grid((M / pr::TM) * (N / pr::TN));
 #define KEDS_STAMP_LAUNCH(V)                                                                                       \
@@ -1129,6 +1490,20 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         }
     }
     const int m_tiles = M / pr::TM, n_tiles = N / pr::TN;         // M is a multiple of 256 here
+    int quad = g_quad >= 0 ? g_quad : quad_env();
+    if (quad < 0) quad = quad_by_shape<EPI>(N, K) ? 1 : 0;
+    if (quad == 2) {
+        if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 1>, pr::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
+        gemm_bt_quad_kernel<EPI, 1><<<m_tiles * n_tiles, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N,
+                                                                                   K, n_tiles, aux, aux_i, aux2, keds_numerics_guard());
+        return keds_check_launch("gemm_bt_quad_kernel<deep>");
+    }
+    if (quad) {
+        if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI>, pr::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
+        gemm_bt_quad_kernel<EPI><<<m_tiles * n_tiles, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N,
+                                                                                K, n_tiles, aux, aux_i, aux2, keds_numerics_guard());
+        return keds_check_launch("gemm_bt_quad_kernel");
+    }
     if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
         if (g_resid_prologue) {
             if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI, 0, 1>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
@@ -1194,8 +1569,11 @@ extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
+    g_quad = (on >> 11) & 3;            // bits 11-12: 256^2 tiles on the 4-wave kernel (1), its early-DMA form (2), 3 = never
+    if (g_quad == 0) g_quad = -1;       // (0 = the default: by shape)
+    if (g_quad == 3) g_quad = 0;
     g_resid_prologue = (on >> 10) & 1;  // bit 10: fp16-residual GEMMs take residual + bias as the accumulators' initial value (A/B)
-    g_pair_stamp = (on >> 12) & 7;      // bits 12-14: stamped diagnostic build of the qkv / residual GEMMs (2: no statistics loads, 3: no stores, 4: no atomics, 5: no residual traffic at all)
+    g_pair_stamp = (on >> 13) & 7;      // bits 13-15: stamped diagnostic build of the qkv / residual GEMMs (2: no statistics loads, 3: no stores, 4: no atomics, 5: no residual traffic at all)
     return KEDS_OK;
 }
 

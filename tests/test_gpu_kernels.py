@@ -396,7 +396,7 @@ def test_gemm_residual_stats_epilogue_fp16_stream(M, N, K):
     # A/B variant of the 256^2 kernel (bit 10): x + b fed in as the accumulators' initial value instead of being loaded in
     # the epilogue -- only the order of the fp32 additions differs: same reference, same tolerance, and a missing bias is
     # zeros in both
-    lib.keds_gemm_force_small(1 << 10)
+    lib.keds_gemm_force_small((1 << 10) | (3 << 11))       # (3 << 11: on the 8-wave kernel, whatever the shape rule says)
     try:
         x3 = x0.clone()
         _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(a), K, _lib.ptr(w), _lib.ptr(b), _lib.ptr(x3), N, M, N, K,
@@ -538,3 +538,54 @@ def test_large_gallery_ranking_and_imgnet_metric(nq, ng):
     mo = O.get_metrics_imgnet(ref, gal, ql, tl)                    # and close to the oracle (near-tie flips move single hits)
     for k, v in mo.items():
         assert abs(v - mg[k]) <= 1.0 / nq + 1e-6, (k, v, mg[k])
+
+
+@pytest.mark.parametrize("K", [256, 1024])
+def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(K):
+    """The 4-wave 256 x 256 kernel (round 3: one wave per SIMD, 128 x 128 outputs per wave, accumulators in fixed AGPRs) runs
+    the same MFMA chains in the same k order and the same epilogues as the 8-wave kernel: every epilogue the towers use must
+    give the same bits (plain bias -> bf16, LayerNorm-folded bias / QuickGELU on fp16 operands, fp16 residual + statistics)."""
+    lib = _lib.load()
+    M, N = 4096, 4096                                            # 256 tiles of 256 x 256: the big-tile path
+    g = torch.Generator(device="cuda").manual_seed(K)
+    x = torch.randn(M, K, generator=g, device="cuda") * 1.3 + 0.2
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    gamma = 1 + 0.2 * torch.randn(K, generator=g, device="cuda")
+    beta = 0.1 * torch.randn(K, generator=g, device="cuda")
+    wf, bc = _fold(w, b, gamma, beta, torch.float16)
+    xh = torch.zeros((M, K), dtype=torch.float16, device="cuda")
+    stats = torch.zeros((M, 2), dtype=torch.int64, device="cuda")
+    _lib.check(lib.keds_rowstats_cast_ex(_lib.ptr(x), _lib.ptr(xh), 1, _lib.ptr(stats), M, K, _lib.stream()), "rowstats")
+    xb, wb = x.to(torch.bfloat16), w.to(torch.bfloat16)
+    resid0 = (2 * torch.randn(M, N, generator=g, device="cuda")).half()
+    _lib.ensure_gemm_workspace("cuda")
+
+    def run(flag):
+        lib.keds_gemm_force_small(flag)
+        try:
+            outs = []
+            o = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+            _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(xb), K, _lib.ptr(wb), _lib.ptr(b), _lib.ptr(o), N, M, N, K, _lib.EPI_BIAS_BF16,
+                                            None, 0, None, _lib.stream()), "plain")
+            outs.append(o)
+            for code in (_lib.EPI_LN_BIAS_BF16_H, _lib.EPI_LN_QGELU_BF16_H):
+                o = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+                other = torch.full((M, 2), 7, dtype=torch.int64, device="cuda")
+                _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(xh), K, _lib.ptr(wf), _lib.ptr(bc), _lib.ptr(o), N, M, N, K, code,
+                                                _lib.ptr(stats), 0, _lib.ptr(other), _lib.stream()), "ln")
+                outs += [o, other]
+            r = resid0.clone()
+            st = torch.zeros((M, 2), dtype=torch.int64, device="cuda")
+            _lib.check(lib.keds_gemm_bt_ex2(_lib.ptr(xb), K, _lib.ptr(wb), _lib.ptr(b), _lib.ptr(r), N, M, N, K,
+                                            _lib.EPI_RESID_STATS_F16, _lib.ptr(st), 0, None, _lib.stream()), "resid")
+            outs += [r, st]
+            torch.cuda.synchronize()
+            return outs
+        finally:
+            lib.keds_gemm_force_small(0)
+    eight, four, deep = run(3 << 11), run(1 << 11), run(2 << 11)       # (2 << 11: the 4-wave kernel's early-DMA form)
+    want = xb.float() @ wb.float().t() + b
+    assert rel_l2(four[0], want) <= 4e-3
+    for a, c, d in zip(eight, four, deep):
+        assert torch.equal(a, c) and torch.equal(a, d)

@@ -26,7 +26,7 @@ def main():
         _lib.ensure_gemm_workspace(a.device)
         res = {"acc-init (r03)": [], "epilogue load (r02)": []}
         for rnd in range(rounds):
-            for name, flag in (("acc-init (r03)", 1 << 10), ("epilogue load (r02)", 0)):
+            for name, flag in (("acc-init (r03)", (1 << 10) | (3 << 11)), ("epilogue load (r02)", 3 << 11)):
                 lib.keds_gemm_force_small(flag)
 
                 def run():

@@ -7,6 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from keds_amd import _lib
 from keds_amd._lib import ptr, check, stream
 lib = _lib.load()
+QUADBITS = {"0": 3, "1": 1, "2": 2}[os.environ.get("QUAD", "0")]     # 8-wave kernel | 4-wave | 4-wave, early DMA
 SHAPE = os.environ.get("SHAPE", "qkv")          # qkv (LN-folded epilogue) | out | proj (fp16-residual epilogue)
 M, N, K = {"qkv": (32768, 3072, 1024), "out": (32768, 1024, 1024), "proj": (32768, 1024, 4096)}[SHAPE]
 RESID = SHAPE != "qkv"
@@ -40,6 +41,7 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 DELAY = 0
 def gemm(aux2):
     check(lib.keds_gemm_bt_ex2(ptr(a), K, ptr(w), ptr(bias), ptr(out), N, M, N, K, EPI, ptr(stats), DELAY, ptr(aux2) if aux2 is not None else None, stream()), "gemm")
+lib.keds_gemm_force_small(QUADBITS << 11)
 run(other); torch.cuda.synchronize()
 e0.record(); gemm(other); e1.record(); torch.cuda.synchronize()
 print(f"== SHAPE={SHAPE} {M}x{N}x{K}: product launch (unstamped) {e0.elapsed_time(e1) * 1e3:.1f} us")
@@ -48,7 +50,7 @@ VARIANTS = (((1, "product epilogue", 0), (3, "no stores", 0), (4, "no statistics
             if RESID else ((1, "product epilogue", 0), (2, "no statistics loads", 0), (3, "no stores", 0),
                            (1, "product epilogue, half of the CUs 25k cycles late", 25000), (1, "product epilogue again", 0)))
 for variant, what, DELAY in VARIANTS:
-    lib.keds_gemm_force_small(variant << 12)
+    lib.keds_gemm_force_small((variant << 13) | (QUADBITS << 11))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(3):
         run(buf)
