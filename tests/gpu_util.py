@@ -42,3 +42,43 @@ def min_cosine(a, b):
 
 def bf16_round(x):
     return x.to(torch.bfloat16).to(torch.float32)
+
+
+# ---- parity assertion with tracked baselines --------------------------------------------------------------------------
+# Class ceilings (what the path promises for ANY input of that kind: DESIGN.md section 3) ...
+CLASS_LIMITS = (                      # (name fragment, min cosine, max rel-L2): first match wins
+    ("tokens_", 0.9990, 1.3e-2),      # knowledge tokens [B,3,D]: three rows of very different norm per query
+    ("encode_image", 0.99995, 6.0e-3), ("query_image", 0.99995, 6.0e-3), ("patch_embed", 0.99995, 6.0e-3),
+    ("block", 0.99995, 6.0e-3), ("gallery_features", 0.99995, 1.0e-2), ("query_features", 0.99995, 1.0e-2),
+    ("encode_text", 0.99995, 1.1e-2), ("forward.text", 0.99995, 1.1e-2),
+    ("", 0.99994, 1.3e-2),            # composed / mixture / knowledge-module outputs
+)
+_BASE = None
+
+
+def parity_limits(name, cos_min=None, rel_max=None):
+    """... and, per test row, at most 2x the error MEASURED on the committed build (tests/golden/parity_baseline.json):
+    a 3x numerics regression no longer passes (round-2 review: asserted tolerances were 2.5-6x the measured values)."""
+    global _BASE
+    if _BASE is None:
+        path = os.path.join(ROOT, "tests", "golden", "parity_baseline.json")
+        _BASE = json.load(open(path))["rows"] if os.path.exists(path) else {}
+    c_lim, r_lim = next((c, r) for frag, c, r in CLASS_LIMITS if frag in name)
+    if cos_min is not None:
+        c_lim = max(c_lim, cos_min) if cos_min > 0.9999 else c_lim
+    if rel_max is not None:
+        r_lim = min(r_lim, rel_max)
+    b = _BASE.get(name)
+    if b:
+        r_lim = min(r_lim, 2.0 * b["rel_l2"])
+        c_lim = max(c_lim, 1.0 - 2.0 * (1.0 - b["min_cosine"]))
+    return c_lim, r_lim
+
+
+def assert_parity(name, got, want, cos_min=None, rel_max=None):
+    c, r = min_cosine(got, want), rel_l2(got, want)
+    c_lim, r_lim = parity_limits(name, cos_min, rel_max)
+    report(name, min_cosine=c, rel_l2=r, max_abs=max_abs(got, want), limit_cosine=c_lim, limit_rel_l2=r_lim)
+    assert torch.isfinite(got.float()).all(), f"{name}: non-finite output"
+    assert c >= c_lim, f"{name}: cosine {c} < {c_lim}"
+    assert r <= r_lim, f"{name}: rel-L2 {r} > {r_lim}"

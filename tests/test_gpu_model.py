@@ -17,7 +17,7 @@ import torch
 import keds_amd
 from oracle import keds_oracle as O
 from tests.conftest import golden_path
-from tests.gpu_util import max_abs, min_cosine, rel_l2, report
+from tests.gpu_util import assert_parity, max_abs, min_cosine, rel_l2, report
 
 pytestmark = pytest.mark.gpu
 
@@ -28,12 +28,10 @@ VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=
 COS_MIN, REL_MAX = 0.9999, 1.5e-2
 
 
-def _assert_close(name, got, want, cos_min=COS_MIN, rel_max=REL_MAX):
-    c, r = min_cosine(got, want), rel_l2(got, want)
-    report(name, min_cosine=c, rel_l2=r, max_abs=max_abs(got, want))
-    assert torch.isfinite(got.float()).all(), f"{name}: non-finite output"
-    assert c >= cos_min, f"{name}: cosine {c}"
-    assert r <= rel_max, f"{name}: rel-L2 {r}"
+def _assert_close(name, got, want, cos_min=None, rel_max=None):
+    """Class ceiling (image 6e-3 / text 1.1e-2 / composed 1.3e-2 rel-L2, cosine >= 0.99994-0.99995) AND at most twice the
+    error measured on the committed build (tests/golden/parity_baseline.json)."""
+    assert_parity(name, got, want, cos_min, rel_max)
 
 
 @pytest.fixture(scope="module")

@@ -13,7 +13,7 @@ import keds_amd
 from keds_amd import _lib, session
 from oracle import keds_oracle as O
 from tests.conftest import golden_path
-from tests.gpu_util import max_abs, min_cosine, rel_l2, report
+from tests.gpu_util import assert_parity, max_abs, min_cosine, rel_l2, report
 from tests.test_gpu_model import COS_MIN, REL_MAX, TINY, _streams
 
 pytestmark = pytest.mark.gpu
@@ -35,9 +35,7 @@ def tiny():
 
 
 def _close(name, got, want):
-    c, r = min_cosine(got, want), rel_l2(got, want)
-    report(name, min_cosine=c, rel_l2=r)
-    assert c >= COS_MIN and r <= REL_MAX, (name, c, r)
+    assert_parity(name, got, want)
 
 
 def test_vit_handle_matches_facade_and_golden(ctx, tiny):

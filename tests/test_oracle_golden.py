@@ -227,3 +227,50 @@ def test_vitl14_full_size():
     _close(O.encode_text(sd, text), g["encode_text"], atol=5e-5, rtol=1e-4)
     _close(O.encode_text_img_retrieval(sd, text, torch.from_numpy(g["tok3"]), split_ind=265, repeat=False),
            g["eti3"], atol=5e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("tag,cfg,dim,middle", [
+    ("tiny", dict(embed_dim=128, image_resolution=56, vision_layers=2, vision_width=128, vision_patch_size=14,
+                  context_length=77, vocab_size=512, transformer_width=128, transformer_layers=2), 128, 128),
+    ("vitl_text", dict(embed_dim=768, image_resolution=56, vision_layers=1, vision_width=128, vision_patch_size=14,
+                       context_length=77, vocab_size=49408, transformer_width=768, transformer_layers=12), 768, 512)])
+def test_training_loss_and_gradients_match_the_reference_loss_function(tag, cfg, dim, middle):
+    """`oracle.training_loss` (restatement of src/trainer.py:44-127) pinned to the reference's OWN
+    `get_loss_img2text_image` + `get_retrieved_features` run under a 1-rank gloo group with distributed = aggregate = True
+    and dropout 0 (tools/mint_golden.py train): the loss and torch-autograd gradients of all 54 module parameters.  The
+    oracle's gradients are in turn the reference of the HIP backward kernels (tests/test_gpu_train.py)."""
+    g = np.load(golden_path(f"train_step_{tag}.npz"))
+    sd_clip = O.synth_clip_state_dict(**cfg, seed=7)
+    sds = (O.synth_im2text_state_dict(dim, middle, dim, 2, seed=31, tag="i2t"),
+           O.synth_crossformer_state_dict(dim, 3, seed=31, tag="fuse"),
+           O.synth_crossformer_state_dict(dim, 3, seed=31, tag="cond"))
+    chk = sum(float(sum(v.double().sum().item() for v in sd.values())) for sd in (sd_clip,) + sds)
+    assert abs(chk - float(g["weights_checksum"])) <= 1e-6 * max(1.0, abs(chk))       # generator drift would show here
+    n_db = int(g["n_db"])
+    image_base, text_base = O.synth_database(n_db, dim, seed=2002), O.synth_database(n_db, dim, seed=2003)
+    feat = torch.from_numpy(g["image_features"])
+    ti, tt, _, _ = O.get_retrieved_features(feat, image_base, text_base, 16)
+    leaves = [{k: v.clone().requires_grad_(True) for k, v in sd.items()} for sd in sds]
+    with torch.enable_grad():
+        loss = O.training_loss(sd_clip, leaves[0], leaves[1], leaves[2], feat, ti, tt, torch.from_numpy(g["text"]),
+                               int(g["star"]), masks=None, p_drop=0.0)
+        names, tensors = [], []
+        for pfx, leaf in zip(("i2t.", "fuse.", "cond."), leaves):
+            for k, v in leaf.items():
+                names.append(pfx + k)
+                tensors.append(v)
+        grads = dict(zip(names, torch.autograd.grad(loss, tensors)))
+    assert abs(float(loss) - float(g["loss"])) <= 2e-6 * max(1.0, abs(float(g["loss"])))
+    assert sorted(names) == sorted(str(n) for n in g["names"])
+    for k in names:
+        mine = grads[k].detach()
+        if "g." + k in g.files:
+            want = torch.from_numpy(g["g." + k])
+            tol = 1e-4 * max(float(want.abs().max()), 1e-3)      # fp32 summation order through up to 12 blocks of backward
+            assert float((mine - want).abs().max()) <= tol, k
+        else:
+            s_, a_ = g["gs." + k]
+            assert abs(mine.double().sum().item() - s_) <= 1e-4 * max(a_, 1e-6), k
+            assert abs(mine.double().abs().sum().item() - a_) <= 1e-4 * max(a_, 1e-6), k
+            head = torch.from_numpy(g["gh." + k])
+            assert float((mine.reshape(-1)[:256] - head).abs().max()) <= 1e-4 * max(float(head.abs().max()), 1e-3), k

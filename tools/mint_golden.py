@@ -405,6 +405,80 @@ def mint_dual_full(batch=8, n_db=500000):
     print("dual_vitl14_full: ok; top-16/17 gaps image", (Di[:, 16] - Di[:, 15]).min(), "text", (Dt[:, 16] - Dt[:, 15]).min())
 
 
+def mint_train_step(tag, cfg, dim, middle, batch, n_db=512):
+    """One training step of the knowledge modules through the reference's OWN loss function (src/trainer.py:44-165,
+    `get_loss_img2text_image`, extracted with `ast`) and its own `get_retrieved_features` (:198-259), under a 1-rank gloo
+    group with args.distributed = args.aggregate = True (the all_gather branch, :84-127), on the reference modules in
+    training mode with dropout 0.  The one documented deviation: the reference's `get_text_features` builds a 78-token
+    sequence and fails, so the name is bound to the reference model's evaluation splice
+    `encode_text_img_retrieval("a photo of *", tokens)`.  Stored: inputs, the loss, and torch-autograd gradients of the
+    reference modules' 54 parameters (whole tensors when small; sum / abs-sum / leading 256 elements otherwise)."""
+    import torch.distributed as dist
+    import torch.nn as nn
+    sd_clip = O.synth_clip_state_dict(**cfg, seed=7)
+    model = CLIP(**{**cfg, "transformer_heads": cfg["transformer_width"] // 64}).eval()
+    model.load_state_dict(sd_clip, strict=True)
+    sds = (O.synth_im2text_state_dict(dim, middle, dim, 2, seed=31, tag="i2t"),
+           O.synth_crossformer_state_dict(dim, 3, seed=31, tag="fuse"),
+           O.synth_crossformer_state_dict(dim, 3, seed=31, tag="cond"))
+    img2text = IM2TEXT(embed_dim=dim, middle_dim=middle, output_dim=dim, n_layer=2, dropout=0.0).train()
+    retrieval_fuse = CrossFormer(q_dim=dim, k_dim=dim, v_dim=dim, num_layers=3).train()
+    text_condition = CrossFormer(q_dim=dim, k_dim=dim, v_dim=dim, num_layers=3).train()
+    img2text.load_state_dict(sds[0]); retrieval_fuse.load_state_dict(sds[1]); text_condition.load_state_dict(sds[2])
+    image_base = O.synth_database(n_db, dim, seed=2002)
+    text_base = O.synth_database(n_db, dim, seed=2003)
+    ii, ti = FakeFlatL2(), FakeFlatL2()
+    ii.add(image_base.numpy()); ti.add(text_base.numpy())
+    database = [image_base, text_base, [str(i) for i in range(n_db)], ii, ti]
+    rs = np.random.RandomState(77)
+    image_features = torch.from_numpy((image_base[rs.randint(0, n_db, size=batch)].numpy()
+                                       + 0.3 * rs.standard_normal((batch, dim)) / np.sqrt(dim)).astype(np.float32) * 3.0)
+    caps = torch.zeros(batch, dim)                                   # ori_cap_feature: read, never used in this branch
+    star = 265
+    text = torch.zeros(77, dtype=torch.long)
+    text[:6] = torch.tensor([49406 if cfg["vocab_size"] > 49406 else cfg["vocab_size"] - 2, 320, 1125, 539, star,
+                             cfg["vocab_size"] - 1])             # <sot> a photo of * <eot>
+    text[1:4] = text[1:4] % (cfg["vocab_size"] - 2)
+
+    def get_text_features(model_, token_features, args_):            # the documented deviation (evaluation splice)
+        return model_.encode_text_img_retrieval(text[None, :].repeat(token_features.size(0), 1), token_features,
+                                                split_ind=star, repeat=False)
+
+    ns = {"torch": torch, "np": np, "dist": dist, "get_text_features": get_text_features}
+    ns["get_retrieved_features"] = extract_function(os.path.join(REF, "trainer.py"), "get_retrieved_features", ns)
+    loss_fn = extract_function(os.path.join(REF, "trainer.py"), "get_loss_img2text_image", ns)
+
+    class Args:
+        distributed, aggregate, gpu = True, True, None
+    real_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self                    # trainer.py:56-57 move tensors to args.gpu unconditionally
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 1000), rank=0, world_size=1)
+    try:
+        torch.manual_seed(5)                                          # (the randperm of the neighbour axis, :216-217: a numerical no-op)
+        with torch.enable_grad():
+            loss = loss_fn(model, img2text, retrieval_fuse, text_condition, image_features, (caps, None, None),
+                           nn.CrossEntropyLoss(), nn.CrossEntropyLoss(), None, Args(), database)
+            params = [("i2t." + k, v) for k, v in img2text.named_parameters()] + \
+                     [("fuse." + k, v) for k, v in retrieval_fuse.named_parameters()] + \
+                     [("cond." + k, v) for k, v in text_condition.named_parameters()]
+            grads = torch.autograd.grad(loss, [v for _, v in params])
+    finally:
+        dist.destroy_process_group()
+        torch.Tensor.cuda = real_cuda
+    out = {"image_features": image_features.numpy(), "text": text.numpy(), "n_db": np.int64(n_db), "star": np.int64(star),
+           "loss": np.float64(loss.item()), "weights_checksum": np.float64(checksum(sd_clip) + sum(checksum(x) for x in sds)),
+           "names": np.array([k for k, _ in params])}
+    for (k, _), g in zip(params, grads):
+        g = g.detach()
+        if g.numel() <= 4096:
+            out["g." + k] = g.numpy()
+        else:
+            out["gs." + k] = np.array([g.double().sum().item(), g.double().abs().sum().item()])
+            out["gh." + k] = g.reshape(-1)[:256].numpy()
+    np.savez_compressed(os.path.join(OUT, f"train_step_{tag}.npz"), **out)
+    print(f"train_step_{tag}: loss {loss.item():.6f}, {len(params)} gradients")
+
+
 def mint_heavy_tail(batch=2):
     """ViT-L/14 + text tower with heavy-tailed activations (massive channels of 50-200 sigma in the residual stream,
     as real CLIP checkpoints have): the reference's fp32 outputs and per-block CLS rows."""
@@ -484,6 +558,12 @@ if __name__ == "__main__":
         mint_metrics()
     if "vitl" in which:
         mint_clip("vitl14", VITL, batch=2, star=265)
+    if "train" in which:
+        torch.set_grad_enabled(True)
+        mint_train_step("tiny", TINY, 128, 128, batch=6)
+        # text tower of ViT-L/14 (12 x 768) with a one-block stand-in for the visual tower, which the loss never runs
+        mint_train_step("vitl_text", {**VITL, "image_resolution": 56, "vision_layers": 1, "vision_width": 128}, 768, 512, batch=4)
+        torch.set_grad_enabled(False)
     # full-size fixtures (minutes of CPU each; not in the default list)
     if "heavy" in which:
         mint_heavy_tail()
