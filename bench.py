@@ -399,6 +399,7 @@ def main():
             _lib.prof_enable(False)
     fence()
     elapsed = time.perf_counter() - t0
+    guard_tripped = bool(model.numerics_sync())                 # the lazily checked numerics guard of the timed passes
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -492,6 +493,9 @@ def main():
                               # read-only stream over 4 GiB on this box: 7.15 TB/s (profiles/r01_microbench.txt)
                               "peak_measured": PEAK_HBM_MEASURED_GBPS, "frac_of_measured": scan_ach / PEAK_HBM_MEASURED_GBPS},
             "profiled_steps": prof_steps, "side_lane_rows": side_rows,
+            "numerics_guard": {"mode": model.numerics, "tripped": guard_tripped,
+                               "checked": "eagerly on the first passes, then lazily (flag copied to pinned memory behind every pass, "
+                                          "verified after the timed region)"},
             "search_overlap": ("n/a (dual: the knowledge path consumes the neighbours at once)" if dual else
                                "none (one GPU: no collective to hide)" if xchg is None else
                                ("search of batch i on a second stream beside the encoder pass of batch i+1" if overlap["on"]

@@ -1037,6 +1037,7 @@ int g_scan_debug = 0;   // timing-only ablations of the D=768 scan kernel
 int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresholds)
 int g_force_exact = 0;  // test hook: 1 sends every query through the exact fallback
 int g_scan_nt = 1;      // non-temporal LDS-DMA for the D = 768 candidate pass (A/B hook: keds_scan_debug bit 6 turns it off)
+int g_thr_depth = 0;    // threshold-pass list depth: 0 = by launch shape, 1 / 4 forced (A/B hook: keds_scan_debug bits 7-9)
 
 template <int D, int L>
 int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr,
@@ -1113,6 +1114,8 @@ extern "C" int keds_scan_debug(int variant) {
     g_scan_phases = (variant >> 4) & 1;   // bit 4: force the single-phase scan (exact as well; for A/B tests)
     g_force_exact = (variant >> 5) & 1;   // bit 5: fail every certificate (tests of the exact fallback)
     g_scan_nt = (variant >> 6) & 1 ? 0 : 1;   // bit 6: default-policy key stream instead of non-temporal (A/B)
+    g_thr_depth = (variant >> 7) & 7;         // bits 7-9: threshold-pass list depth 1 or 4 forced (0: by launch shape)
+    if (g_thr_depth != 1 && g_thr_depth != 4) g_thr_depth = 0;
     return KEDS_OK;
 }
 
@@ -1201,7 +1204,23 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
         qprep_kernel<<<nqb * QBLOCK / 4, 256, 0, st>>>(queries + (size_t)q0 * dim, nb, dim, normalize_q, qn, w.qb,
                                                       nqb * QBLOCK, w.qstat, w.counters);
         if ((rc = keds_check_launch("qprep_kernel"))) return rc;
-        auto scan_thr = [&]() -> int {                             // depth-4 lists, no threshold
+        // Threshold pass list depth.  Round 3: ONE entry per lane (its running maximum) wherever that still leaves 4 x ncand
+        // lane maxima per query: the ncand-th largest of nwgA * 4 group maxima is reached by ncand distinct rows (all a
+        // threshold has to guarantee), and with ~30 rows per group it sits within a few places of the exact ncand-th best of
+        // the sample -- the top ncand rows fall into distinct groups almost surely -- while the pass drops from an
+        // insert-bound 2.2 TB/s (depth-4 lists filling from empty) to streaming speed and its merge reads a quarter of the
+        // entries.  Few workgroups per query block (row-sharded search of many query blocks) keep depth 4.
+        const int depthA = g_thr_depth ? g_thr_depth : ((long)nwgA * 4 >= 4L * ncand ? 1 : 4);
+        auto scan_thr = [&]() -> int {                             // shallow lists, no threshold
+            if (depthA == 1) {
+                switch (dim) {
+                    case 128: return launch_scan<128, 1>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                    case 256: return launch_scan<256, 1>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                    case 512: return launch_scan<512, 1>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                    case 768: return launch_scan<768, 1>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                    default: return launch_scan<1024, 1>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
+                }
+            }
             switch (dim) {
                 case 128: return launch_scan<128, 4>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
                 case 256: return launch_scan<256, 4>(packed, 0, stagesA, w.qb, nullptr, w.lpairs, w.lmeta, nwgA, nqb, st);
@@ -1226,7 +1245,7 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
             // inserts are rare for ANY data.
             if ((rc = scan_thr())) return rc;
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_pairs_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgA, 4 * 4, w.aidx, w.aval, w.thr, ncand, nullptr,
+            merge_pairs_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgA, 4 * depthA, w.aidx, w.aval, w.thr, ncand, nullptr,
                                                              nullptr);
             if ((rc = keds_check_launch("merge_pairs_kernel(thr)"))) return rc;
         }

@@ -168,6 +168,9 @@ class _Packed:
         self.device = conv.device
 
 
+GUARD_EAGER_PASSES = 8      # numerics = "auto": tower passes whose guard flag is read back at once (see CLIP.__init__)
+
+
 class CLIP(nn.Module):
     def __init__(self, embed_dim: int, image_resolution: int, vision_layers: Union[Tuple[int, int, int, int], int],
                  vision_width: int, vision_patch_size: int, context_length: int, vocab_size: int,
@@ -203,6 +206,17 @@ class CLIP(nn.Module):
         self.numerics = "safe" if os.environ.get("KEDS_DETERMINISTIC", "0") == "1" else os.environ.get("KEDS_NUMERICS", "auto")
         self.numerics_tripped = False
         self._guard: Optional[torch.Tensor] = None
+        # "auto" reads the guard flag back EAGERLY (one host-device sync per pass, the pass is re-run on the safe flow when it
+        # tripped) for the first GUARD_EAGER_PASSES passes after the weights were packed -- what trips the guard is a property
+        # of the weights far more than of one batch -- and LAZILY afterwards: the flag travels to pinned host memory behind
+        # the pass, is looked at when the next pass is enqueued (or by numerics_sync()), and a late trip warns, switches the
+        # model to the safe flow for every later pass and sets `numerics_late_trip` (the passes since the last check ran on
+        # the fast flow: re-run them if their accuracy matters).  The host then never waits for a tower: the search of batch
+        # i and the tower of batch i+1 are enqueued while batch i is still running (round-2 advisor finding).
+        self.numerics_late_trip = False
+        self._guard_eager_left = GUARD_EAGER_PASSES
+        self._guard_host: Optional[torch.Tensor] = None
+        self._guard_event = None
 
     # ---- init (same distributions as model.py:511-541) ------------------------------------------
     def initialize_parameters(self):
@@ -257,6 +271,7 @@ class CLIP(nn.Module):
         folded = self.numerics != "safe" and not self.numerics_tripped
         if self._packed is None or self._packed.folded != folded:
             self._packed = _Packed(self, folded=folded)
+            self._guard_eager_left = GUARD_EAGER_PASSES
         _lib.ensure_gemm_workspace(self._packed.device)
         return self._packed
 
@@ -265,11 +280,40 @@ class CLIP(nn.Module):
             raise ValueError("numerics must be 'auto', 'fast' or 'safe'")
         if mode == "safe" and self.precision == "fp8":
             raise ValueError("fp8 needs the folded LayerNorm path")
-        self.numerics, self.numerics_tripped = mode, False
+        self._guard_poll(wait=True)
+        self.numerics, self.numerics_tripped, self.numerics_late_trip = mode, False, False
+        self._guard_eager_left = GUARD_EAGER_PASSES
         return self
+
+    def _guard_trip(self, late: bool):
+        import warnings
+        warnings.warn("keds_amd.CLIP: activations left the range the fast tower flow is accurate in (|row mean|/std > 32 or a "
+                      "non-finite fp16 residual); " + ("the passes since the last check ran on the fast flow (numerics_late_trip); "
+                      "later passes run" if late else "re-running") + " on the fp32-stream flow and staying there", RuntimeWarning)
+        self._guard.zero_()
+        self.numerics_tripped = True
+        self.numerics_late_trip = self.numerics_late_trip or late
+
+    def _guard_poll(self, wait: bool) -> None:
+        """Look at the flag copy that travelled behind the last lazily checked pass (blocking only when `wait`)."""
+        ev = self._guard_event
+        if ev is None or not (wait or ev.query()):
+            return
+        if wait:
+            ev.synchronize()
+        self._guard_event = None
+        if int(self._guard_host[0]) != 0 and not self.numerics_tripped:
+            self._guard_trip(late=True)
+
+    def numerics_sync(self) -> bool:
+        """Block until every lazily checked pass has been verified; True when the guard tripped at any point (the model is
+        then on the safe flow; `numerics_late_trip` says whether passes had already been returned from the fast flow)."""
+        self._guard_poll(wait=True)
+        return self.numerics_tripped
 
     def _guarded(self, run):
         """Run one tower pass (`run(engine)` enqueues it and returns the output tensor) under the numerics guard."""
+        self._guard_poll(wait=False)
         eng = self._engine()
         # (a stream that is being captured into a hipGraph cannot be synchronised: no flag read there -- capture a model whose
         # activations were checked eagerly, or set_numerics("safe"))
@@ -283,13 +327,20 @@ class CLIP(nn.Module):
             out = run(eng)
         finally:
             check(lib.keds_numerics_guard_set(None), "keds_numerics_guard_set")
+        if self._guard_eager_left <= 0:                      # lazy: the flag follows the pass to pinned host memory
+            if self._guard_host is None:
+                self._guard_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                self._guard_event_obj = torch.cuda.Event()
+            if self._guard_event is not None:                # at most one copy in flight: the flag is sticky, nothing is lost
+                self._guard_poll(wait=True)
+            self._guard_host.copy_(self._guard, non_blocking=True)
+            self._guard_event_obj.record()
+            self._guard_event = self._guard_event_obj
+            return out
+        self._guard_eager_left -= 1
         if int(self._guard.item()) == 0:
             return out
-        import warnings
-        warnings.warn("keds_amd.CLIP: activations left the range the fast tower flow is accurate in (|row mean|/std > 32 or a "
-                      "non-finite fp16 residual); re-running on the fp32-stream flow and staying there", RuntimeWarning)
-        self._guard.zero_()
-        self.numerics_tripped = True
+        self._guard_trip(late=False)
         return run(self._engine())
 
     # ---- encoders ------------------------------------------------------------------------------------
@@ -317,6 +368,16 @@ class CLIP(nn.Module):
             return out
         return self._guarded(run).to(self.dtype)
 
+    def _host_tokens(self, text: torch.Tensor) -> torch.Tensor:
+        """The token rows on the HOST for the argument checks the reference's own indexing performs (one EOT per row, ids
+        inside the table, the split token, the read-out column): one device-to-host copy per call when the caller passed
+        device tokens (none for the CPU tokens a DataLoader yields) instead of five blocking reductions on the device."""
+        th = text.cpu() if text.is_cuda else text
+        # nn.Embedding raises IndexError on an id outside the table (model.py:579); the gather kernel does not check
+        if th.numel() and (int(th.min()) < 0 or int(th.max()) >= self.vocab_size):
+            raise IndexError(f"token id outside [0, {self.vocab_size})")
+        return th
+
     def _eot_columns(self, text: torch.Tensor) -> torch.Tensor:
         hits = text == self.end_id
         if not bool((hits.sum(dim=1) == 1).all()):
@@ -330,11 +391,8 @@ class CLIP(nn.Module):
         B = text.shape[0]
         if B == 0:
             return torch.empty((0, self.embed_dim), dtype=self.dtype, device=eng.device)
-        # nn.Embedding raises IndexError on an id outside the table (model.py:579); the gather kernel does not check
-        if int(text.min()) < 0 or int(text.max()) >= self.vocab_size:
-            raise IndexError(f"token id outside [0, {self.vocab_size})")
-        tok = text.to(eng.device, dtype=torch.int32).contiguous()
-        ro = readout.to(eng.device, dtype=torch.int32).contiguous()
+        tok = text.to(eng.device, dtype=torch.int32).contiguous()           # (ids were range-checked on the host: _host_tokens)
+        ro = readout.to(torch.int32).to(eng.device, non_blocking=True).contiguous()
         it = None if img_tokens is None else img_tokens.to(eng.device, dtype=torch.float32).contiguous()
         n_tok = 0 if it is None else it.shape[1]
 
@@ -351,7 +409,9 @@ class CLIP(nn.Module):
         """model.py:577-590.  text int [B, L] -> [B, embed_dim]; read-out at the EOT column."""
         if text.dim() != 2 or text.shape[1] != self.context_length:
             raise RuntimeError(f"expected tokens [B,{self.context_length}], got {tuple(text.shape)}")
-        return self._run_text(text, self._eot_columns(text), None, 0, normalize)
+        if text.shape[0] == 0:
+            return self._run_text(text, text.new_zeros(0), None, 0, normalize)
+        return self._run_text(text, self._eot_columns(self._host_tokens(text)), None, 0, normalize)
 
     def encode_text_img_retrieval(self, text, img_tokens, split_ind=4, repeat=True, normalize: bool = False):
         """model.py:808-851.  The first `split_ind` token of ROW 0 is replaced by the 2 or 3 pseudo tokens of
@@ -369,11 +429,12 @@ class CLIP(nn.Module):
                                f"{self.context_length})")
         if img_tokens.shape[2] != self.transformer_width:
             raise RuntimeError("pseudo-token width does not match the text transformer")
-        where = (text[0] == int(split_ind)).nonzero()
+        th = self._host_tokens(text)
+        where = (th[0] == int(split_ind)).nonzero()
         if where.numel() == 0:
             raise IndexError("split token not present in text[0]")
         ins = int(where[0])
-        readout = self._eot_columns(text) + (n_tok - 1)
+        readout = self._eot_columns(th) + (n_tok - 1)
         if int(readout.max()) >= self.context_length:
             raise IndexError("read-out row beyond the context length")
         return self._run_text(text, readout, img_tokens, ins, normalize)
@@ -389,13 +450,14 @@ class CLIP(nn.Module):
                                f"be {self.context_length})")               # reference: size mismatch at model.py:883
         if text.dim() != 2 or text.shape[0] != img_tokens.shape[0] or text.shape[1] != self.context_length:
             raise RuntimeError(f"token rows {tuple(text.shape)} do not match {img_tokens.shape[0]} pseudo-token rows")
-        where = (text[0] == int(split_ind)).nonzero()
+        th = self._host_tokens(text)
+        where = (th[0] == int(split_ind)).nonzero()
         if where.numel() == 0:
             raise IndexError("split token not present in text[0]")
         ins = int(where[0])
         if ins + 3 > self.context_length:
             raise RuntimeError("no room for 3 pseudo tokens after the split token")
-        eot = self._eot_columns(text)
+        eot = self._eot_columns(th)
         if bool(((eot >= ins) & (eot < ins + 3)).any()):
             raise IndexError("the EOT token lies inside the overwritten span")
         L = self.context_length

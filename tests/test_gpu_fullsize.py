@@ -146,6 +146,23 @@ def test_numerics_guard_switches_flow_when_rows_lose_their_centre():
         warnings.simplefilter("error")
         ok.encode_image(img.cuda())
     assert not ok.numerics_tripped
+    # after its first passes "auto" checks the flag LAZILY (no host sync per pass): a trip is then noticed when the next pass
+    # is enqueued or at numerics_sync(), the model switches flows for every later pass and says that passes already returned
+    # came from the fast flow
+    lazy = keds_amd.build_model({k: v for k, v in sd.items()}, fp16=False).cuda()
+    lazy._engine()
+    lazy._guard_eager_left = 0
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        first = lazy.encode_image(img.cuda())              # returned from the fast flow, nothing waited for
+    assert torch.equal(first, bad) and not lazy.numerics_tripped
+    with pytest.warns(RuntimeWarning, match="numerics_late_trip"):
+        assert lazy.numerics_sync() is True
+    assert lazy.numerics_tripped and lazy.numerics_late_trip
+    assert torch.equal(lazy.encode_image(img.cuda()), got)  # the safe flow from here on
+    for _ in range(keds_amd.model.GUARD_EAGER_PASSES + 3):  # a benign model crosses from eager to lazy checks without a trip
+        ok.encode_image(img.cuda())
+    assert ok.numerics_sync() is False and ok._guard_eager_left == 0
 
 
 def test_dual_stream_composed_query_full_size_against_reference_golden():
