@@ -1076,40 +1076,97 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 // random data, tools/micro/vendor_gemm.py: fc 1,174 vs 969, proj 1,438 vs 1,199, 8192^3 1,526 vs 1,390 TFLOP/s), and
 // rocprofv3 names what it runs: a 256-thread workgroup per 256 x 256 x 64 tile -- one wave per SIMD, 128 x 128 outputs per
 // wave, 256 accumulators in AGPRs, 16 + 16 fragment registers per K-step.  Per K-tile that is 32 ds_read_b128 per wave
-// (128 KB of LDS reads per workgroup against 192 KB for eight 128 x 64 waves: a fragment feeds 8 MFMAs instead of 4 or 8),
-// no second wave competing for the SIMD's matrix pipe and issue port, and four instead of eight parties at the barrier.
+// (128 KB of LDS reads per workgroup against 192 KB for eight 128 x 64 waves), no second wave competing for the SIMD's
+// matrix pipe and issue port, and four instead of eight parties at the barrier.  Both kernels run AT THE BOARD'S POWER CAP
+// (rocm-smi, tools/micro/power_clock_probe.py: 1,390-1,400 W for the vendor's kernel and for ours), the vendor's at a
+// LOWER shader clock (1.4-1.9 GHz against 2.0-2.25) with more of its cycles in the matrix pipe: at the cap, throughput is
+// bought with utilisation (fewer stall / prologue / epilogue cycles run at a lower voltage point), not with clock.
 // Same HBM -> LDS image, staging (LDS-DMA, one counted wait + barrier per K-tile), tile walk and epilogues as the 8-wave
 // kernel: wave (wm, wn2) owns rows [128 wm, +128) x columns [128 wn2, +128) = the 8-wave kernel's wave columns 2 wn2 and
 // 2 wn2 + 1 ("halves" h = 0, 1 below).
 // The 256 accumulators are NOT C++ values: left to the register allocator (MFMA builtin, "+a" pins, physical-register
 // pins -- all three built) they are renamed around the loop's back edge at a cost of 590-1,000 v_accvgpr moves per K-tile,
 // or spilled.  They live in fixed AGPRs that only the literal-register inline asm of gemm_quad_gen.h touches
-// (tools/gen_gemm_quad.py): zero-fill, one asm statement per MFMA (fragments come in as ordinary "v" operands, so the
-// compiler still places the s_waitcnt lgkmcnt for its own ds_reads), read-back per 64-column half for the C++ epilogues.
-// Fragments are fully double-buffered (a ds_read never targets a register an MFMA issued less than a K-step ago reads), and
-// program order IS issue order: a sched_barrier closes every group of four MFMAs + one LDS read (+ one DMA piece).
-// DEEP: the DMA pieces of K-tile p+2 are requested a K-step EARLIER.  A wave reads all 16 fragments of K-step (p, 1) behind
-// the first 16 MFMAs of K-step (p, 0); one more barrier a third of the way through that step says every wave has tile p in
-// registers, its LDS buffer is free, and the 16 pieces of tile p+2 go out under the rest of the step -- 1.35 K-tiles before
-// their wait (a counted vmcnt(16): the pieces of tile p+2 stay in flight) instead of 1.0.  For operands that stream from HBM
-// (c_proj: A is the 268 MB MLP hidden matrix, read once; the 8-wave kernel spends 15 % of that K-loop in vmcnt waits).
-template <int EPI, int DEEP = 0, int STAMP = 0>
-__global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
-                                                              const float* __restrict__ bias, void* __restrict__ out,
-                                                              int M, int N, int K, int n_tiles,
-                                                              const float* __restrict__ aux, int aux_i,
-                                                              void* __restrict__ aux2, int* __restrict__ guard) {
-    using namespace pr;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    [[maybe_unused]] unsigned long long t_entry = 0, t_loop0 = 0;
-    // stamped diagnostic builds 2..8 (timing only, results wrong): STAMP - 1 = bit mask of what the steady-state K-loop leaves
-    // out -- 1: the DMA pieces, 2: the fragment reads, 4: the per-K-tile wait + barrier
-    constexpr int DBG = STAMP > 1 ? STAMP - 1 : 0;
-    if constexpr (STAMP) t_entry = __builtin_amdgcn_s_memtime();
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int tm, tn;
-    const int m_tiles = gridDim.x / n_tiles;
-    if ((m_tiles & 7) == 0 && (n_tiles & 3) == 0) {              // same 8 x 4 supertiles per XCD, m fastest (see above)
+// (tools/gen_gemm_quad.py): one asm statement per MFMA (fragments come in as ordinary "v" operands, so the compiler still
+// places the s_waitcnt lgkmcnt for its own ds_reads; the first K-step of a tile starts the chains from the constant 0),
+// read-back per 64-column half for the C++ epilogues.  Fragments are fully double-buffered (a ds_read never targets a
+// register an MFMA issued less than a K-step ago reads), and program order IS issue order: a sched_barrier closes every gap.
+//
+// A K-step is 32 gaps (one behind every pair of MFMAs), each carrying at most ONE memory instruction: a 16x16x32 MFMA holds
+// the SIMD's vector issue for 8 of its 16 cycles and issue costs add (MI355X_MICROARCH.md, cycle constants), so a gap with
+// two LDS reads and a DMA piece overruns by their sum.  Measured with the stamped ablation builds (tools/stamp_quad.py,
+// cycles per K-tile; 2,099 for the MFMAs alone): 16 reads in 16 consecutive gaps +53; a DMA piece wants MORE room -- 16
+// pieces in 16 consecutive gaps +400, in every other gap (one per four MFMAs) +140; everything in clusters of two reads
+// + one piece per four MFMAs (the first build) +313.  So:
+//   a step WITHOUT DMA pieces: its 16 reads in gaps 0-15 (they read the buffer the next step's pieces overwrite: done early,
+//     the wait before that step's barrier finds them finished);
+//   a step WITH the 16 pieces: piece i in gap 2i, read i in gap 2i+1, the X fragments first and W fragment j (first used by
+//     the next step's MFMA 8j) last.                                                      -> 2,230-2,250 cycles per K-tile
+// group g = eight MFMAs = gaps 4g..4g+3.  KEDS_QUAD_ORDER 0: X fragment g against the eight W fragments (SrcB constant, SrcA
+// cycling); 1: W fragment g against the eight X fragments (SrcA constant over eight MFMAs, the vendor kernel's order)
+#ifndef KEDS_QUAD_ORDER
+#define KEDS_QUAD_ORDER 1
+#endif
+#define KEDS_QMFMA(FIRST, j, mi, wc, xc)                                                                       \
+    if constexpr (FIRST) {                                                                                     \
+        if constexpr (epi_f16(EPI)) { KEDS_QUAD_MFMAZ_##j##_##mi("v_mfma_f32_16x16x32_f16", wc[j], xc[mi]) }   \
+        else { KEDS_QUAD_MFMAZ_##j##_##mi("v_mfma_f32_16x16x32_bf16", wc[j], xc[mi]) }                         \
+    } else {                                                                                                   \
+        if constexpr (epi_f16(EPI)) { KEDS_QUAD_MFMA_##j##_##mi("v_mfma_f32_16x16x32_f16", wc[j], xc[mi]) }    \
+        else { KEDS_QUAD_MFMA_##j##_##mi("v_mfma_f32_16x16x32_bf16", wc[j], xc[mi]) }                          \
+    }
+#if KEDS_QUAD_ORDER == 0
+#define KEDS_QG2(FIRST, g_, a_, b_, wc, xc) KEDS_QMFMA(FIRST, a_, g_, wc, xc) KEDS_QMFMA(FIRST, b_, g_, wc, xc)
+#else
+#define KEDS_QG2(FIRST, g_, a_, b_, wc, xc) KEDS_QMFMA(FIRST, g_, a_, wc, xc) KEDS_QMFMA(FIRST, g_, b_, wc, xc)
+#endif
+// read #r of the next K-step's fragments: X fragments 0-7, then W fragments 0-7
+#define KEDS_QRD(r_, xn, wn_, nb, nslot)                                                                       \
+    if constexpr ((r_) < 8) xn[(r_) & 7] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + ((r_) & 7) * 2048); \
+    else wn_[(r_) & 7] = *reinterpret_cast<const bf16x8*>((nb) + wrow + (nslot) + ((r_) & 7) * 2048);
+// gap n (0..31) of a step
+#define KEDS_QGAP(n_, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                                 \
+    if constexpr (ISSUE) {                                                                                     \
+        if constexpr (((n_) & 1) == 0) {                                                                       \
+            if constexpr (!(DBG & 1)) issue((ip), (n_) >> 1);                                                  \
+        } else if constexpr (PREFETCH && !(DBG & 2)) {                                                         \
+            KEDS_QRD((n_) >> 1, xn, wn_, nb, nslot)                                                            \
+        }                                                                                                      \
+    } else if constexpr (PREFETCH && (n_) < 16 && !(DBG & 2)) {                                                \
+        KEDS_QRD(n_, xn, wn_, nb, nslot)                                                                       \
+    }                                                                                                          \
+    __builtin_amdgcn_sched_barrier(0);
+#define KEDS_QUAD_GROUP(FIRST, mi, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                            \
+    KEDS_QG2(FIRST, mi, 0, 1, wc, xc) KEDS_QGAP(4 * (mi), xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)             \
+    KEDS_QG2(FIRST, mi, 2, 3, wc, xc) KEDS_QGAP(4 * (mi) + 1, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)         \
+    KEDS_QG2(FIRST, mi, 4, 5, wc, xc) KEDS_QGAP(4 * (mi) + 2, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)         \
+    KEDS_QG2(FIRST, mi, 6, 7, wc, xc) KEDS_QGAP(4 * (mi) + 3, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)
+// One K-step: 64 MFMAs from (xc, wc); the 16 fragment reads of the NEXT K-step go to (xn, wn_) from buffer `nb` at chunk
+// offset `nslot`; with ISSUE the 16 DMA pieces of K-tile `ip` go out; SYNC: K-tile landed + buffer free (wait + barrier).
+#define KEDS_QUAD_STEP(FIRST, xc, wc, xn, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                           \
+    {                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        if constexpr (SYNC && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                                     \
+        KEDS_QUAD_GROUP(FIRST, 0, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+        KEDS_QUAD_GROUP(FIRST, 1, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+        KEDS_QUAD_GROUP(FIRST, 2, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+        KEDS_QUAD_GROUP(FIRST, 3, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+        KEDS_QUAD_GROUP(FIRST, 4, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+        KEDS_QUAD_GROUP(FIRST, 5, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+        KEDS_QUAD_GROUP(FIRST, 6, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+        KEDS_QUAD_GROUP(FIRST, 7, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
+    }
+
+namespace qd {
+constexpr int SIDE0 = pr::SIDE_OFF;                 // two side areas (tile i uses i & 1) ...
+constexpr int RED_OFF = pr::SIDE_OFF + 2 * 4096;    // ... and 8 KiB for the statistics pre-reduction of the residual epilogue
+constexpr int LDS_BYTES = RED_OFF + 8192;           // 144 KiB
+}  // namespace qd
+
+// logical tile id -> (tm, tn): the 8 x 4 supertiles per XCD of the 8-wave kernel, m fastest
+__device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_tiles, int& tm, int& tn) {
+    if ((m_tiles & 7) == 0 && (n_tiles & 3) == 0) {
         const int grp = bid >> 5, within = bid & 31;
         const int grows = m_tiles >> 3;
         const int gn = grp / grows, gm = grp - gn * grows;
@@ -1119,7 +1176,28 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         tm = bid / n_tiles;
         tn = bid - tm * n_tiles;
     }
-    const int m0 = tm * TM, n0 = tn * TN;
+}
+
+// PERSIST: gridDim.x workgroups (one per CU) walk the tiles id = blockIdx.x, + gridDim.x, ... (the ids the dispatcher would
+// have dealt them, so the XCD grouping of the walk is unchanged).  Behind a tile's K-loop and one barrier the workgroup
+// requests the NEXT tile's first two K-tiles (and has fetched its row statistics / bias slices during the K-loop), THEN runs
+// this tile's epilogue: the 5 k cycles of prologue latency, the store drain and the gap between workgroups lie under the
+// 10 k cycles of epilogue.  The 8-wave kernel could not do this (round 1-2: at 256 VGPRs the tile loop spilled); here the
+// accumulators are outside the allocator's view and the wave has ~90 VGPRs to spare.
+template <int EPI, int STAMP = 0, int PERSIST = 0>
+__global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                              const float* __restrict__ bias, void* __restrict__ out,
+                                                              int M, int N, int K, int n_tiles,
+                                                              const float* __restrict__ aux, int aux_i,
+                                                              void* __restrict__ aux2, int* __restrict__ guard, int ntiles) {
+    using namespace pr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    [[maybe_unused]] unsigned long long t_entry = 0, t_loop0 = 0;
+    // stamped diagnostic builds 2..8 (timing only, results wrong): STAMP - 1 = bit mask of what the steady-state K-loop leaves
+    // out -- 1: the DMA pieces, 2: the fragment reads, 4: the per-K-tile wait + barrier
+    constexpr int DBG = STAMP > 1 ? STAMP - 1 : 0;
+    if constexpr (STAMP) t_entry = __builtin_amdgcn_s_memtime();
+    const int m_tiles = ntiles / n_tiles;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn2 = wave & 1, wm = wave >> 1;
@@ -1128,17 +1206,17 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     // ---- staging: piece j (8 LDS rows = 1 KiB) of an operand; this wave owns pieces wave + 4 i (rows + 32 i), i < 8
     const int R0 = 8 * wave + (lane >> 3);                        // 0..31
     const int sch = (lane & 7) ^ swz_f(R0);                        // swz_f(R0 + 32 i) == swz_f(R0)
-    const char* xt = reinterpret_cast<const char*>(X + (size_t)m0 * K);
-    const char* wt = reinterpret_cast<const char*>(W + (size_t)n0 * K);
     const unsigned xoff = (unsigned)R0 * (unsigned)K * 2u + sch * 16;
     const unsigned woff = (unsigned)perm_w(R0) * (unsigned)K * 2u + sch * 16;   // perm_w(R0 + 32 i) == perm_w(R0) + 32 i
     const unsigned rstride = 32u * (unsigned)K * 2u;              // 32 rows further down
     // LDS-DMA in its buffer form (`buffer_load_dwordx4 v_lane, s[rsrc], s_off offen lds`): the lane part of the address is
-    // ONE loop-invariant VGPR per operand, the piece / K-tile part a scalar -- no vector add per piece (the global_load_lds
-    // form of the 8-wave kernel spends one v_add per piece: 32 vector-issue slots per K-tile on a SIMD whose issue port is
-    // what the K-loop is bound by, see the stamps in DESIGN.md section 5)
-    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(xt), 0, 0x7FFFFFFF, 0x00020000);
-    const auto wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(wt), 0, 0x7FFFFFFF, 0x00020000);
+    // ONE loop-invariant VGPR per operand, the piece / K-tile part a scalar -- no vector add per piece
+    // (a macro, not a lambda: a lambda RETURNING the descriptor type makes hipcc 7.2 drop the kernel's host-side stub without
+    // a diagnostic -- every instantiation then links as an undefined symbol)
+#define make_rs(base) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(base)), 0, 0x7FFFFFFF, 0x00020000)
+    // (xrs / wrs: buffer descriptors of the CURRENT tile's operand panels; re-pointed at the next tile once this tile's last
+    // piece has been requested)
+    auto xrs = make_rs(X), wrs = make_rs(W);
     auto issue = [&](int p, int q) {                               // DMA piece q (0..15: X pieces 0..7, W pieces 0..7) of K-tile p
         const int i = q & 7;
         char* dst = smem + (p & 1) * PBUF_BYTES + (q < 8 ? 0 : OP_BYTES) + (wave + 4 * i) * 1024;
@@ -1152,217 +1230,177 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
     const int xrow = (128 * wm + c) * 128;                         // + mi * 2048
     const int wrow = OP_BYTES + (128 * wn2 + c) * 128;             // + j * 2048, j = 4 h + ni
-
-    KEDS_QUAD_ZERO_ALL
-
     const int np = K / TK;                                         // >= 2
-    // LN epilogues: row t's statistics and column t's bias' / column sum per thread, fetched BEFORE the DMA pieces
+    const int step = PERSIST ? (int)gridDim.x : ntiles;            // (not persistent: one tile per workgroup)
+
+    // side data of a tile: row t's LayerNorm statistics and column t's bias' / column sum (LN epilogues), column t's bias
+    // (residual epilogue), one element per thread, requested with inline-asm loads (the compiler would wait vmcnt(0) for a
+    // plain load at its first use, i.e. also for every DMA piece in flight) and turned into the LDS side area later
     [[maybe_unused]] u32x4 st_raw = u32x4{0, 0, 0, 0};
     [[maybe_unused]] float pb = 0.f, pc = 0.f;
-    if constexpr (epi_is_ln(EPI)) {
-        const keds_stat_t* sp = reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)(m0 + tid);
-        const float* bp = bias + n0 + tid;
-        const float* cp = bp + N;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st_raw) : "v"(sp) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
-        asm volatile("global_load_dword %0, %1, off" : "=v"(pc) : "v"(cp) : "memory");
-    }
-    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
-        if (bias) {
-            const float* bp = bias + n0 + tid;
+    auto side_request = [&](int m0_, int n0_) {
+        if constexpr (epi_is_ln(EPI)) {
+            const keds_stat_t* sp = reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)(m0_ + tid);
+            const float* bp = bias + n0_ + tid;
+            const float* cp = bp + N;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(st_raw) : "v"(sp) : "memory");
             asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+            asm volatile("global_load_dword %0, %1, off" : "=v"(pc) : "v"(cp) : "memory");
         }
-    }
+        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+            if (bias) {
+                const float* bp = bias + n0_ + tid;
+                asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+            }
+        }
+    };
+    auto side_write = [&](char* side, int n0_) {                   // (the requested values have landed: caller waited)
+        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) *reinterpret_cast<float*>(side + 2048 + tid * 4) = pb;
+        if constexpr (epi_is_ln(EPI)) {
+            float rs, nm;
+            ln_coeff_from((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0]),
+                          (keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]), 1.0f / (float)K, rs, nm,
+                          n0_ == 0 ? guard : nullptr);
+            *reinterpret_cast<f32x2*>(side + tid * 8) = f32x2{rs, nm};
+            *reinterpret_cast<float*>(side + 2048 + tid * 4) = pb;
+            *reinterpret_cast<float*>(side + 3072 + tid * 4) = pc;
+        }
+    };
+
+    int id = blockIdx.x;
+    int tm, tn;
+    quad_tile_coords(xcd_remap(id, ntiles), m_tiles, n_tiles, tm, tn);
+    int m0 = tm * TM, n0 = tn * TN;
+    xrs = make_rs(X + (size_t)m0 * K);
+    wrs = make_rs(W + (size_t)n0 * K);
+    side_request(m0, n0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) issue(0, q);
 #pragma unroll
     for (int q = 0; q < 16; ++q) issue(1, q);
-    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
-        asm volatile("s_waitcnt vmcnt(32)" : "+v"(pb)::"memory");
-        *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + tid * 4) = pb;
-    }
-    if constexpr (epi_is_ln(EPI)) {
-        asm volatile("s_waitcnt vmcnt(32)" : "+v"(st_raw), "+v"(pb), "+v"(pc)::"memory");
-        float rs, nm;
-        ln_coeff_from((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0]),
-                      (keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]), 1.0f / (float)K, rs, nm,
-                      n0 == 0 ? guard : nullptr);
-        *reinterpret_cast<f32x2*>(smem + SIDE_OFF + tid * 8) = f32x2{rs, nm};
-        *reinterpret_cast<float*>(smem + SIDE_OFF + 2048 + tid * 4) = pb;
-        *reinterpret_cast<float*>(smem + SIDE_OFF + 3072 + tid * 4) = pc;
-    }
+    if constexpr (epi_is_ln(EPI)) asm volatile("s_waitcnt vmcnt(32)" : "+v"(st_raw), "+v"(pb), "+v"(pc)::"memory");
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) asm volatile("s_waitcnt vmcnt(32)" : "+v"(pb)::"memory");
+    side_write(smem + qd::SIDE0, n0);
     asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
-    bf16x8 xa[8], wa[8], xb[8], wb[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(smem + wrow + slot0 + j * 2048);
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(smem + xrow + slot0 + mi * 2048);
 
-    // One K-step: 64 MFMAs from (xc, wc); the 16 fragment reads of the NEXT K-step go to (xn, wn_) from buffer `nb` at chunk
-    // offset `nslot`; with ISSUE the 16 DMA pieces of K-tile `ip` follow.  Group mi = X fragment mi against the eight W
-    // fragments, in two halves of four MFMAs with one LDS read (and one DMA piece) behind each: the wave is alone on its
-    // SIMD, so what stands between two MFMAs issues in the 16 cycles the matrix pipe is busy with the first.
-#define KEDS_QMFMA(j, mi, wc, xc)                                                                              \
-    if constexpr (epi_f16(EPI)) { KEDS_QUAD_MFMA_##j##_##mi("v_mfma_f32_16x16x32_f16", wc[j], xc[mi]) }        \
-    else { KEDS_QUAD_MFMA_##j##_##mi("v_mfma_f32_16x16x32_bf16", wc[j], xc[mi]) }
-// (all 16 fragment reads of the next K-step sit in the FIRST half of the step, two behind each group of four MFMAs: the step
-// that consumes them opens with s_waitcnt lgkmcnt(0), and a read issued four MFMAs before that wait stalls the only wave
-// of the SIMD for its whole LDS latency)
-// group g = eight MFMAs.  KEDS_QUAD_ORDER 0: X fragment g against the eight W fragments (SrcB constant, SrcA cycling);
-// 1: W fragment g against the eight X fragments (SrcA constant over eight MFMAs, the order the vendor's kernel issues in)
-#ifndef KEDS_QUAD_ORDER
-#define KEDS_QUAD_ORDER 1
-#endif
-#if KEDS_QUAD_ORDER == 0
-#define KEDS_QG4A(g_, wc, xc) KEDS_QMFMA(0, g_, wc, xc) KEDS_QMFMA(1, g_, wc, xc) KEDS_QMFMA(2, g_, wc, xc) KEDS_QMFMA(3, g_, wc, xc)
-#define KEDS_QG4B(g_, wc, xc) KEDS_QMFMA(4, g_, wc, xc) KEDS_QMFMA(5, g_, wc, xc) KEDS_QMFMA(6, g_, wc, xc) KEDS_QMFMA(7, g_, wc, xc)
-#else
-#define KEDS_QG4A(g_, wc, xc) KEDS_QMFMA(g_, 0, wc, xc) KEDS_QMFMA(g_, 1, wc, xc) KEDS_QMFMA(g_, 2, wc, xc) KEDS_QMFMA(g_, 3, wc, xc)
-#define KEDS_QG4B(g_, wc, xc) KEDS_QMFMA(g_, 4, wc, xc) KEDS_QMFMA(g_, 5, wc, xc) KEDS_QMFMA(g_, 6, wc, xc) KEDS_QMFMA(g_, 7, wc, xc)
-#endif
-#define KEDS_QUAD_GROUP(mi, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                   \
-    KEDS_QG4A(mi, wc, xc)                                                                                      \
-    if constexpr (PREFETCH && (mi) < 4 && !(DBG & 2)) {                                                        \
-        wn_[2 * (mi)] = *reinterpret_cast<const bf16x8*>((nb) + wrow + (nslot) + (2 * (mi)) * 2048);           \
-        wn_[2 * (mi) + 1] = *reinterpret_cast<const bf16x8*>((nb) + wrow + (nslot) + (2 * (mi) + 1) * 2048);   \
-    }                                                                                                          \
-    if constexpr (ISSUE && !(DBG & 1)) issue((ip), 2 * mi);                                                    \
-    __builtin_amdgcn_sched_barrier(0);                                                                         \
-    KEDS_QG4B(mi, wc, xc)                                                                                      \
-    if constexpr (PREFETCH && (mi) < 4 && !(DBG & 2)) {                                                        \
-        xn[2 * (mi)] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + (2 * (mi)) * 2048);            \
-        xn[2 * (mi) + 1] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + (2 * (mi) + 1) * 2048);    \
-    }                                                                                                          \
-    if constexpr (ISSUE && !(DBG & 1)) issue((ip), 2 * mi + 1);                                                \
-    __builtin_amdgcn_sched_barrier(0);
-#define KEDS_QUAD_STEP(xc, wc, xn, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                                  \
-    {                                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr (SYNC && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-        __builtin_amdgcn_sched_barrier(0);                                                                     \
-        KEDS_QUAD_GROUP(0, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-        KEDS_QUAD_GROUP(1, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-        KEDS_QUAD_GROUP(2, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-        KEDS_QUAD_GROUP(3, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-        KEDS_QUAD_GROUP(4, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-        KEDS_QUAD_GROUP(5, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-        KEDS_QUAD_GROUP(6, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-        KEDS_QUAD_GROUP(7, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                    \
-    }
-
-    // DEEP form of K-step (p, 0) with tile p+2 to request: all 16 fragment reads of (p, 1) behind the first 16 MFMAs, eight
-    // plain MFMAs while they return, "buffer free" barrier, then the 16 DMA pieces under the remaining 40 MFMAs.
-#define KEDS_QD_HALF_(ja, jb, jc, jd, mi, xc, wc, R0_, R1_, R2_, R3_)                                          \
-    KEDS_QMFMA(ja, mi, wc, xc) R0_ KEDS_QMFMA(jb, mi, wc, xc) R1_                                              \
-    KEDS_QMFMA(jc, mi, wc, xc) R2_ KEDS_QMFMA(jd, mi, wc, xc) R3_                                              \
-    __builtin_amdgcn_sched_barrier(0);
-#define KEDS_QD_HALF_0(mi, xc, wc, R0_, R1_, R2_, R3_) KEDS_QD_HALF_(0, 1, 2, 3, mi, xc, wc, R0_, R1_, R2_, R3_)
-#define KEDS_QD_HALF_4(mi, xc, wc, R0_, R1_, R2_, R3_) KEDS_QD_HALF_(4, 5, 6, 7, mi, xc, wc, R0_, R1_, R2_, R3_)
-#define KEDS_QD_HALF(j0, mi, xc, wc, R0_, R1_, R2_, R3_) KEDS_QD_HALF_##j0(mi, xc, wc, R0_, R1_, R2_, R3_)
-#define KEDS_QD_RW(j) wb[j] = *reinterpret_cast<const bf16x8*>(cb + wrow + slot1 + (j) * 2048);
-#define KEDS_QD_RX(j) xb[j] = *reinterpret_cast<const bf16x8*>(cb + xrow + slot1 + (j) * 2048);
-#define KEDS_QD_I(q) issue(p + 2, q);
-    int p = 0;
-    for (; p + 2 < np; ++p) {                                      // steady state: tile p+2 exists
-        const char* cb = smem + (p & 1) * PBUF_BYTES;               // buffer of tile p
-        const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;         // buffer of tile p+1
-        if constexpr (DEEP) {
-            __builtin_amdgcn_sched_barrier(0);
-            KEDS_QD_HALF(0, 0, xa, wa, KEDS_QD_RW(0), KEDS_QD_RW(1), KEDS_QD_RW(2), KEDS_QD_RW(3))
-            KEDS_QD_HALF(4, 0, xa, wa, KEDS_QD_RW(4), KEDS_QD_RW(5), KEDS_QD_RW(6), KEDS_QD_RW(7))
-            KEDS_QD_HALF(0, 1, xa, wa, KEDS_QD_RX(0), KEDS_QD_RX(1), KEDS_QD_RX(2), KEDS_QD_RX(3))
-            KEDS_QD_HALF(4, 1, xa, wa, KEDS_QD_RX(4), KEDS_QD_RX(5), KEDS_QD_RX(6), KEDS_QD_RX(7))
-            KEDS_QD_HALF(0, 2, xa, wa, , , , )
-            KEDS_QD_HALF(4, 2, xa, wa, , , , )
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave holds tile p in registers
-            __builtin_amdgcn_sched_barrier(0);
-            KEDS_QD_HALF(0, 3, xa, wa, KEDS_QD_I(0), , KEDS_QD_I(1), )
-            KEDS_QD_HALF(4, 3, xa, wa, KEDS_QD_I(2), , KEDS_QD_I(3), )
-            KEDS_QD_HALF(0, 4, xa, wa, KEDS_QD_I(4), , KEDS_QD_I(5), )
-            KEDS_QD_HALF(4, 4, xa, wa, KEDS_QD_I(6), , KEDS_QD_I(7), )
-            KEDS_QD_HALF(0, 5, xa, wa, KEDS_QD_I(8), , KEDS_QD_I(9), )
-            KEDS_QD_HALF(4, 5, xa, wa, KEDS_QD_I(10), , KEDS_QD_I(11), )
-            KEDS_QD_HALF(0, 6, xa, wa, KEDS_QD_I(12), , , )
-            KEDS_QD_HALF(4, 6, xa, wa, KEDS_QD_I(13), , , )
-            KEDS_QD_HALF(0, 7, xa, wa, KEDS_QD_I(14), , , )
-            KEDS_QD_HALF(4, 7, xa, wa, KEDS_QD_I(15), , , )
-            // K-step (p, 1): tile p+1 has landed for every wave (the 16 pieces of tile p+2 stay in flight)
-            asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-            KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, false, false, 0, true)
-        } else {
-            KEDS_QUAD_STEP(xa, wa, xb, wb, cb, slot1, false, false, 0, true)          // K-step 2p
-            KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, true, true, p + 2, true)       // K-step 2p+1
+    for (int it = 0;; ++it) {
+        char* side = smem + qd::SIDE0 + (it & 1) * 4096;
+        if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
+        // next tile of this workgroup (PERSIST)
+        const int nid = id + step;
+        const bool more = PERSIST && nid < ntiles;
+        int nm0 = 0, nn0 = 0;
+        if (more) {
+            int ntm, ntn;
+            quad_tile_coords(xcd_remap(nid, ntiles), m_tiles, n_tiles, ntm, ntn);
+            nm0 = ntm * TM;
+            nn0 = ntn * TN;
         }
-    }
-#undef KEDS_QD_HALF
-#undef KEDS_QD_HALF_
-#undef KEDS_QD_HALF_0
-#undef KEDS_QD_HALF_4
-#undef KEDS_QD_RW
-#undef KEDS_QD_RX
-#undef KEDS_QD_I
-    {                                                              // tile np-2: nothing left to issue
-        const char* cb = smem + (p & 1) * PBUF_BYTES;
-        const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;
-        KEDS_QUAD_STEP(xa, wa, xb, wb, cb, slot1, false, false, 0, true)
-        KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, true, false, 0, true)
-        KEDS_QUAD_STEP(xa, wa, xb, wb, ob, slot1, false, false, 0, true)          // tile np-1
-        KEDS_QUAD_STEP(xb, wb, xa, wa, ob, slot0, false, false, 0, false)
-    }
-#undef KEDS_QUAD_STEP
-#undef KEDS_QUAD_GROUP
-#undef KEDS_QMFMA
+        bf16x8 xa[8], wa[8], xb[8], wb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(smem + wrow + slot0 + j * 2048);
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(smem + xrow + slot0 + mi * 2048);
 
-    // ---- epilogues: the 8-wave kernel's, once per 64-column half (wave column 2 wn2 + h) read back from its AGPRs
-    [[maybe_unused]] unsigned long long t_loop1 = 0;
-    if constexpr (STAMP) t_loop1 = __builtin_amdgcn_s_memtime();
-    [[maybe_unused]] void* stamp_out = aux2;
-    if constexpr (STAMP) aux2 = nullptr;                              // (stamped build: aux2 carries the stamp buffer)
-    KEDS_QUAD_DRAIN
-    f32x4 av[4][8];
-    [[maybe_unused]] keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
-    [[maybe_unused]] char* red = smem + (np & 1) * PBUF_BYTES;
+        // K-steps (0,0) | [(p,1) (p+1,0)] for p < np-2 | (np-2,1) (np-1,0) (np-1,1)
+        KEDS_QUAD_STEP(true, xa, wa, xb, wb, smem, slot1, false, false, 0, true)
+        int p = 0;
+        for (; p + 2 < np; ++p) {                                      // steady state: tile p+2 exists
+            const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;         // buffer of K-tile p+1
+            KEDS_QUAD_STEP(false, xb, wb, xa, wa, ob, slot0, true, true, p + 2, true)       // K-step (p, 1)
+            KEDS_QUAD_STEP(false, xa, wa, xb, wb, ob, slot1, false, false, 0, true)         // K-step (p+1, 0)
+        }
+        {
+            const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;
+            KEDS_QUAD_STEP(false, xb, wb, xa, wa, ob, slot0, true, false, 0, true)          // K-step (np-2, 1)
+            KEDS_QUAD_STEP(false, xa, wa, xb, wb, ob, slot1, false, false, 0, true)         // K-step (np-1, 0)
+            KEDS_QUAD_STEP(false, xb, wb, xa, wa, ob, slot0, false, false, 0, false)        // K-step (np-1, 1)
+        }
+
+        [[maybe_unused]] unsigned long long t_loop1 = 0;
+        if constexpr (STAMP) t_loop1 = __builtin_amdgcn_s_memtime();
+        if (more) {
+            // every wave has its last fragments in registers: both operand buffers are free for the next tile's K-tiles 0, 1
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            // the next tile's side data: PLAIN loads (the compiler tracks them, so a register it spills during the epilogue
+            // is spilled after its data arrived -- an inline-asm load in flight across the epilogue would not be), used after
+            // the epilogue
+            if constexpr (epi_is_ln(EPI)) {
+                st_raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)(nm0 + tid));
+                pb = bias[nn0 + tid];
+                pc = bias[N + nn0 + tid];
+            }
+            if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) pb = bias ? bias[nn0 + tid] : 0.f;
+            xrs = make_rs(X + (size_t)nm0 * K);
+            wrs = make_rs(W + (size_t)nn0 * K);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) issue(0, q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) issue(1, q);
+        }
+
+        // ---- epilogues: the 8-wave kernel's, once per 64-column half (wave column 2 wn2 + h) read back from its AGPRs
+        [[maybe_unused]] void* stamp_out = aux2;
+        void* aux2e = STAMP ? nullptr : aux2;                             // (stamped build: aux2 carries the stamp buffer)
+        KEDS_QUAD_DRAIN
+        f32x4 av[4][8];
+        [[maybe_unused]] keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
+        [[maybe_unused]] char* red = smem + qd::RED_OFF;
 #define KEDS_QUAD_EPI(h)                                                                                               \
     if constexpr (epi_is_ln(EPI))                                                                                      \
-        pair_ln_epilogue<EPI, 0>(av, smem + SIDE_OFF, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2);                    \
+        pair_ln_epilogue<EPI, 0>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e);                              \
     else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)                                                                \
-        pair_resid_epilogue<0, false>(av, smem + SIDE_OFF, out, m0, n0, N, wm, 2 * wn2 + h, g, c, stats, red);         \
+        pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, stats, red);                    \
     else                                                                                                               \
-        tile_epilogue<EPI, 8>(av, bias, out, m0 + 128 * wm + c, M, n0 + 64 * (2 * wn2 + h) + 8 * g, N, K, aux, aux_i, aux2, N, g == 0);
-    KEDS_QUAD_READ_HALF0(av)
-    KEDS_QUAD_EPI(0)
-    __builtin_amdgcn_sched_barrier(0);
-    KEDS_QUAD_READ_HALF1(av)
-    KEDS_QUAD_EPI(1)
+        tile_epilogue<EPI, 8>(av, bias, out, m0 + 128 * wm + c, M, n0 + 64 * (2 * wn2 + h) + 8 * g, N, K, aux, aux_i, aux2e, N, g == 0);
+        KEDS_QUAD_READ_HALF0(av)
+        KEDS_QUAD_EPI(0)
+        __builtin_amdgcn_sched_barrier(0);
+        KEDS_QUAD_READ_HALF1(av)
+        KEDS_QUAD_EPI(1)
 #undef KEDS_QUAD_EPI
-    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
-        if (stats) {                                                    // kernel-uniform
-            __syncthreads();
-            const f32x2* rr = reinterpret_cast<const f32x2*>(red) + tid;
-            const f32x2 a = rr[0], b = rr[256], c2 = rr[512], d = rr[768];
-            keds_stat_add(stats + 2 * (size_t)(m0 + tid), (a[0] + b[0]) + (c2[0] + d[0]), (a[1] + b[1]) + (c2[1] + d[1]));
+        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+            if (stats) {                                                    // kernel-uniform
+                __syncthreads();
+                const f32x2* rr = reinterpret_cast<const f32x2*>(red) + tid;
+                const f32x2 a = rr[0], b = rr[256], c2 = rr[512], d = rr[768];
+                keds_stat_add(stats + 2 * (size_t)(m0 + tid), (a[0] + b[0]) + (c2[0] + d[0]), (a[1] + b[1]) + (c2[1] + d[1]));
+            }
         }
-    }
-    if constexpr (STAMP) {                                           // same record layout as the 8-wave kernel's stamped build
-        const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned long long t_end = __builtin_amdgcn_s_memtime();
-        if (lane == 0) {
-            unsigned long long* o = reinterpret_cast<unsigned long long*>(stamp_out) + ((size_t)blockIdx.x * 8 + wave) * 8;
-            o[0] = t_loop0 - t_entry;
-            o[1] = t_loop1 - t_loop0;
-            o[2] = t_issued - t_loop1;
-            o[3] = 0;
-            o[4] = 0;
-            o[5] = t_end - t_issued;
-            o[6] = t_entry;
-            o[7] = t_end;
-            unsigned long long* o2 = reinterpret_cast<unsigned long long*>(stamp_out) + (size_t)gridDim.x * 64 + (size_t)blockIdx.x * 8 + wave;
-            *o2 = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+        if constexpr (STAMP) {                                           // same record layout as the 8-wave kernel's stamped build
+            const unsigned long long t_issued = __builtin_amdgcn_s_memtime();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+            if (lane == 0) {
+                unsigned long long* o = reinterpret_cast<unsigned long long*>(stamp_out) + ((size_t)blockIdx.x * 8 + wave) * 8;
+                o[0] = t_loop0 - t_entry;
+                o[1] = t_loop1 - t_loop0;
+                o[2] = t_issued - t_loop1;
+                o[3] = 0;
+                o[4] = 0;
+                o[5] = t_end - t_issued;
+                o[6] = t_entry;
+                o[7] = t_end;
+                unsigned long long* o2 = reinterpret_cast<unsigned long long*>(stamp_out) + (size_t)ntiles * 64 + (size_t)blockIdx.x * 8 + wave;
+                *o2 = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+            }
         }
+        if (!more) break;
+        // the next tile: its side data and its K-tile 0 are on the way since before the epilogue
+        id = nid;
+        m0 = nm0;
+        n0 = nn0;
+        side_write(smem + qd::SIDE0 + ((it + 1) & 1) * 4096, n0);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
+#undef make_rs
+#undef KEDS_QUAD_STEP
+#undef KEDS_QUAD_GROUP
+#undef KEDS_QG2
+#undef KEDS_QGAP
+#undef KEDS_QRD
+#undef KEDS_QMFMA
 
 // NOTE (measured twice in round 1): a PERSISTENT form of this kernel does not pay.  Second attempt, with the fp16 residual
 // stream and the LDS-staged LN epilogue in place: one workgroup per CU walks its tiles; before the LAST K-step of a tile
@@ -1410,8 +1448,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
 // chip can power, not by its schedule: idle cycles removed come back as clock.  Not kept.
 
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
-// 256^2 tiles on the 4-wave kernel: -1 = by shape (quad_by_shape), 0 = never, 1 = always, 2 = always, early-DMA form
-// (bits 11-12 of keds_gemm_force_small's argument force 1 / 2; KEDS_GEMM_QUAD=0/1 in the environment overrides the default)
+// 256^2 tiles on the 4-wave kernel: -1 = by shape (quad_by_shape: persistent form), 0 = never, 1 = always, one tile per
+// workgroup, 2 = always, persistent (one workgroup per CU walks the tiles, next tile's first K-tiles under the epilogue)
+// (bits 11-12 of keds_gemm_force_small's argument force 1 / 2, 3 = never; KEDS_GEMM_QUAD=0/1/2 in the environment overrides
+// the default)
 int g_quad = -1;
 int quad_env() {
     static int v = -2;
@@ -1421,12 +1461,14 @@ int quad_env() {
     }
     return v;
 }
-// Same-process A/B on the ViT-L/14 shapes (tools/ab_quad.py, medians of 5 x 20 launches, round 3): the 4-wave kernel wins
-// where the K-loop dominates the tile (qkv +2.8 %, c_proj +3.5 %) and loses where the epilogue does (out-proj -4 %: one wave
-// per SIMD runs the whole read-modify-write epilogue with nothing beside it; c_fc -0.5 %).
+// Same-process A/B on the ViT-L/14 shapes at B = 128 (tools/ab_quad.py, medians of 5 x 20 launches, round 3; 8 waves /
+// 4 waves / 4 waves persistent, us): qkv 189.4 / 184.1 / 179.2, c_fc 243.6 / 239.5 / 236.3, c_proj 216.3 / 214.7 / (212.5),
+// out-proj 66.3 / 67.7 / -- : the 4-wave kernel wins where the K-loop dominates the tile and its persistent form where the
+// LayerNorm epilogues (no loads of their own) leave registers for the tile loop; out-proj (K = 1024, a tile that is mostly
+// read-modify-write epilogue, which one wave per SIMD runs with nothing beside it) stays on the 8-wave kernel.
 template <int EPI>
 bool quad_by_shape(int N, int K) {
-    if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_LN_BIAS_BF16) return K >= 512;
+    if constexpr (epi_is_ln(EPI)) return K >= 512;
     if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) return K >= 2048;
     return false;
 }
@@ -1444,30 +1486,24 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
                int aux_i, void* aux2, hipStream_t st) {
     if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
     if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_RESID_STATS_F16) {
-        if (g_pair_stamp && g_quad > 0) {                                // stamped build of the 4-wave kernel
-            const dim3 grid((M / pr::TM) * (N / pr::TN));
-            if (g_quad == 2) {
-                (void)keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 1, 1>, pr::LDS_BYTES, "gemm_bt_quad_kernel<stamp>");
-                gemm_bt_quad_kernel<EPI, 1, 1><<<grid, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                               N / pr::TN, aux, aux_i, aux2, nullptr);
-            } else {
+        if (g_pair_stamp && g_quad > 0) {                            // stamped build of the 4-wave kernel
+            const int ntiles = (M / pr::TM) * (N / pr::TN);
 #define KEDS_QSTAMP(V)                                                                                              \
     {                                                                                                              \
-        (void)keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 0, V>, pr::LDS_BYTES, "gemm_bt_quad_kernel<stamp>"); \
-        gemm_bt_quad_kernel<EPI, 0, V><<<grid, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, \
-                                                                         N / pr::TN, aux, aux_i, aux2, nullptr);    \
+        (void)keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, V>, qd::LDS_BYTES, "gemm_bt_quad_kernel<stamp>"); \
+        gemm_bt_quad_kernel<EPI, V><<<ntiles, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, \
+                                                                        N / pr::TN, aux, aux_i, aux2, nullptr, ntiles); \
     }
-                switch (g_pair_stamp) {
-                    case 2: KEDS_QSTAMP(2) break;
-                    case 3: KEDS_QSTAMP(3) break;
-                    case 4: KEDS_QSTAMP(4) break;
-                    case 5: KEDS_QSTAMP(5) break;
-                    case 6: KEDS_QSTAMP(6) break;
-                    case 7: KEDS_QSTAMP(8) break;
-                    default: KEDS_QSTAMP(1) break;
-                }
-#undef KEDS_QSTAMP
+            switch (g_pair_stamp) {
+                case 2: KEDS_QSTAMP(2) break;
+                case 3: KEDS_QSTAMP(3) break;
+                case 4: KEDS_QSTAMP(4) break;
+                case 5: KEDS_QSTAMP(5) break;
+                case 6: KEDS_QSTAMP(6) break;
+                case 7: KEDS_QSTAMP(8) break;
+                default: KEDS_QSTAMP(1) break;
             }
+#undef KEDS_QSTAMP
             return keds_check_launch("gemm_bt_quad_kernel<stamp>");
         }
         if (g_pair_stamp) {
@@ -1491,17 +1527,23 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
     }
     const int m_tiles = M / pr::TM, n_tiles = N / pr::TN;         // M is a multiple of 256 here
     int quad = g_quad >= 0 ? g_quad : quad_env();
-    if (quad < 0) quad = quad_by_shape<EPI>(N, K) ? 1 : 0;
-    if (quad == 2) {
-        if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 1>, pr::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
-        gemm_bt_quad_kernel<EPI, 1><<<m_tiles * n_tiles, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N,
-                                                                                   K, n_tiles, aux, aux_i, aux2, keds_numerics_guard());
-        return keds_check_launch("gemm_bt_quad_kernel<deep>");
-    }
-    if (quad) {
-        if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI>, pr::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
-        gemm_bt_quad_kernel<EPI><<<m_tiles * n_tiles, 256, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N,
-                                                                                K, n_tiles, aux, aux_i, aux2, keds_numerics_guard());
+    if (quad < 0) quad = quad_by_shape<EPI>(N, K) ? 2 : 0;
+    if (quad) {                                   // 1: one tile per workgroup, 2: persistent (one workgroup per CU walks the tiles)
+        const int ntiles = m_tiles * n_tiles;
+        int cus = keds_device_cus();
+        if (cus > 256) cus = 256;
+        cus &= ~7;                                // whole XCD groups: workgroup b and tile ids b, b + grid, ... share an XCD label
+        // (the residual epilogue holds 16 residual chunks per lane beside the read-back accumulators: in the tile loop it spills,
+        // out-proj 94 vs 70 us -- that epilogue keeps one tile per workgroup)
+        if (quad == 2 && ntiles > cus && cus >= 8 && EPI != KEDS_EPI_RESID_STATS_F16) {
+            if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 0, 1>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
+            gemm_bt_quad_kernel<EPI, 0, 1><<<cus, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
+                                                                            n_tiles, aux, aux_i, aux2, keds_numerics_guard(), ntiles);
+            return keds_check_launch("gemm_bt_quad_kernel<persistent>");
+        }
+        if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
+        gemm_bt_quad_kernel<EPI><<<ntiles, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles,
+                                                                     aux, aux_i, aux2, keds_numerics_guard(), ntiles);
         return keds_check_launch("gemm_bt_quad_kernel");
     }
     if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
@@ -1569,7 +1611,7 @@ extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
-    g_quad = (on >> 11) & 3;            // bits 11-12: 256^2 tiles on the 4-wave kernel (1), its early-DMA form (2), 3 = never
+    g_quad = (on >> 11) & 3;            // bits 11-12: 256^2 tiles on the 4-wave kernel (1), its persistent form (2), 3 = never
     if (g_quad == 0) g_quad = -1;       // (0 = the default: by shape)
     if (g_quad == 3) g_quad = 0;
     g_resid_prologue = (on >> 10) & 1;  // bit 10: fp16-residual GEMMs take residual + bias as the accumulators' initial value (A/B)

@@ -540,13 +540,15 @@ def test_large_gallery_ranking_and_imgnet_metric(nq, ng):
         assert abs(v - mg[k]) <= 1.0 / nq + 1e-6, (k, v, mg[k])
 
 
-@pytest.mark.parametrize("K", [256, 1024])
-def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(K):
+@pytest.mark.parametrize("M,K", [(4096, 256), (4096, 1024), (8192 + 1024, 256), (12288, 512)])
+def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(M, K):
     """The 4-wave 256 x 256 kernel (round 3: one wave per SIMD, 128 x 128 outputs per wave, accumulators in fixed AGPRs) runs
     the same MFMA chains in the same k order and the same epilogues as the 8-wave kernel: every epilogue the towers use must
-    give the same bits (plain bias -> bf16, LayerNorm-folded bias / QuickGELU on fp16 operands, fp16 residual + statistics)."""
+    give the same bits (plain bias -> bf16, LayerNorm-folded bias / QuickGELU on fp16 operands, fp16 residual + statistics).
+    Its persistent form (one workgroup per CU walks the tiles; M > 4096 here: 2-3 tiles per workgroup, ragged last round)
+    must as well."""
     lib = _lib.load()
-    M, N = 4096, 4096                                            # 256 tiles of 256 x 256: the big-tile path
+    N = 4096                                                     # >= 256 tiles of 256 x 256: the big-tile path
     g = torch.Generator(device="cuda").manual_seed(K)
     x = torch.randn(M, K, generator=g, device="cuda") * 1.3 + 0.2
     w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
@@ -584,7 +586,7 @@ def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(K):
             return outs
         finally:
             lib.keds_gemm_force_small(0)
-    eight, four, deep = run(3 << 11), run(1 << 11), run(2 << 11)       # (2 << 11: the 4-wave kernel's early-DMA form)
+    eight, four, deep = run(3 << 11), run(1 << 11), run(2 << 11)       # (2 << 11: the 4-wave kernel's persistent form)
     want = xb.float() @ wb.float().t() + b
     assert rel_l2(four[0], want) <= 4e-3
     for a, c, d in zip(eight, four, deep):
