@@ -1125,10 +1125,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     if constexpr ((r_) < 8) xn[(r_) & 7] = *reinterpret_cast<const bf16x8*>((nb) + xrow + (nslot) + ((r_) & 7) * 2048); \
     else wn_[(r_) & 7] = *reinterpret_cast<const bf16x8*>((nb) + wrow + (nslot) + ((r_) & 7) * 2048);
 // gap n (0..31) of a step
+// (ISSUE: 0 / false = no DMA pieces in this step, 1 / true = all 16, 2 = pieces 0-7 only)
 #define KEDS_QGAP(n_, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                                                 \
     if constexpr (ISSUE) {                                                                                     \
         if constexpr (((n_) & 1) == 0) {                                                                       \
-            if constexpr (!(DBG & 1)) issue((ip), (n_) >> 1);                                                  \
+            if constexpr (!(DBG & 1) && ((int)(ISSUE) == 1 || (n_) < 16)) issue((ip), (n_) >> 1);              \
         } else if constexpr (PREFETCH && !(DBG & 2)) {                                                         \
             KEDS_QRD((n_) >> 1, xn, wn_, nb, nslot)                                                            \
         }                                                                                                      \
@@ -1394,6 +1395,148 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
 }
+// ---- the 4-wave kernel with a THREE-deep ring for the A operand (residual epilogue, long K: c_proj) --------------------
+// c_proj streams its A operand (the 268 MB MLP hidden matrix) from HBM exactly once; with two LDS buffers a K-tile's pieces are
+// requested one K-tile (~1.3 us) before they are needed, less than an HBM round trip under load, and the K-loop waits 9-16 % of
+// its time for them (stamps: 2,570-2,780 cycles per K-tile against 2,200 without the pieces; the 8-wave kernel's vm_wait is
+// 15-22 % of its loop).  Here LDS holds A in three buffers and W (8 MB for all tiles: L2-resident) in two -- 5 x 32 KiB, all
+// 160 KiB -- so A pieces go out TWO K-tiles ahead: step (p, 1) requests W of tile p+2 and A of tile p+3, and the wait of
+// step (p+1, 1) is a counted vmcnt(8) that leaves those eight A pieces in flight.  Bias slice and statistics scratch alias the
+// W ring after the K-loop.  One tile per workgroup.
+template <int EPI>
+__global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
+                                                               const float* __restrict__ bias, void* __restrict__ out,
+                                                               int M, int N, int K, int n_tiles,
+                                                               const float* __restrict__ aux, int ntiles) {
+    static_assert(EPI == KEDS_EPI_RESID_STATS_F16, "three-deep A ring: residual epilogue only");
+    using namespace pr;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DBG = 0;
+    constexpr int WRING = 3 * OP_BYTES;                               // A buffers at 0, 32, 64 KiB; W buffers at 96, 128 KiB
+    const int m_tiles = ntiles / n_tiles;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn2 = wave & 1, wm = wave >> 1;
+    const int g = lane >> 4, c = lane & 15;
+    const int R0 = 8 * wave + (lane >> 3);
+    const int sch = (lane & 7) ^ swz_f(R0);
+    const unsigned xoff = (unsigned)R0 * (unsigned)K * 2u + sch * 16;
+    const unsigned woff = (unsigned)perm_w(R0) * (unsigned)K * 2u + sch * 16;
+    const unsigned rstride = 32u * (unsigned)K * 2u;
+    int tm, tn;
+    quad_tile_coords(xcd_remap(blockIdx.x, ntiles), m_tiles, n_tiles, tm, tn);
+    const int m0 = tm * TM, n0 = tn * TN;
+    auto xrs = make_rs(X + (size_t)m0 * K);
+    auto wrs = make_rs(W + (size_t)n0 * K);
+    auto issue_a = [&](int kt, int buf, int i) {                       // A piece i (0..7) of K-tile kt into A buffer buf
+        char* dst = smem + buf * OP_BYTES + (wave + 4 * i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff,
+                                                 i * rstride + (unsigned)kt * (TK * 2), 0, 0);
+    };
+    auto issue_w = [&](int kt, int buf, int i) {
+        char* dst = smem + WRING + buf * OP_BYTES + (wave + 4 * i) * 1024;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, woff,
+                                                 i * rstride + (unsigned)kt * (TK * 2), 0, 0);
+    };
+    // the K-step macros call issue(ip, q): here pieces 0-7 = W of K-tile ip into the W buffer tile p just left, pieces 8-15 = A
+    // of K-tile ip + 1 into the A buffer tile p just left
+    int wfree = 0, afree = 0;
+    auto issue = [&](int ip, int q) {
+        if (q < 8) issue_w(ip, wfree, q);
+        else issue_a(ip + 1, afree, q - 8);
+    };
+    const int f = (c >> 1) & 7;
+    const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
+    const int xrow = (128 * wm + c) * 128;                              // relative to an A buffer
+    const int wrow0 = (128 * wn2 + c) * 128;                            // relative to a W buffer
+    const int np = K / TK;                                              // >= 4 (the launcher checks)
+    float pb = 0.f;
+    if (bias) {
+        const float* bp = bias + n0 + tid;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(pb) : "v"(bp) : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_a(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_w(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_a(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_w(1, 1, i);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) issue_a(2, 2, i);
+    asm volatile("s_waitcnt vmcnt(40)" : "+v"(pb)::"memory");
+    asm volatile("s_waitcnt vmcnt(24) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    bf16x8 xa[8], wa[8], xb[8], wb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(smem + WRING + wrow0 + slot0 + j * 2048);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(smem + xrow + slot0 + mi * 2048);
+
+    // tile p: A buffer ia, W buffer iw; the macros read X fragments at (nb) + xrow and W fragments at (nb) + wrow, so `wrow`
+    // carries the distance from the A buffer in use to the W buffer in use
+    int ia = 0, iw = 0, wrow = WRING + wrow0;
+    {
+        const char* ab = smem;
+        KEDS_QUAD_STEP(true, xa, wa, xb, wb, ab, slot1, false, 0, 0, true)                       // K-step (0, 0)
+    }
+    int p = 0;
+    for (; p + 3 < np; ++p) {                                           // steady state: K-tiles p+2 (W) and p+3 (A) exist
+        const int ia1 = ia == 2 ? 0 : ia + 1, iw1 = iw ^ 1;
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");                  // tile p+1 landed, tile p's buffers free
+        wfree = iw;
+        afree = ia;
+        {
+            const char* ab = smem + ia1 * OP_BYTES;
+            wrow = WRING + (iw1 - ia1) * OP_BYTES + wrow0;
+            KEDS_QUAD_STEP(false, xb, wb, xa, wa, ab, slot0, false, 1, p + 2, true)               // K-step (p, 1)
+            KEDS_QUAD_STEP(false, xa, wa, xb, wb, ab, slot1, false, 0, 0, true)                   // K-step (p+1, 0)
+        }
+        ia = ia1;
+        iw = iw1;
+    }
+    {                                                                   // p = np-3: W of the last K-tile is still to request
+        const int ia1 = ia == 2 ? 0 : ia + 1, iw1 = iw ^ 1;
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        wfree = iw;
+        const char* ab = smem + ia1 * OP_BYTES;
+        wrow = WRING + (iw1 - ia1) * OP_BYTES + wrow0;
+        KEDS_QUAD_STEP(false, xb, wb, xa, wa, ab, slot0, false, 2, p + 2, true)                   // K-step (np-3, 1)
+        KEDS_QUAD_STEP(false, xa, wa, xb, wb, ab, slot1, false, 0, 0, true)                       // K-step (np-2, 0)
+        ia = ia1;
+        iw = iw1;
+    }
+    {                                                                   // p = np-2: nothing left to request
+        const int ia1 = ia == 2 ? 0 : ia + 1, iw1 = iw ^ 1;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const char* ab = smem + ia1 * OP_BYTES;
+        wrow = WRING + (iw1 - ia1) * OP_BYTES + wrow0;
+        KEDS_QUAD_STEP(false, xb, wb, xa, wa, ab, slot0, false, 0, 0, true)                       // K-step (np-2, 1)
+        KEDS_QUAD_STEP(false, xa, wa, xb, wb, ab, slot1, false, 0, 0, true)                       // K-step (np-1, 0)
+        KEDS_QUAD_STEP(false, xb, wb, xa, wa, ab, slot0, false, 0, 0, false)                      // K-step (np-1, 1)
+    }
+    // every wave has read its last fragments: the W ring becomes bias slice (side + 2048) and statistics scratch
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    char* side = smem + WRING;
+    char* red = smem + WRING + 8192;
+    *reinterpret_cast<float*>(side + 2048 + tid * 4) = pb;
+    __syncthreads();
+    KEDS_QUAD_DRAIN
+    f32x4 av[4][8];
+    keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
+    KEDS_QUAD_READ_HALF0(av)
+    pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + 0, g, c, stats, red);
+    __builtin_amdgcn_sched_barrier(0);
+    KEDS_QUAD_READ_HALF1(av)
+    pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + 1, g, c, stats, red);
+    if (stats) {                                                        // kernel-uniform
+        __syncthreads();
+        const f32x2* rr = reinterpret_cast<const f32x2*>(red) + tid;
+        const f32x2 a = rr[0], b = rr[256], c2 = rr[512], d = rr[768];
+        keds_stat_add(stats + 2 * (size_t)(m0 + tid), (a[0] + b[0]) + (c2[0] + d[0]), (a[1] + b[1]) + (c2[1] + d[1]));
+    }
+}
+
 #undef make_rs
 #undef KEDS_QUAD_STEP
 #undef KEDS_QUAD_GROUP
@@ -1448,6 +1591,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
 // chip can power, not by its schedule: idle cycles removed come back as clock.  Not kept.
 
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
+int g_quad3 = 1;          // 4-wave kernel, residual epilogue: three-deep A ring (bit 16 of keds_gemm_force_small's argument: off)
 // 256^2 tiles on the 4-wave kernel: -1 = by shape (quad_by_shape: persistent form), 0 = never, 1 = always, one tile per
 // workgroup, 2 = always, persistent (one workgroup per CU walks the tiles, next tile's first K-tiles under the epilogue)
 // (bits 11-12 of keds_gemm_force_small's argument force 1 / 2, 3 = never; KEDS_GEMM_QUAD=0/1/2 in the environment overrides
@@ -1541,6 +1685,14 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
                                                                             n_tiles, aux, aux_i, aux2, keds_numerics_guard(), ntiles);
             return keds_check_launch("gemm_bt_quad_kernel<persistent>");
         }
+        if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
+            if (g_quad3 && K >= 1024 && K / pr::TK >= 4) {               // long K: A operand through a three-deep ring
+                if (int rc = keds_func_lds_once((const void*)gemm_bt_quad3_kernel<EPI>, 5 * pr::OP_BYTES, "gemm_bt_quad3_kernel")) return rc;
+                gemm_bt_quad3_kernel<EPI><<<ntiles, 256, 5 * pr::OP_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
+                                                                                n_tiles, aux, ntiles);
+                return keds_check_launch("gemm_bt_quad3_kernel");
+            }
+        }
         if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
         gemm_bt_quad_kernel<EPI><<<ntiles, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles,
                                                                      aux, aux_i, aux2, keds_numerics_guard(), ntiles);
@@ -1611,6 +1763,7 @@ extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
+    g_quad3 = !((on >> 16) & 1);        // bit 16: no three-deep A ring in the 4-wave residual GEMM (A/B)
     g_quad = (on >> 11) & 3;            // bits 11-12: 256^2 tiles on the 4-wave kernel (1), its persistent form (2), 3 = never
     if (g_quad == 0) g_quad = -1;       // (0 = the default: by shape)
     if (g_quad == 3) g_quad = 0;

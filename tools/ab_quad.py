@@ -33,9 +33,9 @@ def main():
         stats[:, 1] = int(1.0 * K * 2 ** 28)
         other = torch.zeros(M, 2, device="cuda", dtype=torch.int64)
         out = torch.randn(M, N, device="cuda").half() if epi == _lib.EPI_RESID_STATS_F16 else torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-        res = {"8 waves": [], "4 waves": [], "4 waves, persistent": []}
+        res = {"8 waves": [], "4 waves": [], "4 waves, persistent": [], "4 waves, 2-deep A": []}
         for rnd in range(rounds):
-            for name, flag in (("8 waves", 3 << 11), ("4 waves", 1 << 11), ("4 waves, persistent", 2 << 11)):
+            for name, flag in (("8 waves", 3 << 11), ("4 waves", 1 << 11), ("4 waves, persistent", 2 << 11), ("4 waves, 2-deep A", (1 << 11) | (1 << 16))):
                 lib.keds_gemm_force_small(flag)
 
                 def run():
