@@ -87,7 +87,7 @@ size_t keds_index_packed_bytes(int64_t n, int dim);
 /* `.add`: build the scan image from fp32 rows [n, dim] (device).  The image is the exact
  * LDS layout the scan kernel streams: per stage of 32 keys, XOR-swizzled bf16 rows followed
  * by 32 fp32 bias terms (-0.5*||x||^2 for L2, 0 for IP; -inf for rows >= n). */
-int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream);
+int keds_index_pack(const float* db, int64_t n, int dim, int metric, void* packed, void* stream);   /* n <= 2,048 * 16,384 rows per shard */
 /* chunked `.add`: `packed` already holds the image of rows [0, old_n) of `db` (same buffer, sized for n rows); pack rows
  * [old_n, n) only (the stage that old_n falls into is rewritten), keeping the bounds of the earlier rows. */
 int keds_index_pack_append(const float* db, int64_t old_n, int64_t n, int dim, int metric, void* packed, void* stream);
@@ -360,13 +360,16 @@ typedef struct {
 } keds_text_params;
 
 size_t keds_tower_workspace_bytes(int width, int seq, int B);
-/* Rows (B*seq mod 256) that keds_tower_forward runs as their own chain on a second, high-priority stream beside the
- * full 256-row tiles (0: one stream; always 0 with KEDS_SIDE_STREAM=0).  Their launches carry no profiling events:
- * keds_prof_read(KEDS_PROF_GEMM) then covers the full-tile launches only (bench.py scales the flops to match). */
+/* Rows (B*seq mod 256) that a tower pass of keds_vit_run / keds_text_run runs as their own chain on a second, high-priority
+ * stream beside the full 256-row tiles (0: one stream; always 0 with KEDS_SIDE_STREAM=0, and 0 with KEDS_TOWER_FILL=1, an
+ * experiment that runs the ragged last row tile as a full tile on filler rows -- measured slower, off by default).
+ * Side-lane launches carry no profiling events: keds_prof_read(KEDS_PROF_GEMM) then covers the
+ * full-tile launches only (bench.py scales the flops to match). */
 int keds_tower_side_rows(int width, int seq, int B, int fp8);
 int keds_side_lane_enable(int on);            /* run-time override of KEDS_SIDE_STREAM (default: on); results are identical */
+int keds_tower_fill_enable(int on);           /* run-time override of KEDS_TOWER_FILL (default: off): ragged last row tile on filler rows */
 
-/* x fp32 [B*seq (padded to 128), width] in place through all residual blocks (model.py:372-373) */
+/* x fp32 [B*seq (padded to 128), width] in place through all residual blocks (model.py:372-373); workspace: rows padded to 256 */
 int keds_tower_forward(const keds_tower_params* p, float* x, int B,
                        void* workspace, size_t workspace_bytes, void* stream);
 

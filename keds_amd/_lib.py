@@ -186,6 +186,7 @@ SIGNATURES = {
     "keds_l2_normalize": (i32, [vp, vp, i32, i32, vp]),
     "keds_mix_normalize": (i32, [vp, vp, f32, f32, vp, vp, vp, i32, i32, vp]),
     "keds_cast_bf16": (i32, [vp, vp, i64, vp]),
+    "keds_tower_fill_enable": (i32, [i32]),
     "keds_tower_workspace_bytes": (sz, [i32, i32, i32]),
     "keds_tokenizer_create": (i32, [C.c_char_p, C.POINTER(vp)]),
     "keds_tokenizer_destroy": (None, [vp]),

@@ -100,6 +100,7 @@ struct DevScratch {
 DevScratch g_splitk_dev[64];
 thread_local float* tl_splitk_p = nullptr;
 thread_local size_t tl_splitk_bytes = 0;
+thread_local bool tl_splitk_off = false;        // inside a scope opened with a null buffer: no GEMM of this thread splits K
 }  // namespace
 
 int keds_func_lds_once(const void* func, int bytes, const char* what) {
@@ -129,15 +130,22 @@ int keds_device_cus() {
     return g_cus[dev];
 }
 
-KedsSplitKScope::KedsSplitKScope(void* p, size_t bytes) : prev_p(tl_splitk_p), prev_bytes(tl_splitk_bytes) {
+KedsSplitKScope::KedsSplitKScope(void* p, size_t bytes) : prev_p(tl_splitk_p), prev_bytes(tl_splitk_bytes), prev_off(tl_splitk_off) {
     tl_splitk_p = (float*)p;
     tl_splitk_bytes = p ? bytes : 0;
+    tl_splitk_off = p == nullptr;
 }
 KedsSplitKScope::~KedsSplitKScope() {
     tl_splitk_p = prev_p;
     tl_splitk_bytes = prev_bytes;
+    tl_splitk_off = prev_off;
 }
 void keds_splitk_scratch(float** p, size_t* bytes) {
+    if (tl_splitk_off) {                        // a composite call that runs GEMMs on two streams at once: never split K
+        *p = nullptr;
+        *bytes = 0;
+        return;
+    }
     if (tl_splitk_p) {
         *p = tl_splitk_p;
         *bytes = tl_splitk_bytes;

@@ -763,6 +763,7 @@ constexpr int LDS_BYTES = SIDE_OFF + 4096;      // 132 KiB
 // STAMP (diagnostic build of one instantiation, tools/stamp_gemm.py): s_memtime stamps around the prologue, every
 // K-tile's wait and barrier, the loop and the epilogue; aux2 then receives 8 counters per wave instead of its usual role.
 // RP (KEDS_EPI_RESID_STATS_F16 only): residual tile + bias as the accumulators' initial value (pair_resid_epilogue_acc)
+__device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_tiles, int& tm, int& tn);   // (defined below)
 template <int EPI, int STAMP = 0, int RP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
@@ -787,19 +788,10 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     // with a plain n-fastest order) when the tile grid allows it.
     int tm, tn;
     const int m_tiles = gridDim.x / n_tiles;
-    if ((m_tiles & 7) == 0 && (n_tiles & 3) == 0) {
-        // groups walk m fastest: the 32-tile groups that follow each other on an XCD share their W panels (the smaller
-        // operand), not their A panels: -0.12 ms per step in a same-box A/B (round 2).  Group shapes 16 x 2 (+0.3 ms),
-        // 4 x 8 (no change) and 32 x 1 (+1.6 ms) measured against this 8 x 4.
-        const int grp = bid >> 5, within = bid & 31;
-        const int grows = m_tiles >> 3;
-        const int gn = grp / grows, gm = grp - gn * grows;
-        tm = gm * 8 + (within & 7);
-        tn = gn * 4 + (within >> 3);
-    } else {
-        tm = bid / n_tiles;
-        tn = bid - tm * n_tiles;
-    }
+    // groups walk m fastest: the 32-tile groups that follow each other on an XCD share their W panels (the smaller
+    // operand), not their A panels: -0.12 ms per step in a same-box A/B (round 2).  Group shapes 16 x 2 (+0.3 ms),
+    // 4 x 8 (no change) and 32 x 1 (+1.6 ms) measured against this 8 x 4.
+    quad_tile_coords(bid, m_tiles, n_tiles, tm, tn);
     const int m0 = tm * TM, n0 = tn * TN;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1166,13 +1158,20 @@ constexpr int LDS_BYTES = RED_OFF + 8192;           // 144 KiB
 }  // namespace qd
 
 // logical tile id -> (tm, tn): the 8 x 4 supertiles per XCD of the 8-wave kernel, m fastest
+// (m_tiles need not be a multiple of 8 -- a tower's ragged 129th row tile: the first m_tiles & ~7 row tiles form the
+// supertiles, the rest follow in plain order)
 __device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_tiles, int& tm, int& tn) {
-    if ((m_tiles & 7) == 0 && (n_tiles & 3) == 0) {
+    const int m8 = m_tiles & ~7;
+    if (m8 && (n_tiles & 3) == 0 && bid < m8 * n_tiles) {
         const int grp = bid >> 5, within = bid & 31;
-        const int grows = m_tiles >> 3;
+        const int grows = m8 >> 3;
         const int gn = grp / grows, gm = grp - gn * grows;
         tm = gm * 8 + (within & 7);
         tn = gn * 4 + (within >> 3);
+    } else if (m8 && (n_tiles & 3) == 0) {
+        const int r = bid - m8 * n_tiles;
+        tm = m8 + r / n_tiles;
+        tn = r - (tm - m8) * n_tiles;
     } else {
         tm = bid / n_tiles;
         tn = bid - tm * n_tiles;

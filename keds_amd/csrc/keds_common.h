@@ -63,15 +63,19 @@ int keds_func_lds_once(const void* func, int bytes, const char* what);
 int keds_device_cus();
 
 // ---- split-K scratch of the small-M GEMMs (host) -------------------------------------------------------------------
-// A GEMM launch that splits K writes fp32 partial tiles to scratch memory and reduces them in a second launch.  Every
-// composite call (towers, read-out, knowledge path) carves KEDS_SPLITK_BYTES out of ITS OWN caller-supplied workspace
-// and makes it the scratch of the GEMMs it enqueues for the duration of the call (thread-local scope): two handles,
-// threads or streams never share partial sums.  Direct keds_gemm_bt* calls outside such a scope use the per-device
-// buffer registered with keds_gemm_set_workspace (one stream at a time per device), or do not split.
+// A GEMM launch that splits K writes fp32 partial tiles to scratch memory and reduces them in a second launch.  A tower
+// pass (keds_tower_forward: the only composite call whose shapes split K -- remainder rows / CLS tail at K >= 2048) carves
+// KEDS_SPLITK_BYTES out of ITS OWN caller-supplied workspace and makes it the scratch of the GEMMs it enqueues for the
+// duration of the call (thread-local scope): two handles, threads or streams never share partial sums.  The knowledge path
+// runs its two CrossFormer chains on two streams AT ONCE, so it opens a scope with a NULL buffer = "no GEMM of this call
+// splits K" (its K is 512 / 768: nothing would split today; the scope makes that a guarantee instead of a coincidence).
+// Direct keds_gemm_bt* calls outside any scope use the per-device buffer registered with keds_gemm_set_workspace (one
+// stream at a time per device), or do not split.
 #define KEDS_SPLITK_BYTES ((size_t)8 << 20)      /* splits * tiles <= 128 tiles of 128 x 128 fp32 */
 struct KedsSplitKScope {
     float* prev_p;
     size_t prev_bytes;
+    bool prev_off;
     KedsSplitKScope(void* p, size_t bytes);
     ~KedsSplitKScope();
 };

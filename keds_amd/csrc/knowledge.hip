@@ -397,6 +397,7 @@ extern "C" int keds_knowledge_run(const keds_knowledge_params* p, const float* q
     KEDS_REQUIRE(p->i2t.dim_in == dim && p->fuse.dim == dim && p->cond.dim == dim && p->fuse.heads == p->cond.heads,
                  "keds_knowledge_run: IM2TEXT and CrossFormer dims must agree");
     KnWs w = carve_kn(p, B, K, workspace);
+    KedsSplitKScope no_split(nullptr, 0);     // the two CrossFormer chains run on two streams at once: no GEMM here may split K
     if (workspace_bytes < w.bytes) {
         keds_set_error("keds_knowledge_run: workspace %zu < %zu", workspace_bytes, w.bytes);
         return KEDS_E_WORKSPACE;

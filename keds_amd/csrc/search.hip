@@ -1131,7 +1131,10 @@ extern "C" int keds_index_pack_append(const float* db, int64_t old_n, int64_t n,
     KEDS_REQUIRE(old_n >= 0 && old_n < n, "keds_index_pack_append: old_n must be in [0, n)");
     KEDS_REQUIRE(dim_supported(dim), "keds_index_pack: dim %d unsupported (128,256,512,768,1024)", dim);
     KEDS_REQUIRE(metric == KEDS_METRIC_L2 || metric == KEDS_METRIC_IP, "keds_index_pack: bad metric");
-    KEDS_REQUIRE(n < (1LL << 31) - 64, "keds_index_pack: at most 2^31 rows per shard");
+    // the exact fp32 pass that backs the certificate walks a shard in at most 2,048 chunks of at most 16,384 rows
+    // (exact_chunk_rows): a larger shard could be packed but never searched -- refuse it here, where the caller builds it
+    KEDS_REQUIRE(n <= 2048LL * 16384, "keds_index_pack: at most %lld rows per shard (shard the database: keds_index_set_base)",
+                 2048LL * 16384);
     hipStream_t st = (hipStream_t)stream;
     switch (dim) {
         case 128: return launch_pack<128>(db, old_n, n, metric, packed, st);

@@ -16,7 +16,7 @@ bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
 
 namespace {
 
-size_t pad_rows(size_t m) { return keds_align_up(m, 128); }
+size_t pad_rows(size_t m) { return keds_align_up(m, 256); }     // (256: a tower may run its ragged last row tile as a full one)
 
 // scratch of one tower: h [Mp,w] (the fp16 residual stream of the folded flow; the bf16 LayerNorm output of the unfolded
 // one) | qkv [Mp,3w] | attn [Mp,w] | MLP hidden [Mp,4w] (bf16) |
@@ -137,6 +137,24 @@ bool bf16_rows_split(int M, int w) {
            keds_gemm_splits_rows(M, w, 4 * w);
 }
 
+// Round 3 experiment, OFF by default: the ragged last row tile as a FULL tile.  At B = 128 a ViT-L/14 tower has 32,896 rows =
+// 128 x 256 + 128; the 128 remainder rows run as their own chain of four small GEMMs per block on the side lane (0.39 ms per
+// step).  Rows only meet in the attention, so the GEMMs can just as well run on 129 full tiles: 128 filler rows behind the
+// last token (a copy of the first rows; never read by the attention -- their attention output stays zero -- or by the
+// read-out), 0.39 % more GEMM work, one lane.  Correct (test_ragged_row_tile_on_filler_rows_matches_the_two_lane_tower) and
+// 4 ms per step SLOWER (23.9 vs 19.85 ms, same-box A/B): 129 row tiles x 4..16 column tiles is no longer a whole number of
+// 256-workgroup rounds, and every one of the 94 GEMM launches of a step pays a nearly empty extra round (12..16 tiles on 256
+// CUs) that the side lane's small launches used to fill.  KEDS_TOWER_FILL=1 / keds_tower_fill_enable(1) turn it on.
+int g_tower_fill = -1;                          // -1: take KEDS_TOWER_FILL (default off)
+int tower_fill_rows(int M, int w) {
+    if (g_tower_fill < 0) {
+        const char* e = getenv("KEDS_TOWER_FILL");
+        g_tower_fill = e && e[0] == '1';
+    }
+    const int fill = (256 - M % 256) % 256;
+    return g_tower_fill && fill && bf16_rows_split(M, w) && (long)fill * 64 <= M ? fill : 0;
+}
+
 // BASELINE config 5: the four GEMMs of every block on MXFP8 operands (gemm_fp8.hip).  The residual stream stays fp32;
 // its MXFP8 copy (xq, xs), the attention output (aq) and the MLP hidden (hq) are e4m3 + one e8m0 scale per 32 columns,
 // produced by the GEMM epilogues themselves (the attention output by the attention kernel).  Rows beyond the last full
@@ -180,7 +198,9 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
     return keds_cast_rows_f16_f32_impl(t.h, x, M, w, w, st);       // the caller reads x in fp32
 }
 
-int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st) {
+// allow_fill: the caller's x holds pad_rows(B * seq) rows (keds_vit_run / keds_text_run carve it so); the public
+// keds_tower_forward promises only a multiple of 128 and keeps the two-lane scheme
+int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, bool allow_fill) {
     const int w = p->width, S = p->seq;
     const int M = B * S;
     TowerWs t = carve_tower(ws, w, S, B);
@@ -206,12 +226,20 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
     if (folded) {
         // When every GEMM of the block would split into full 256-row tiles + a remainder launch anyway, the remainder
         // rows become their own chain on the side lane; otherwise one span covers all rows.
-        const bool two = bf16_rows_split(M, w);
+        const int fill = allow_fill ? tower_fill_rows(M, w) : 0;
+        const bool two = !fill && bf16_rows_split(M, w);
         RowLanes lanes;
         if ((rc = lanes.init(st, two))) return rc;
-        const RowSpan body{0, lanes.split ? Mm : M, st};
+        const RowSpan body{0, lanes.split ? Mm : M + fill, st};
         const RowSpan rem{(size_t)Mm, lanes.split ? M - Mm : 0, lanes.side};
-        if ((rc = keds_rowstats_cast_ex(x, t.h, 1, (float*)t.st1, M, w, st))) return rc;
+        if (fill) {       // filler rows: a copy of the first rows of the stream; their attention output is zero in every block
+            if (hipMemcpyAsync(x + (size_t)M * w, x, (size_t)fill * w * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemsetAsync(t.att + (size_t)M * w, 0, (size_t)fill * w * sizeof(bf16_t), st) != hipSuccess) {
+                keds_set_error("keds_tower_forward: filler rows: %s", hipGetErrorString(hipGetLastError()));
+                return KEDS_E_LAUNCH;
+            }
+        }
+        if ((rc = keds_rowstats_cast_ex(x, t.h, 1, (float*)t.st1, M + fill, w, st))) return rc;
         if ((rc = lanes.to_side())) return rc;
         for (int l = 0; l < p->layers; ++l) {
             const keds_block_params& k = p->blocks[l];
@@ -270,9 +298,15 @@ extern "C" size_t keds_tower_workspace_bytes(int width, int seq, int B) {
     return carve_tower(nullptr, width, seq, B).bytes;
 }
 
+extern "C" int keds_tower_fill_enable(int on) {       // run-time override of KEDS_TOWER_FILL (A/B, tests)
+    g_tower_fill = on ? 1 : 0;
+    return KEDS_OK;
+}
+
 extern "C" int keds_tower_side_rows(int width, int seq, int B, int fp8) {
     if (width <= 0 || seq <= 0 || B <= 0) return 0;
     const int M = B * seq, Mt = M % 256;
+    if (!fp8 && tower_fill_rows(M, width)) return 0;       // the ragged tile runs as a full one on the caller's stream
     const bool split = fp8 ? (M >= 256 && Mt > 0) : bf16_rows_split(M, width);
     return split && keds_side_lane_enabled() ? Mt : 0;    // only a query: no stream is created here (no GPU needed)
 }
@@ -286,7 +320,7 @@ extern "C" int keds_tower_forward(const keds_tower_params* p, float* x, int B, v
         keds_set_error("keds_tower_forward: workspace too small");
         return KEDS_E_WORKSPACE;
     }
-    return tower_forward(p, x, B, workspace, (hipStream_t)stream);
+    return tower_forward(p, x, B, workspace, (hipStream_t)stream, false);
 }
 
 // ---- ViT -------------------------------------------------------------------------------------
@@ -343,7 +377,7 @@ extern "C" int keds_vit_run(const keds_vit_params* p, const float* image, int B,
     if ((rc = keds_cls_rows_impl(v.x, p->class_emb, p->pos_emb, B, S, w, st))) return rc;
     // ln_pre in place (each wave holds its whole row in registers before it stores)
     if ((rc = keds_layernorm_impl(v.x, w, nullptr, 1, p->ln_pre_g, p->ln_pre_b, v.x, 1, B * S, w, st))) return rc;
-    if ((rc = tower_forward(&p->tower, v.x, B, v.tower, st))) return rc;
+    if ((rc = tower_forward(&p->tower, v.x, B, v.tower, st, true))) return rc;
     return keds_readout(v.x, S, nullptr, p->ln_post_g, p->ln_post_b, p->proj_t, out, B, w, p->embed_dim, normalize, v.ro,
                         keds_readout_workspace_bytes(B, w), stream);
 }
@@ -392,7 +426,7 @@ extern "C" int keds_text_run(const keds_text_params* p, const int32_t* tokens, c
     const int w = p->tower.width, L = p->tower.seq;
     if ((rc = keds_embed_tokens(tokens, p->token_emb, p->pos_emb, img_tokens, n_tok, insert_col, v.x, B, L, w, stream)))
         return rc;
-    if ((rc = tower_forward(&p->tower, v.x, B, v.tower, (hipStream_t)stream))) return rc;
+    if ((rc = tower_forward(&p->tower, v.x, B, v.tower, (hipStream_t)stream, true))) return rc;
     return keds_readout(v.x, L, readout_row, p->ln_final_g, p->ln_final_b, p->proj_t, out, B, w, p->embed_dim, normalize,
                         v.ro, keds_readout_workspace_bytes(B, w), stream);
 }

@@ -62,11 +62,12 @@ def test_size_queries_need_no_gpu():
     # k up to 128 (256 candidates per query) and the chunk lists of the exact fallback grow the workspace
     assert lib.keds_index_search_workspace_bytes_ex(128, 768, 500000, 101) > lib.keds_index_search_workspace_bytes_ex(128, 768, 500000, 16)
     assert lib.keds_index_search_workspace_bytes_ex(128, 768, 500000, 129) == 0
-    assert lib.keds_tower_workspace_bytes(1024, 257, 128) == (32896 * 1024 * 2 + 2 * 32896 * 4096 * 2 + 2 * 32896 * 16
+    # rows padded to whole 256-row tiles (32,896 -> 33,024: the ragged last tile can run as a full one on filler rows)
+    assert lib.keds_tower_workspace_bytes(1024, 257, 128) == (33024 * 1024 * 2 + 2 * 33024 * 4096 * 2 + 2 * 33024 * 16
                                                               + 6 * (32768 * 1024 + 32768 * 32)        # + MXFP8 operands
                                                               + (8 << 20))                             # + this call's split-K scratch
     # remainder rows of a tower pass run beside the full tiles (side lane): 128 of 32,896 at B = 128, none for a text tower
-    assert lib.keds_tower_side_rows(1024, 257, 128, 0) in (0, 128)      # 0 with KEDS_SIDE_STREAM=0
+    assert lib.keds_tower_side_rows(1024, 257, 128, 0) in (0, 128)      # 0 with KEDS_SIDE_STREAM=0 (or KEDS_TOWER_FILL=1)
     assert lib.keds_tower_side_rows(768, 77, 128, 0) == 0
 
 
