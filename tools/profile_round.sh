@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile: rocprofv3 kernel stats of the bench command + two PMC passes (FETCH_SIZE, WRITE_SIZE) of two
 # bench-identical steps.  Run on the GPU box from the repo root:  bash tools/profile_round.sh <tag>
-tag=${1:-r01_v4}
+tag=${1:-r03_final}
 export TMPDIR=/tmp
 W=/tmp/keds_prof_$tag; rm -rf $W; mkdir -p $W gpurun_out
 rocprofv3 --kernel-trace --stats --output-format csv -d $W/stats -o bench -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline > $W/bench.log 2>&1
