@@ -870,7 +870,8 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
             o[3] = t_issued - t_loop;   // last key, normalisation, stores issued
             o[4] = t_in;
             o[5] = t_end;
-            o[6] = __builtin_amdgcn_s_getreg(63492);   // HW_ID: where the wave ran
+            o[6] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) |                 // HW_ID: where the wave ran
+                   ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32);          // XCC_ID
             o[7] = t_end - t_issued;    // store drain
         }
     }
@@ -884,6 +885,23 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
 // per SIMD the item loop spills 36-110 registers (hoisted lane offsets, the next item's query fragments beside the output
 // tiles), and every spill reload is a vmcnt wait that, vmcnt being in-order, also waits for the LDS-DMA in flight -- the
 // prefetch it was built for.  Not kept; an assembly item loop is the way to do this.
+// NOTE (measured, round 3; profiles/r03_attention_experiments.txt): three more forms, all bit-identical or equally accurate,
+// none faster than the kernel above.
+//  (a) ONE 8-wave workgroup per CU at the 256-register budget with TWO full item images in LDS (2 x 69 KB), item i+1
+//      requested behind the top barrier of item i, the per-item body unchanged: no spill (196 VGPRs), 84 us against 63 us
+//      (B = 128; 44 vs 34 at B = 64).  Two co-resident one-item workgroups already hide each other's row waits AND give every
+//      SIMD four waves to interleave exp / MFMA / LDS reads; the persistent form keeps the first and halves the second.
+//      160 KB of LDS holds two images either way: "prefetch" and "four waves per SIMD" exclude each other at bf16 K / V.
+//  (b) one vmcnt(0) wait at the top and no mid-item barrier; the same with the last-query share of waves 4-7 moved in front
+//      of their tiles (a half-tile stagger of the SIMD partners); the same with s_setprio 1 for waves 4-7: 60.6-64.4,
+//      62.3-68.1, 60.7-66.6 us against 59.8-64.6 on the same boxes -- inside the box-to-box spread.
+//  (c) the last query row on the matrix pipe: each wave runs one more key-tile step on its OWN key tile with row 256's query
+//      broadcast into all 32 B-operand columns (4 + 4 MFMAs, 16 exp2, no cross-lane reduction, lanes 0 / 32 store the
+//      partial; key 256 joins in the combine).  118 VGPRs instead of 128, same error (last rows 1.7e-3 rel-L2), 59.8-64.7 us
+//      against 60.3-64.0 for the VALU form: the row costs one key-tile step per wave (a ninth of the tile work, 4.5 us:
+//      "partials only" ablation 62 us, no last row 57.5) whichever unit runs it.
+// In-kernel stamps with XCC_ID: every CU runs exactly 8 workgroups, 1.84 of 2 resident on average, the next workgroup enters
+// 700-900 cycles after an exit, per-CU span 114.6 k cycles mean / 127 k max: a tenth of the launch is the spread between CUs.
 // NOTE (measured, round 2): the "keys 0-127 first" wait of the kernel above is not what the hardware executes: __syncthreads()
 // is a workgroup-scope fence and drains vmcnt in front of the barrier, the compiler puts s_waitcnt vmcnt(0) in front of the
 // first ds_write behind an LDS-DMA and in front of the first ds_read_tr builtin (it cannot tell them from the DMA in flight),

@@ -29,5 +29,40 @@ for i, n in enumerate(names):
 v = st[:, :, 7]
 print(f"  {'store drain':46s} mean {v.mean():8.0f}  min {v.min():8.0f}  max {v.max():8.0f}")
 # workgroups per CU over time: HW_ID -> (xcc, se, cu)
-hw = st[:, 0, 6].long()
+raw = buf.cpu().reshape(B * H, 8, 8)
+hw = raw[:, 0, 6] & 0xFFFFFFFF
+xcc = (raw[:, 0, 6] >> 32) & 0xF
 print("distinct HW_ID CU fields:", len(set(((hw >> 8) & 0xF).tolist())), "x SE", len(set(((hw >> 13) & 0x7).tolist())))
+
+# per-CU residency: key = (xcc, se, cu); a workgroup is resident from its first wave's entry to its last wave's exit
+import collections
+key = (xcc * 64 + ((hw >> 13) & 0x7) * 16 + ((hw >> 8) & 0xF)).tolist()
+t_in = raw[:, :, 4].min(dim=1).values.tolist()
+t_out = raw[:, :, 5].max(dim=1).values.tolist()
+cus = collections.defaultdict(list)
+for k, a, b_ in zip(key, t_in, t_out):
+    cus[k].append((a, b_))
+print("CUs seen:", len(cus), " workgroups per CU min/max:", min(len(v) for v in cus.values()), max(len(v) for v in cus.values()))
+occ, spans, gaps, idle1 = [], [], [], []
+for k, v in cus.items():
+    v.sort()
+    span = max(b_ for _, b_ in v) - v[0][0]
+    resident = sum(b_ - a for a, b_ in v)
+    occ.append(resident / span); spans.append(span)
+    # time with fewer than two workgroups resident
+    ev = sorted([(a, 1) for a, _ in v] + [(b_, -1) for _, b_ in v])
+    n, last, lt2 = 0, ev[0][0], 0
+    for t, d in ev:
+        if n < 2: lt2 += t - last
+        n += d; last = t
+    idle1.append(lt2 / span)
+    # gap between an exit and the next entry on this CU
+    outs = sorted(b_ for _, b_ in v)
+    ins = sorted(a for a, _ in v)[2:]
+    for o_, i_ in zip(outs, ins):
+        gaps.append(i_ - o_)
+import statistics as stt
+print(f"per-CU span mean {stt.mean(spans):.0f} cycles (max {max(spans):.0f}); mean resident workgroups {stt.mean(occ):.2f} of 2; "
+      f"time with < 2 resident {100 * stt.mean(idle1):.1f} %")
+if gaps:
+    print(f"exit -> next entry on the same CU: mean {stt.mean(gaps):.0f} cycles, median {stt.median(gaps):.0f}, max {max(gaps):.0f}")
