@@ -1184,6 +1184,15 @@ __device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_til
 // this tile's epilogue: the 5 k cycles of prologue latency, the store drain and the gap between workgroups lie under the
 // 10 k cycles of epilogue.  The 8-wave kernel could not do this (round 1-2: at 256 VGPRs the tile loop spilled); here the
 // accumulators are outside the allocator's view and the wave has ~90 VGPRs to spare.
+// NOTE (measured, round 3): all workgroups walk equal tiles in lockstep, so the whole chip stores 33 MB at once every ~50 k
+// cycles while the matrix pipes idle (the epilogue's 10.7 k cycles are 3.3 k of issue -- 256 accvgpr reads, 256 v_pk_fma,
+// 128 cvt_pk, 40 stores -- and the rest store back-pressure).  Starting XCDs 4-7 16 k / 32 k cycles late (8 / 17 us) costs
+// only 0-3 / 3-8 us -- but NOT because the bursts stop colliding: a zero-idle form of the same phase shift (XCDs 4-7 split
+// their first tile into two half-width units -- W fragments 0-3, i.e. MFMA groups 0-3 of every K-step, on columns
+// [0, 64) u [128, 192) in front of their other tiles and, on a W panel moved by 64 columns, the rest behind them; bit-
+// identical) gains nothing: qkv 186.5 vs 187.5 us, c_fc 251.4 vs 244.9.  The chip runs these kernels at its power cap; an
+// idle half buys the working half clock, and a stall cycle costs little energy, so removing stall cycles -- rather than
+// joules -- buys little time.  (Plain vs non-temporal output stores, any mix: no difference in the isolated GEMM either.)
 template <int EPI, int STAMP = 0, int PERSIST = 0>
 __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,

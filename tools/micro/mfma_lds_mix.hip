@@ -13,7 +13,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
-template <int SHAPE>
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+template <int SHAPE, int F16 = 0>
 __global__ __launch_bounds__(512, 2) void mix_kernel(const uint4* __restrict__ src, float* out, int iters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];     // two operand buffers of 64 KiB: X | W each 32 KiB
     for (int i = threadIdx.x; i < 131072 / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = src[i];
@@ -43,7 +44,10 @@ __global__ __launch_bounds__(512, 2) void mix_kernel(const uint4* __restrict__ s
 #pragma unroll
                 for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], x[mi], acc[ni][mi], 0, 0, 0);
+                    for (int ni = 0; ni < 4; ++ni) {
+                        if constexpr (F16) acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w[ni]), __builtin_bit_cast(f16x8, x[mi]), acc[ni][mi], 0, 0, 0);
+                        else acc[ni][mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[ni], x[mi], acc[ni][mi], 0, 0, 0);
+                    }
             }
         }
 #pragma unroll
@@ -140,15 +144,15 @@ void run4(const char* name, const uint4* src, float* out) {
            ms * 1e-3 / iters * 2.0e9);
 }
 
-template <int SHAPE>
+template <int SHAPE, int F16 = 0>
 void run(const char* name, const uint4* src, float* out) {
     const int iters = 3000;
-    hipFuncSetAttribute((const void*)mix_kernel<SHAPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    hipFuncSetAttribute((const void*)mix_kernel<SHAPE, F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    mix_kernel<SHAPE><<<256, 512, 131072>>>(src, out, 100);
+    mix_kernel<SHAPE, F16><<<256, 512, 131072>>>(src, out, 100);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    mix_kernel<SHAPE><<<256, 512, 131072>>>(src, out, iters);
+    mix_kernel<SHAPE, F16><<<256, 512, 131072>>>(src, out, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flops = 256.0 * iters * 2.0 * 256 * 256 * 64;      // one 256 x 256 x 64 K-tile per iteration per workgroup
@@ -156,20 +160,39 @@ void run(const char* name, const uint4* src, float* out) {
            ms * 1e-3 / iters * 2.0e9);
 }
 
+// operand data: what toggles sets the power, and the power cap sets the clock.  mode 0: uniform [-2, 2) in both operands;
+// 1: X uniform [-2, 2), W scaled by 1/32 (weights ~ K^-0.5); 2: zeros; 3: normal(0, 1) X, normal(0, 1/32) W.  f16: the same
+// VALUES rounded to fp16 instead of bf16.
+static float frand() { return (rand() & 0xFFFFFF) / 16777216.0f; }
+static float nrand() { float u = frand() + 1e-7f, v = frand(); return sqrtf(-2.f * logf(u)) * cosf(6.2831853f * v); }
+static unsigned short to_bf16(float v) { unsigned u; memcpy(&u, &v, 4); u += 0x7FFF + ((u >> 16) & 1); return (unsigned short)(u >> 16); }
+static unsigned short to_f16(float v) { _Float16 h = (_Float16)v; unsigned short r; memcpy(&r, &h, 2); return r; }
+void fill(unsigned short* h, int mode, bool f16) {
+    for (int buf = 0; buf < 2; ++buf)
+        for (int i = 0; i < 32768; ++i) {
+            const bool is_w = i >= 16384;                 // each 64 KiB buffer: X (32 KiB) | W (32 KiB)
+            float v = 0.f;
+            if (mode == 0) v = (frand() - 0.5f) * 4.0f;
+            if (mode == 1) v = (frand() - 0.5f) * 4.0f * (is_w ? 1.0f / 32 : 1.0f);
+            if (mode == 3) v = nrand() * (is_w ? 1.0f / 32 : 1.0f);
+            h[buf * 32768 + i] = f16 ? to_f16(v) : to_bf16(v);
+        }
+}
+#include <cmath>
 int main() {
     uint4* src; float* out;
     hipMalloc(&src, 131072); hipMalloc(&out, 64);
     unsigned short* h = (unsigned short*)malloc(131072);
     srand(1);
-    for (int i = 0; i < 65536; ++i) {            // random bf16 in roughly [-2, 2]
-        const float v = ((rand() & 0xFFFF) / 32768.0f - 1.0f) * 2.0f;
-        unsigned u; memcpy(&u, &v, 4); h[i] = (unsigned short)(u >> 16);
-    }
-    hipMemcpy(src, h, 131072, hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 2; ++rep) {
-        run<0>("16x16x32: 24 ds_read_b128 + 64 MFMA per wave K-tile", src, out);
-        run<1>("32x32x16: 24 ds_read_b128 + 32 MFMA per wave K-tile", src, out);
-        run4("4 waves x 128x128: 32 ds_read_b128 + 128 MFMA per wave", src, out);
-    }
+    const char* modes[4] = {"uniform [-2,2) both", "X uniform [-2,2), W / 32", "zeros", "X normal(0,1), W normal(0,1/32)"};
+    for (int rep = 0; rep < 2; ++rep)
+        for (int mode = 0; mode < 4; ++mode) {
+            printf("-- data: %s\n", modes[mode]);
+            fill(h, mode, false); hipMemcpy(src, h, 131072, hipMemcpyHostToDevice);
+            run<0, 0>("16x16x32 bf16: 24 ds_read_b128 + 64 MFMA per wave K-tile", src, out);
+            run<1, 0>("32x32x16 bf16: 24 ds_read_b128 + 32 MFMA per wave K-tile", src, out);
+            fill(h, mode, true); hipMemcpy(src, h, 131072, hipMemcpyHostToDevice);
+            run<0, 1>("16x16x32 f16 : 24 ds_read_b128 + 64 MFMA per wave K-tile", src, out);
+        }
     return 0;
 }
