@@ -1411,6 +1411,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
 // 160 KiB -- so A pieces go out TWO K-tiles ahead: step (p, 1) requests W of tile p+2 and A of tile p+3, and the wait of
 // step (p+1, 1) is a counted vmcnt(8) that leaves those eight A pieces in flight.  Bias slice and statistics scratch alias the
 // W ring after the K-loop.  One tile per workgroup.
+// (Measured, round 3: rotating the K walk per row panel -- panel tm starts at K-tile (s * tm) mod np and wraps, the vendor
+// kernels' "StaggerU" -- is SLOWER here: 234 us at s = 5, 8, 17 against 218, 223 at s = 32, 219 at s = 1; the workgroups share
+// the W panel's K-slices in L2 because they walk K together.)
 template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                                const float* __restrict__ bias, void* __restrict__ out,
