@@ -900,6 +900,9 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
 //      partial; key 256 joins in the combine).  118 VGPRs instead of 128, same error (last rows 1.7e-3 rel-L2), 59.8-64.7 us
 //      against 60.3-64.0 for the VALU form: the row costs one key-tile step per wave (a ninth of the tile work, 4.5 us:
 //      "partials only" ablation 62 us, no last row 57.5) whichever unit runs it.
+//  (d) S^T of key tile t+1 issued in front of P.V of tile t (so that the exp block never waits for its own MFMA chain): the
+//      second score tile is live across the P.V step, 16 registers more than the 128 of four waves per SIMD hold -- 58-82
+//      spilled registers, 22 scratch accesses per four tiles in the loop, with the K fragments read early or late.  Not run.
 // In-kernel stamps with XCC_ID: every CU runs exactly 8 workgroups, 1.84 of 2 resident on average, the next workgroup enters
 // 700-900 cycles after an exit, per-CU span 114.6 k cycles mean / 127 k max: a tenth of the launch is the spread between CUs.
 // NOTE (measured, round 2): the "keys 0-127 first" wait of the kernel above is not what the hardware executes: __syncthreads()
