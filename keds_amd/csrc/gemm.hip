@@ -282,10 +282,14 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
 // computed once per workgroup in the prologue (their loads and the 64-bit fixed-point -> float conversions hide behind the
 // wait for the first K-tile) and sit in the LDS side area; every row of the tile is valid (M % 256 == 0), and a lane's store
 // address is a uniform tile base + a 32-bit offset.  DBG 3 (stamped diagnostic build): no stores.
-template <int EPI, int DBG>
+// ND > 0 (persistent 4-wave kernel, second column half): with `defer` the last ND of the call's 16 stores are NOT issued but
+// handed back in `pend` (pend[i] = store p * 8 + mi = 16 - ND + i); the caller issues them between the first K-steps of its next
+// tile (quad_flush_pending), where nothing competes with them -- see the note at the persistent kernel.
+constexpr int QUAD_ND = 12;
+template <int EPI, int DBG, int ND = 0>
 __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char* __restrict__ side, void* __restrict__ out,
                                                  int m0, int n0, int N, int wm, int wn, int g, int c,
-                                                 void* __restrict__ aux2) {
+                                                 void* __restrict__ aux2, u32x4* __restrict__ pend = nullptr, bool defer = false) {
     float rstd[8], nmr[8];
     int r0 = 128 * wm + c;
     // opaque to the optimiser: inside the persistent kernel's tile loop the 16 lane-constant store offsets derived from r0
@@ -332,8 +336,28 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
             // hint on the A-panel DMA costs 2.5 ms (the four tiles of an XCD that share a panel stop sharing it), on the
             // fp16 residual stores it is neutral, on the attention kernel's 8-byte output stores it costs 2.2 ms, and on the bf16
             // output of the MXFP8 kernel (gemm_fp8.hip) it costs 0.2 ms of that mode's 17.2 ms step.
+            if constexpr (ND > 0) {
+                if (p * 8 + mi >= 16 - ND && defer) {                       // (wave-uniform)
+                    pend[p * 8 + mi - (16 - ND)] = __builtin_bit_cast(u32x4, ov);
+                    continue;
+                }
+            }
             __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(tile_out + off));
         }
+    }
+}
+// stores [i0, i1) of the ND deferred ones: the same addresses the epilogue would have used (tile base kept by the caller)
+template <int ND>
+__device__ __forceinline__ void quad_flush_pending(const u32x4* __restrict__ pend, char* __restrict__ tile_out, int N, int wm, int wn,
+                                                   int g, int c, int i0, int i1) {
+    int r0 = 128 * wm + c;
+    asm volatile("" : "+v"(r0));
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+        if (i < i0 || i >= i1) continue;
+        const int idx = 16 - ND + i, p = idx >> 3, mi = idx & 7;
+        const unsigned off = ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(64 * wn + 32 * p + 8 * g)) * 2u;
+        __builtin_nontemporal_store(pend[i], reinterpret_cast<u32x4*>(tile_out + off));
     }
 }
 
@@ -1135,11 +1159,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     KEDS_QG2(FIRST, mi, 4, 5, wc, xc) KEDS_QGAP(4 * (mi) + 2, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)         \
     KEDS_QG2(FIRST, mi, 6, 7, wc, xc) KEDS_QGAP(4 * (mi) + 3, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)
 // One K-step: 64 MFMAs from (xc, wc); the 16 fragment reads of the NEXT K-step go to (xn, wn_) from buffer `nb` at chunk
-// offset `nslot`; with ISSUE the 16 DMA pieces of K-tile `ip` go out; SYNC: K-tile landed + buffer free (wait + barrier).
+// offset `nslot`; with ISSUE the 16 DMA pieces of K-tile `ip` go out; SYNC: K-tile landed + buffer free (wait + barrier;
+// SYNC = 2: the four youngest memory operations -- deferred output stores of the previous tile -- may stay in flight).
 #define KEDS_QUAD_STEP(FIRST, xc, wc, xn, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                           \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr (SYNC && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        if constexpr ((int)(SYNC) == 2 && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else if constexpr (SYNC && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         KEDS_QUAD_GROUP(FIRST, 0, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
         KEDS_QUAD_GROUP(FIRST, 1, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
@@ -1292,6 +1318,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     side_write(smem + qd::SIDE0, n0);
     asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+    // deferred output stores of the previous tile (PERSIST, LayerNorm epilogues): QUAD_ND x 16 bytes per lane
+    [[maybe_unused]] u32x4 pend[QUAD_ND];
+    [[maybe_unused]] char* pend_base = nullptr;
+    [[maybe_unused]] bool have_pend = false;
+    // (not the QuickGELU form: with the 48 registers of the deferred stores compiled in, c_fc runs 239-241 us with or without
+    // deferring against 232-236 without the code -- its epilogue, 2 x 256 transcendentals per lane, needs the registers more)
+    constexpr bool DEFER = PERSIST && epi_is_ln(EPI) && epi_base(EPI) != KEDS_EPI_BIAS_QGELU_BF16 && !STAMP;
     for (int it = 0;; ++it) {
         char* side = smem + qd::SIDE0 + (it & 1) * 4096;
         if constexpr (STAMP) t_loop0 = __builtin_amdgcn_s_memtime();
@@ -1314,6 +1347,29 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         // K-steps (0,0) | [(p,1) (p+1,0)] for p < np-2 | (np-2,1) (np-1,0) (np-1,1)
         KEDS_QUAD_STEP(true, xa, wa, xb, wb, smem, slot1, false, false, 0, true)
         int p = 0;
+        if constexpr (DEFER) {
+            // the previous tile's deferred stores, two behind every K-step of the first three K-tiles (np >= 8 here).  vmcnt
+            // counts stores and retires in order: the K-tile waits of these iterations and of the one behind them leave the four
+            // youngest operations -- stores, younger than the DMA pieces the wait is for -- in flight (a store's acknowledgement
+            // takes longer than a K-step; waited for with vmcnt(0) the trickle gives back what it saved)
+            if (have_pend) {
+#define KEDS_QUAD_PEEL(pp, SY)                                                                                          \
+    {                                                                                                                   \
+        const char* ob = smem + (((pp) + 1) & 1) * PBUF_BYTES;                                                          \
+        KEDS_QUAD_STEP(false, xb, wb, xa, wa, ob, slot0, SY, true, (pp) + 2, true)                                      \
+        quad_flush_pending<QUAD_ND>(pend, pend_base, N, wm, 2 * wn2 + 1, g, c, 4 * (pp), 4 * (pp) + 2);                 \
+        KEDS_QUAD_STEP(false, xa, wa, xb, wb, ob, slot1, false, false, 0, true)                                         \
+        quad_flush_pending<QUAD_ND>(pend, pend_base, N, wm, 2 * wn2 + 1, g, c, 4 * (pp) + 2, 4 * (pp) + 4);             \
+    }
+                KEDS_QUAD_PEEL(0, 1)
+                KEDS_QUAD_PEEL(1, 2)
+                KEDS_QUAD_PEEL(2, 2)
+                KEDS_QUAD_PEEL(3, 2)                                   // (nothing left to flush: indices 12-15 do not exist)
+#undef KEDS_QUAD_PEEL
+                p = 4;
+                have_pend = false;
+            }
+        }
         for (; p + 2 < np; ++p) {                                      // steady state: tile p+2 exists
             const char* ob = smem + ((p + 1) & 1) * PBUF_BYTES;         // buffer of K-tile p+1
             KEDS_QUAD_STEP(false, xb, wb, xa, wa, ob, slot0, true, true, p + 2, true)       // K-step (p, 1)
@@ -1349,6 +1405,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         }
 
         // ---- epilogues: the 8-wave kernel's, once per 64-column half (wave column 2 wn2 + h) read back from its AGPRs
+        [[maybe_unused]] const bool defer_now = more && aux_i != 0;      // (LayerNorm epilogues do not use aux_i: the A/B switch)
         [[maybe_unused]] void* stamp_out = aux2;
         void* aux2e = STAMP ? nullptr : aux2;                             // (stamped build: aux2 carries the stamp buffer)
         KEDS_QUAD_DRAIN
@@ -1356,8 +1413,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         [[maybe_unused]] keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
         [[maybe_unused]] char* red = smem + qd::RED_OFF;
 #define KEDS_QUAD_EPI(h)                                                                                               \
-    if constexpr (epi_is_ln(EPI))                                                                                      \
-        pair_ln_epilogue<EPI, 0>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e);                              \
+    if constexpr (epi_is_ln(EPI)) {                                                                                    \
+        if constexpr (DEFER && h == 1)                                                                                 \
+            pair_ln_epilogue<EPI, 0, QUAD_ND>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e, pend, defer_now);\
+        else                                                                                                           \
+            pair_ln_epilogue<EPI, 0>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e);                          \
+    }                                                                                                                  \
     else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)                                                                \
         pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, stats, red);                    \
     else                                                                                                               \
@@ -1368,6 +1429,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         KEDS_QUAD_READ_HALF1(av)
         KEDS_QUAD_EPI(1)
 #undef KEDS_QUAD_EPI
+        if constexpr (DEFER) {
+            have_pend = defer_now;
+            pend_base = reinterpret_cast<char*>(out) + ((size_t)m0 * N + n0) * 2;
+        }
         if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
             if (stats) {                                                    // kernel-uniform
                 __syncthreads();
@@ -1602,6 +1667,15 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __r
 // chip can power, not by its schedule: idle cycles removed come back as clock.  Not kept.
 
 int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
+static int quad_defer_env() {     // KEDS_QUAD_DEFER=0 in the environment: no deferred epilogue stores (whole-step A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_QUAD_DEFER");
+        v = !(e && e[0] == '0');
+    }
+    return v;
+}
+int g_quad_defer = 1;     // persistent 4-wave kernel, LayerNorm epilogue: 12 of a tile's 32 stores per lane wait for the next K-loop (bit 17: off)
 int g_quad3 = 1;          // 4-wave kernel, residual epilogue: three-deep A ring (bit 16 of keds_gemm_force_small's argument: off)
 // 256^2 tiles on the 4-wave kernel: -1 = by shape (quad_by_shape: persistent form), 0 = never, 1 = always, one tile per
 // workgroup, 2 = always, persistent (one workgroup per CU walks the tiles, next tile's first K-tiles under the epilogue)
@@ -1693,7 +1767,8 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         if (quad == 2 && ntiles > cus && cus >= 8 && EPI != KEDS_EPI_RESID_STATS_F16) {
             if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 0, 1>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
             gemm_bt_quad_kernel<EPI, 0, 1><<<cus, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                            n_tiles, aux, aux_i, aux2, keds_numerics_guard(), ntiles);
+                                                                            n_tiles, aux, epi_is_ln(EPI) ? (g_quad_defer && quad_defer_env()) : aux_i, aux2,
+                                                                            keds_numerics_guard(), ntiles);
             return keds_check_launch("gemm_bt_quad_kernel<persistent>");
         }
         if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
@@ -1775,6 +1850,7 @@ extern "C" int keds_gemm_force_small(int on) {
     g_no_split = (on >> 9) & 1;         // bit 9: disable split-K (A/B tests)
     g_skip_tail = (on >> 8) & 1;        // bit 8: timing-only, skip remainder rows
     g_quad3 = !((on >> 16) & 1);        // bit 16: no three-deep A ring in the 4-wave residual GEMM (A/B)
+    g_quad_defer = !((on >> 17) & 1);   // bit 17: no deferred epilogue stores in the persistent 4-wave kernel (A/B)
     g_quad = (on >> 11) & 3;            // bits 11-12: 256^2 tiles on the 4-wave kernel (1), its persistent form (2), 3 = never
     if (g_quad == 0) g_quad = -1;       // (0 = the default: by shape)
     if (g_quad == 3) g_quad = 0;

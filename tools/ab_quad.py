@@ -33,9 +33,10 @@ def main():
         stats[:, 1] = int(1.0 * K * 2 ** 28)
         other = torch.zeros(M, 2, device="cuda", dtype=torch.int64)
         out = torch.randn(M, N, device="cuda").half() if epi == _lib.EPI_RESID_STATS_F16 else torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-        res = {"8 waves": [], "4 waves": [], "4 waves, persistent": [], "4 waves, 2-deep A": []}
+        res = {"8 waves": [], "4 waves": [], "4 waves, persistent": [], "4 waves, 2-deep A": [], "4 waves, persistent, no deferred stores": []}
         for rnd in range(rounds):
-            for name, flag in (("8 waves", 3 << 11), ("4 waves", 1 << 11), ("4 waves, persistent", 2 << 11), ("4 waves, 2-deep A", (1 << 11) | (1 << 16))):
+            for name, flag in (("8 waves", 3 << 11), ("4 waves", 1 << 11), ("4 waves, persistent", 2 << 11), ("4 waves, 2-deep A", (1 << 11) | (1 << 16)),
+                               ("4 waves, persistent, no deferred stores", (2 << 11) | (1 << 17))):
                 lib.keds_gemm_force_small(flag)
 
                 def run():
@@ -57,7 +58,7 @@ def main():
         lib.keds_gemm_force_small(0)
         for name, v in res.items():
             med, mn = statistics.median(v), min(v)
-            print(f"{tag:16s} {name:18s} median {med:7.1f} us ({2.0 * M * N * K / med / 1e6:7.1f} TF)   min {mn:7.1f} us", flush=True)
+            print(f"{tag:16s} {name:40s} median {med:7.1f} us ({2.0 * M * N * K / med / 1e6:7.1f} TF)   min {mn:7.1f} us", flush=True)
 
 
 if __name__ == "__main__":
