@@ -282,11 +282,13 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
 // computed once per workgroup in the prologue (their loads and the 64-bit fixed-point -> float conversions hide behind the
 // wait for the first K-tile) and sit in the LDS side area; every row of the tile is valid (M % 256 == 0), and a lane's store
 // address is a uniform tile base + a 32-bit offset.  DBG 3 (stamped diagnostic build): no stores.
-// ND > 0 (persistent 4-wave kernel, second column half): with `defer` the last ND of the call's 16 stores are NOT issued but
-// handed back in `pend` (pend[i] = store p * 8 + mi = 16 - ND + i); the caller issues them between the first K-steps of its next
-// tile (quad_flush_pending), where nothing competes with them -- see the note at the persistent kernel.
-constexpr int QUAD_ND = 12;
-template <int EPI, int DBG, int ND = 0>
+// ND > 0 (persistent 4-wave kernel; H = the wave's 64-column half this call covers, PSEL = its 32-column quarter, -1: both):
+// a lane's 32 stores of a tile are numbered s = 16 H + 8 p + mi; with `defer` the last ND of them are NOT issued but handed
+// back in `pend` (pend[s - (32 - ND)]); the caller issues them between the first K-steps of its next tile
+// (quad_flush_pending), where nothing competes with them -- see the note at the persistent kernel.
+template <int EPI>
+constexpr int quad_nd() { return 18; }       // (measured on qkv, same-process A/B: 12 stores -7.7 us, 18 -8.7, 22 -9.3 of 179)
+template <int EPI, int DBG, int ND = 0, int H = 0, int PSEL = -1>
 __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char* __restrict__ side, void* __restrict__ out,
                                                  int m0, int n0, int N, int wm, int wn, int g, int c,
                                                  void* __restrict__ aux2, u32x4* __restrict__ pend = nullptr, bool defer = false) {
@@ -301,7 +303,7 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
         rstd[mi] = cf[0];
         nmr[mi] = cf[1];
     }
-    if (aux2 && n0 == 0 && wn == 0 && g == 0) {          // the one wave column that clears the other statistics buffer
+    if (PSEL <= 0 && aux2 && n0 == 0 && wn == 0 && g == 0) {          // the one wave column that clears the other statistics buffer
         keds_stat_t* zero = reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)(m0 + r0);
 #pragma unroll
         for (int mi = 0; mi < 8; ++mi) keds_stat_zero(zero + 32 * mi);
@@ -309,6 +311,7 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
     char* tile_out = reinterpret_cast<char*>(out) + ((size_t)m0 * N + n0) * 2;          // wave-uniform
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
+        if (PSEL >= 0 && p != PSEL) continue;
         const int nl = 64 * wn + 32 * p + 8 * g;
         const f32x4 b0 = *reinterpret_cast<const f32x4*>(side + 2048 + nl * 4), b1 = *reinterpret_cast<const f32x4*>(side + 2048 + nl * 4 + 16);
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(side + 3072 + nl * 4), c1 = *reinterpret_cast<const f32x4*>(side + 3072 + nl * 4 + 16);
@@ -337,8 +340,8 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
             // fp16 residual stores it is neutral, on the attention kernel's 8-byte output stores it costs 2.2 ms, and on the bf16
             // output of the MXFP8 kernel (gemm_fp8.hip) it costs 0.2 ms of that mode's 17.2 ms step.
             if constexpr (ND > 0) {
-                if (p * 8 + mi >= 16 - ND && defer) {                       // (wave-uniform)
-                    pend[p * 8 + mi - (16 - ND)] = __builtin_bit_cast(u32x4, ov);
+                if (16 * H + p * 8 + mi >= 32 - ND && defer) {              // (wave-uniform)
+                    pend[16 * H + p * 8 + mi - (32 - ND)] = __builtin_bit_cast(u32x4, ov);
                     continue;
                 }
             }
@@ -348,15 +351,15 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
 }
 // stores [i0, i1) of the ND deferred ones: the same addresses the epilogue would have used (tile base kept by the caller)
 template <int ND>
-__device__ __forceinline__ void quad_flush_pending(const u32x4* __restrict__ pend, char* __restrict__ tile_out, int N, int wm, int wn,
+__device__ __forceinline__ void quad_flush_pending(const u32x4* __restrict__ pend, char* __restrict__ tile_out, int N, int wm, int wn2,
                                                    int g, int c, int i0, int i1) {
     int r0 = 128 * wm + c;
     asm volatile("" : "+v"(r0));
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
         if (i < i0 || i >= i1) continue;
-        const int idx = 16 - ND + i, p = idx >> 3, mi = idx & 7;
-        const unsigned off = ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(64 * wn + 32 * p + 8 * g)) * 2u;
+        const int s_ = 32 - ND + i, h = s_ >> 4, p = (s_ >> 3) & 1, mi = s_ & 7;
+        const unsigned off = ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(64 * (2 * wn2 + h) + 32 * p + 8 * g)) * 2u;
         __builtin_nontemporal_store(pend[i], reinterpret_cast<u32x4*>(tile_out + off));
     }
 }
@@ -1160,11 +1163,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     KEDS_QG2(FIRST, mi, 6, 7, wc, xc) KEDS_QGAP(4 * (mi) + 3, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)
 // One K-step: 64 MFMAs from (xc, wc); the 16 fragment reads of the NEXT K-step go to (xn, wn_) from buffer `nb` at chunk
 // offset `nslot`; with ISSUE the 16 DMA pieces of K-tile `ip` go out; SYNC: K-tile landed + buffer free (wait + barrier;
-// SYNC = 2: the four youngest memory operations -- deferred output stores of the previous tile -- may stay in flight).
+// SYNC = n >= 2: the n youngest memory operations -- deferred output stores of the previous tile -- may stay in flight).
 #define KEDS_QUAD_STEP(FIRST, xc, wc, xn, wn_, nb, nslot, SYNC, ISSUE, ip, PREFETCH)                           \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr ((int)(SYNC) == 2 && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        if constexpr ((int)(SYNC) >= 2 && !(DBG & 4))                                                          \
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((int)(SYNC) >= 2 ? (int)(SYNC) : 0) : "memory"); \
         else if constexpr (SYNC && !(DBG & 4)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         KEDS_QUAD_GROUP(FIRST, 0, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                             \
@@ -1219,6 +1223,17 @@ __device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_til
 // identical) gains nothing: qkv 186.5 vs 187.5 us, c_fc 251.4 vs 244.9.  The chip runs these kernels at its power cap; an
 // idle half buys the working half clock, and a stall cycle costs little energy, so removing stall cycles -- rather than
 // joules -- buys little time.  (Plain vs non-temporal output stores, any mix: no difference in the isolated GEMM either.)
+// What the stores do cost (stamped build, epilogue without stores: 5.2 k cycles instead of 10.1-11 k + 1.2 k of drain, the
+// launch 184 instead of 209 us) is their back-pressure on the wave that issues them.  Whole 128-byte lines per instruction
+// (lanes c and c ^ 8 swap a chunk with two DPP moves per dword; the burst alone drains 27 % faster so:
+// tools/micro/store_burst.hip) changes nothing in the kernel (qkv 172.5 vs 173.1 us, c_fc slower), but NOT ISSUING a part
+// of them in the epilogue does: the LayerNorm epilogue of this kernel reads the accumulators back a 32-column quarter at a
+// time (64 live registers instead of 128), keeps the last 18 of a lane's 32 packed 16-byte results in registers, and the NEXT
+// tile's K-loop issues them three at a time behind the K-steps of its first three K-tiles, where the memory pipeline carries
+// nothing but the DMA pieces.  vmcnt counts stores and retires in order, so those K-tile waits are counted (vmcnt(6): the
+// stores younger than the DMA pieces stay in flight) -- with vmcnt(0) the trickle returns what it saved.  qkv 170 vs 179 us
+// (same process, medians of 7 x 20); not for the QuickGELU form (c_fc: its stores already leave under 512 transcendentals
+// per lane; deferring costs it 3 us).
 template <int EPI, int STAMP = 0, int PERSIST = 0>
 __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
@@ -1319,11 +1334,13 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     asm volatile("s_waitcnt vmcnt(16) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
     // deferred output stores of the previous tile (PERSIST, LayerNorm epilogues): QUAD_ND x 16 bytes per lane
+    constexpr int QUAD_ND = quad_nd<EPI>();                          // deferred stores per lane
+    constexpr int QUAD_PS = (QUAD_ND + 5) / 6;                        // ... issued per slot (six slots: behind the K-steps of three K-tiles)
     [[maybe_unused]] u32x4 pend[QUAD_ND];
     [[maybe_unused]] char* pend_base = nullptr;
     [[maybe_unused]] bool have_pend = false;
-    // (not the QuickGELU form: with the 48 registers of the deferred stores compiled in, c_fc runs 239-241 us with or without
-    // deferring against 232-236 without the code -- its epilogue, 2 x 256 transcendentals per lane, needs the registers more)
+    // (not the QuickGELU form: its epilogue is 2 x 256 transcendentals per lane long and its stores leave under them; deferring
+    // 12 of them costs c_fc 3 us -- 242.8 vs 239.8 -- even with the quarter-wise read-back that keeps the registers free)
     constexpr bool DEFER = PERSIST && epi_is_ln(EPI) && epi_base(EPI) != KEDS_EPI_BIAS_QGELU_BF16 && !STAMP;
     for (int it = 0;; ++it) {
         char* side = smem + qd::SIDE0 + (it & 1) * 4096;
@@ -1348,23 +1365,23 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         KEDS_QUAD_STEP(true, xa, wa, xb, wb, smem, slot1, false, false, 0, true)
         int p = 0;
         if constexpr (DEFER) {
-            // the previous tile's deferred stores, two behind every K-step of the first three K-tiles (np >= 8 here).  vmcnt
-            // counts stores and retires in order: the K-tile waits of these iterations and of the one behind them leave the four
-            // youngest operations -- stores, younger than the DMA pieces the wait is for -- in flight (a store's acknowledgement
-            // takes longer than a K-step; waited for with vmcnt(0) the trickle gives back what it saved)
+            // the previous tile's deferred stores, QUAD_PS behind every K-step of the first three K-tiles (np >= 8 here).  vmcnt
+            // counts stores and retires in order: the K-tile waits of these iterations and of the one behind them leave the
+            // 2 QUAD_PS youngest operations -- stores, younger than the DMA pieces the wait is for -- in flight (a store's
+            // acknowledgement takes longer than a K-step; waited for with vmcnt(0) the trickle gives back what it saved)
             if (have_pend) {
 #define KEDS_QUAD_PEEL(pp, SY)                                                                                          \
     {                                                                                                                   \
         const char* ob = smem + (((pp) + 1) & 1) * PBUF_BYTES;                                                          \
         KEDS_QUAD_STEP(false, xb, wb, xa, wa, ob, slot0, SY, true, (pp) + 2, true)                                      \
-        quad_flush_pending<QUAD_ND>(pend, pend_base, N, wm, 2 * wn2 + 1, g, c, 4 * (pp), 4 * (pp) + 2);                 \
+        quad_flush_pending<QUAD_ND>(pend, pend_base, N, wm, wn2, g, c, 2 * QUAD_PS * (pp), 2 * QUAD_PS * (pp) + QUAD_PS); \
         KEDS_QUAD_STEP(false, xa, wa, xb, wb, ob, slot1, false, false, 0, true)                                         \
-        quad_flush_pending<QUAD_ND>(pend, pend_base, N, wm, 2 * wn2 + 1, g, c, 4 * (pp) + 2, 4 * (pp) + 4);             \
+        quad_flush_pending<QUAD_ND>(pend, pend_base, N, wm, wn2, g, c, 2 * QUAD_PS * (pp) + QUAD_PS, 2 * QUAD_PS * (pp) + 2 * QUAD_PS); \
     }
                 KEDS_QUAD_PEEL(0, 1)
-                KEDS_QUAD_PEEL(1, 2)
-                KEDS_QUAD_PEEL(2, 2)
-                KEDS_QUAD_PEEL(3, 2)                                   // (nothing left to flush: indices 12-15 do not exist)
+                KEDS_QUAD_PEEL(1, 2 * QUAD_PS)
+                KEDS_QUAD_PEEL(2, 2 * QUAD_PS)
+                KEDS_QUAD_PEEL(3, 2 * QUAD_PS)                         // (nothing left to flush: the indices are past QUAD_ND)
 #undef KEDS_QUAD_PEEL
                 p = 4;
                 have_pend = false;
@@ -1413,21 +1430,30 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         [[maybe_unused]] keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
         [[maybe_unused]] char* red = smem + qd::RED_OFF;
 #define KEDS_QUAD_EPI(h)                                                                                               \
-    if constexpr (epi_is_ln(EPI)) {                                                                                    \
-        if constexpr (DEFER && h == 1)                                                                                 \
-            pair_ln_epilogue<EPI, 0, QUAD_ND>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e, pend, defer_now);\
-        else                                                                                                           \
-            pair_ln_epilogue<EPI, 0>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e);                          \
-    }                                                                                                                  \
+    if constexpr (epi_is_ln(EPI))                                                                                      \
+        pair_ln_epilogue<EPI, 0>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e);                              \
     else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)                                                                \
         pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, stats, red);                    \
     else                                                                                                               \
         tile_epilogue<EPI, 8>(av, bias, out, m0 + 128 * wm + c, M, n0 + 64 * (2 * wn2 + h) + 8 * g, N, K, aux, aux_i, aux2e, N, g == 0);
-        KEDS_QUAD_READ_HALF0(av)
-        KEDS_QUAD_EPI(0)
-        __builtin_amdgcn_sched_barrier(0);
-        KEDS_QUAD_READ_HALF1(av)
-        KEDS_QUAD_EPI(1)
+        if constexpr (DEFER) {
+            // one 32-column quarter at a time: 64 read-back registers live instead of 128 leave room for the deferred stores
+#define KEDS_QUAD_EPQ(h, p)                                                                                             \
+    KEDS_QUAD_READ_Q##h##p(av)                                                                                          \
+    pair_ln_epilogue<EPI, 0, QUAD_ND, h, p>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, aux2e, pend, defer_now);    \
+    __builtin_amdgcn_sched_barrier(0);
+            KEDS_QUAD_EPQ(0, 0)
+            KEDS_QUAD_EPQ(0, 1)
+            KEDS_QUAD_EPQ(1, 0)
+            KEDS_QUAD_EPQ(1, 1)
+#undef KEDS_QUAD_EPQ
+        } else {
+            KEDS_QUAD_READ_HALF0(av)
+            KEDS_QUAD_EPI(0)
+            __builtin_amdgcn_sched_barrier(0);
+            KEDS_QUAD_READ_HALF1(av)
+            KEDS_QUAD_EPI(1)
+        }
 #undef KEDS_QUAD_EPI
         if constexpr (DEFER) {
             have_pend = defer_now;
