@@ -1434,7 +1434,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         }
 
         // ---- epilogues: the 8-wave kernel's, once per 64-column half (wave column 2 wn2 + h) read back from its AGPRs
-        [[maybe_unused]] const bool defer_now = more && aux_i != 0;      // (LayerNorm epilogues do not use aux_i: the A/B switch)
+        // (LayerNorm epilogues do not use aux_i: the A/B switch; the trickle needs the four peeled K-tiles + two more)
+        [[maybe_unused]] const bool defer_now = more && aux_i != 0 && np >= 8;
         [[maybe_unused]] void* stamp_out = aux2;
         void* aux2e = STAMP ? nullptr : aux2;                             // (stamped build: aux2 carries the stamp buffer)
         KEDS_QUAD_DRAIN

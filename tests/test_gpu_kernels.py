@@ -540,13 +540,15 @@ def test_large_gallery_ranking_and_imgnet_metric(nq, ng):
         assert abs(v - mg[k]) <= 1.0 / nq + 1e-6, (k, v, mg[k])
 
 
-@pytest.mark.parametrize("M,K", [(4096, 256), (4096, 1024), (8192 + 1024, 256), (12288, 512)])
+@pytest.mark.parametrize("M,K", [(4096, 256), (4096, 1024), (8192 + 1024, 256), (12288, 512), (11008, 1024), (11008, 256)])
 def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(M, K):
     """The 4-wave 256 x 256 kernel (round 3: one wave per SIMD, 128 x 128 outputs per wave, accumulators in fixed AGPRs) runs
     the same MFMA chains in the same k order and the same epilogues as the 8-wave kernel: every epilogue the towers use must
     give the same bits (plain bias -> bf16, LayerNorm-folded bias / QuickGELU on fp16 operands, fp16 residual + statistics).
-    Its persistent form (one workgroup per CU walks the tiles; M > 4096 here: 2-3 tiles per workgroup, ragged last round)
-    must as well."""
+    Its persistent form (one workgroup per CU walks the tiles; M = 12288 / 11008 here: 768 / 688 tiles = three rounds, the last
+    one ragged -- fewer tiles than 85 % of whole rounds go to the 128 x 128 kernel and would not test it)
+    must as well -- including the LayerNorm epilogue's deferred stores (K >= 512: 18 of a lane's 32 stores of a tile are issued
+    from inside the next tile's K-loop; K = 256 is too short for the trickle and stores everything in the epilogue)."""
     lib = _lib.load()
     N = 4096                                                     # >= 256 tiles of 256 x 256: the big-tile path
     g = torch.Generator(device="cuda").manual_seed(K)
