@@ -903,6 +903,13 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
 //  (d) S^T of key tile t+1 issued in front of P.V of tile t (so that the exp block never waits for its own MFMA chain): the
 //      second score tile is live across the P.V step, 16 registers more than the 128 of four waves per SIMD hold -- 58-82
 //      spilled registers, 22 scratch accesses per four tiles in the loop, with the K fragments read early or late.  Not run.
+//  (e) the round-2 ring again, on this kernel's body and with everything this round learned (keys 128-255 requested behind the
+//      top barrier, keys 0-127 and row 256 of the NEXT item behind the mid-item barrier, its query fragments loaded into the
+//      registers of this item's right behind their last use, a counted vmcnt(4) at the top so that the four output stores
+//      stay in flight, the last-query shares of waves 0-3 before the first half is overwritten; no overflow recompute yet):
+//      bit-identical, the tile loop itself free of scratch, but 48 spilled registers around it (item top, last-query share,
+//      epilogue) -- 122 us against 62.  A scratch reload is a vmcnt wait behind the DMA in flight; the compiler cannot be
+//      told.  The item loop needs hand-allocated registers.
 // In-kernel stamps with XCC_ID: every CU runs exactly 8 workgroups, 1.84 of 2 resident on average, the next workgroup enters
 // 700-900 cycles after an exit, per-CU span 114.6 k cycles mean / 127 k max: a tenth of the launch is the spread between CUs.
 // NOTE (measured, round 2): the "keys 0-127 first" wait of the kernel above is not what the hardware executes: __syncthreads()
