@@ -254,7 +254,9 @@ int keds_fold_layernorm_mxfp8(const float* W, const float* bias, const float* ga
 int keds_gemm_set_workspace(void* ptr, size_t bytes);
 
 /* test/bench hook: bit 0 routes every GEMM through the 128x128 kernel, bit 8 skips the remainder-row launch (timing
- * only), bit 9 disables split-K */
+ * only), bit 9 disables split-K; A/B switches of the 256x256 kernels: bit 10 residual tile as the accumulators' initial
+ * value, bits 11-12 kernel form (1 = 4 waves, 2 = 4 waves persistent, 3 = 8 waves; 0 = by shape), bits 13-15 stamped
+ * diagnostic build, bit 16 no three-deep A ring, bit 17 no deferred epilogue stores in the persistent kernel */
 int keds_gemm_force_small(int on);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (fp32 statistics, eps 1e-5).
