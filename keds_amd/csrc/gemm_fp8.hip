@@ -365,11 +365,23 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
                 v1 = acc[2 * pp + 1][mi] + b1;
             }
             if constexpr (EPI == 2) {
+                // x * sigmoid(1.702 x)  (src/model/model.py:300-302) on whole vectors: the scale, the + 1 and the product are packed
+                // operations (gemm.hip, pair_ln_epilogue: the scalar form compiled to twice the issue slots)
+                f32x4 z0 = v0 * -2.4554669595930157f, z1 = v1 * -2.4554669595930157f;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {                     // x * sigmoid(1.702 x)  (src/model/model.py:300-302)
-                    v0[j] = v0[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v0[j]));
-                    v1[j] = v1[j] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v1[j]));
+                for (int j = 0; j < 4; ++j) {
+                    z0[j] = __builtin_amdgcn_exp2f(z0[j]);
+                    z1[j] = __builtin_amdgcn_exp2f(z1[j]);
                 }
+                z0 = z0 + 1.0f;
+                z1 = z1 + 1.0f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    z0[j] = __builtin_amdgcn_rcpf(z0[j]);
+                    z1[j] = __builtin_amdgcn_rcpf(z1[j]);
+                }
+                v0 = v0 * z0;
+                v1 = v1 * z1;
             }
             if constexpr (EPI == 3 || EPI == 4) {
                 if constexpr (EPI == 3) {
