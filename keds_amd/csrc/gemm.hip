@@ -406,7 +406,9 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
     f32x2* rw = reinterpret_cast<f32x2*>(red) + wn * 256 + r0;
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) {
-        float s = 0.f, ss = 0.f;
+        // {sum, sum of squares} of the lane's 16 values of the row: four vector partial sums first (packed adds / FMAs, two
+        // elements per issue slot), one horizontal sum at the end -- the per-chunk horizontal sums were 448 scalar adds per tile
+        f32x4 sv = f32x4{0.f, 0.f, 0.f, 0.f}, qv = sv;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const f16x8 q = r[p][mi];
@@ -420,9 +422,10 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
                 f16x8* dst = reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
                 *dst = ov;      // (a non-temporal store here is neutral: the stream is re-read by the very next GEMM)
             }
-            s += sum8(v0, v1);
-            ss += sum8(v0 * v0, v1 * v1);
+            sv = sv + (v0 + v1);
+            qv = qv + (v0 * v0 + v1 * v1);
         }
+        float s = (sv[0] + sv[1]) + (sv[2] + sv[3]), ss = (qv[0] + qv[1]) + (qv[2] + qv[3]);
         s = rows_sum(s);                 // the four lanes (g = 0..3) that share the row hold this wave's 64 columns of it
         ss = rows_sum(ss);
         if constexpr (DBG == 4 || DBG == 5) {
