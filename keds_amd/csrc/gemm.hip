@@ -1805,7 +1805,10 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         if (cus > 256) cus = 256;
         cus &= ~7;                                // whole XCD groups: workgroup b and tile ids b, b + grid, ... share an XCD label
         // (the residual epilogue holds 16 residual chunks per lane beside the read-back accumulators: in the tile loop it spills,
-        // out-proj 94 vs 70 us -- that epilogue keeps one tile per workgroup)
+        // out-proj 94 vs 70 us -- that epilogue keeps one tile per workgroup.  Late in round 3, with the quarter-wise read-back
+        // the tile loop no longer spills (209 VGPRs), and still does not pay: out-proj 66.7 vs 66.3 us, c_proj 216 vs 203.5 on
+        // its three-deep ring -- two tiles per workgroup leave one prologue to hide, and the epilogue's residual loads queue
+        // behind the 32 DMA pieces of the next tile in the in-order vmcnt)
         if (quad == 2 && ntiles > cus && cus >= 8 && EPI != KEDS_EPI_RESID_STATS_F16) {
             if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 0, 1>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
             gemm_bt_quad_kernel<EPI, 0, 1><<<cus, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
