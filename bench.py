@@ -342,7 +342,7 @@ def main():
         return Dk, Ik
 
     def step_dual(timed=False):
-        out = keds_amd.compose_query_features(model, s_img, s_txt, images, tokens, database, id_split=265)
+        out = keds_amd.compose_query_features(model, s_img, s_txt, images, tokens, database, id_split=265, verify=False)
         return out["mixture"], None
 
     step = step_dual if dual else step_encode_search

@@ -88,7 +88,9 @@ int keds_index_destroy(keds_index* idx);
 /* append n fp32 rows (host or device): the fp32 rows and the bf16 scan image live in buffers that grow geometrically,
  * only the new rows are copied and packed (amortised O(rows added)); returns once `rows` may be reused.  A chunked build
  * gives the same image, byte for byte, as one add of all rows.  Not to be called while a search of the SAME index is in
- * flight on another stream (Faiss's rule as well). */
+ * flight on another stream (Faiss's rule as well).  The call has no stream argument: a DEVICE source is waited for with one
+ * device synchronisation before it is read (rows produced on any stream of the caller are complete by then); a host
+ * source is read synchronously. */
 int keds_index_add(keds_index* idx, const float* rows, int64_t n);
 int64_t keds_index_ntotal(const keds_index* idx);
 /* copy of the bf16 scan image (keds_hip.h: keds_index_packed_bytes(ntotal, dim) bytes, host or device destination): what a

@@ -775,6 +775,15 @@ extern "C" int keds_index_add(keds_index* idx, const float* rows, int64_t n) {
         idx->packed = packed;
         idx->cap = cap;
     }
+    {   // a DEVICE source may still be being written on a non-blocking stream of the caller (every torch.cuda.Stream is one;
+        // the null stream does not order behind those): the API has no stream argument, so wait for the device once
+        // (keds_session.h states the contract).  Host sources need nothing.
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, rows) == hipSuccess && at.type == hipMemoryTypeDevice)
+            HIP_TRY(hipDeviceSynchronize(), what);
+        else
+            (void)hipGetLastError();                              // (an unregistered host pointer reports an error: cleared)
+    }
     HIP_TRY(hipMemcpyAsync(idx->rows + (size_t)idx->n * idx->dim, rows, (size_t)n * row_bytes, hipMemcpyDefault, nullptr), what);
     if ((rc = keds_index_pack_append(idx->rows, idx->n, total, idx->dim, idx->metric, idx->packed, nullptr))) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr), what);       // `rows` may be reused by the caller; the image is complete
@@ -787,8 +796,12 @@ extern "C" int keds_index_image(const keds_index* idx, void* packed_out, size_t 
     KEDS_REQUIRE(idx && packed_out, "%s: bad argument", what);
     KEDS_REQUIRE(idx->n > 0, "%s: the index is empty", what);
     KEDS_REQUIRE(bytes >= keds_index_packed_bytes(idx->n, idx->dim), "%s: buffer smaller than keds_index_packed_bytes(ntotal, dim)", what);
+    int prev = -1;                                                // the caller's current device is left as it was
+    (void)hipGetDevice(&prev);
     HIP_TRY(hipSetDevice(idx->device), what);
-    HIP_TRY(hipMemcpy(packed_out, idx->packed, keds_index_packed_bytes(idx->n, idx->dim), hipMemcpyDefault), what);
+    const hipError_t e = hipMemcpy(packed_out, idx->packed, keds_index_packed_bytes(idx->n, idx->dim), hipMemcpyDefault);
+    if (prev >= 0 && prev != idx->device) (void)hipSetDevice(prev);
+    HIP_TRY(e, what);
     return KEDS_OK;
 }
 

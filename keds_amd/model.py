@@ -311,13 +311,30 @@ class CLIP(nn.Module):
         self._guard_poll(wait=True)
         return self.numerics_tripped
 
+    def numerics_checked(self, fn):
+        """Run `fn()` (any number of encoder passes whose outputs the caller KEEPS: a feature-extraction or evaluation loop)
+        and return its result only after every pass in it has been verified: the lazily checked guard is synchronised
+        behind the loop, and when it tripped while passes of this loop had already been returned from the fast flow
+        (`numerics_late_trip`), the loop is run again -- the model is on the fp32-stream flow by then, so the second run is
+        clean.  Loops that collect features must not end on an unverified pass (retrieval.py uses this everywhere)."""
+        before = self.numerics_late_trip
+        out = fn()
+        self.numerics_sync()
+        if self.numerics_late_trip and not before:
+            out = fn()
+            self.numerics_sync()
+        return out
+
     def _guarded(self, run):
         """Run one tower pass (`run(engine)` enqueues it and returns the output tensor) under the numerics guard."""
+        # (a stream that is being captured into a hipGraph can be neither synchronised nor queried -- an event query inside a
+        # global-mode capture invalidates it: no flag read there; call numerics_sync() before the capture, or capture a
+        # model on set_numerics("safe"))
+        if torch.cuda.is_current_stream_capturing():
+            return run(self._engine())
         self._guard_poll(wait=False)
         eng = self._engine()
-        # (a stream that is being captured into a hipGraph cannot be synchronised: no flag read there -- capture a model whose
-        # activations were checked eagerly, or set_numerics("safe"))
-        if self.numerics != "auto" or not eng.folded or self.precision == "fp8" or torch.cuda.is_current_stream_capturing():
+        if self.numerics != "auto" or not eng.folded or self.precision == "fp8":
             return run(eng)
         if self._guard is None or self._guard.device != eng.device:
             self._guard = torch.zeros(1, dtype=torch.int32, device=eng.device)

@@ -39,9 +39,14 @@ def extract_feature_database(model: CLIP, image_batches, text_batches, out_dir: 
     (image_bases, text_bases) as float32 [N, D] device tensors -- what `build_database` takes.  With `out_dir` the two
     matrices are also written as `cc_image_databases.pt` / `cc_text_databases.pt` (plain float32 tensors: the reference's
     own on-disk format) and the ready-to-search indices as `cc_image_index.pt` / `cc_text_index.pt` (FlatIndex.save)."""
-    imgs = [model.encode_image(b.to(device) if device is not None else b, normalize=True).float() for b in image_batches]
-    txts = [model.encode_text(b.to(device) if device is not None else b, normalize=True).float() for b in text_batches]
-    image_bases, text_bases = torch.cat(imgs), torch.cat(txts)
+    image_batches, text_batches = list(image_batches), list(text_batches)      # (a second pass must see the same batches)
+
+    def encode_all():
+        imgs = [model.encode_image(b.to(device) if device is not None else b, normalize=True).float() for b in image_batches]
+        txts = [model.encode_text(b.to(device) if device is not None else b, normalize=True).float() for b in text_batches]
+        return torch.cat(imgs), torch.cat(txts)
+    # no row enters the database from an unverified pass of the numerics guard (CLIP.numerics_checked)
+    image_bases, text_bases = model.numerics_checked(encode_all)
     if image_bases.shape != text_bases.shape:
         raise RuntimeError(f"image / text databases differ in shape: {tuple(image_bases.shape)} vs {tuple(text_bases.shape)}")
     if out_dir is not None:
@@ -75,14 +80,17 @@ def extract_feature_database_sharded(model: CLIP, n_rows: int, image_rows, text_
     os.makedirs(out_dir, exist_ok=True)
     out = []
     for name, rows_fn, enc in (("image", image_rows, enc_i), ("text", text_rows, enc_t)):
-        idx = None
-        for a in range(lo, hi, batch):
-            b = min(hi, a + batch)
-            x = rows_fn(a, b)
-            f = enc(x.to(device) if device is not None else x).float()
-            if idx is None:
-                idx = FlatIndex(f.shape[1], "l2", device=f.device, row0=lo)
-            idx.add(f)                                            # chunked add: packs only the new stages
+        def encode_shard():
+            idx = None
+            for a in range(lo, hi, batch):
+                b = min(hi, a + batch)
+                x = rows_fn(a, b)
+                f = enc(x.to(device) if device is not None else x).float()
+                if idx is None:
+                    idx = FlatIndex(f.shape[1], "l2", device=f.device, row0=lo)
+                idx.add(f)                                        # chunked add: packs only the new stages
+            return idx
+        idx = model.numerics_checked(encode_shard)                # (re-encoded on the safe flow if the guard tripped late)
         if idx is None:
             raise RuntimeError(f"rank {rank} of {world} owns no rows of a {n_rows}-row database")
         idx.save(os.path.join(out_dir, f"cc_{name}_index.shard{rank}-of-{world}.pt"))
@@ -129,14 +137,23 @@ def get_retrieved_features(feature: torch.Tensor, database, args=None, topk: int
 def compose_query_features(model: CLIP, stream_image: KnowledgeStream, stream_text: KnowledgeStream,
                            ref_images: torch.Tensor, text_with_blank: torch.Tensor, database,
                            id_split: int = 265, topk: int = 16, repeat: bool = False,
-                           w_text_stream: float = 0.5) -> Dict[str, torch.Tensor]:
+                           w_text_stream: float = 0.5, verify: bool = True) -> Dict[str, torch.Tensor]:
     """Per-batch body of evaluate_cirr (eval_utils.py:652-714).  evaluate_coco (:511-548) is the same body with
     mixture weight w = 0.05 j for the text stream, evaluate_imgnet_retrieval (:372-415) passes ONE prompt row with
     repeat=True and w = 0.1 j.
 
     Returns the reference's three feature sets under its dict names (eval_utils.py:728-732):
     'composed' = image-stream feature, 'image' = text-stream feature, 'mixture' = their normalised mean.
+
+    verify (default): the batch's three encoder passes are verified by the numerics guard before the features are
+    returned, and re-run on the fp32-stream flow if it tripped (`CLIP.numerics_checked`: one host wait per batch, which
+    the reference's own `.cpu()` in get_retrieved_features pays too).  A caller that keeps the device busy across
+    batches passes verify=False and calls `model.numerics_sync()` itself before it uses the features (bench.py).
     """
+    if verify:
+        return model.numerics_checked(lambda: compose_query_features(
+            model, stream_image, stream_text, ref_images, text_with_blank, database, id_split=id_split, topk=topk,
+            repeat=repeat, w_text_stream=w_text_stream, verify=False))
     q = model.encode_image(ref_images).float()
     topk_image, topk_text = get_retrieved_features(q, database, None, topk=topk)
     tok_a = stream_image(q, topk_image, topk_text)                                   # [B,3,D]

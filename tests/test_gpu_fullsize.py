@@ -160,6 +160,15 @@ def test_numerics_guard_switches_flow_when_rows_lose_their_centre():
         assert lazy.numerics_sync() is True
     assert lazy.numerics_tripped and lazy.numerics_late_trip
     assert torch.equal(lazy.encode_image(img.cuda()), got)  # the safe flow from here on
+    # a loop that KEEPS its outputs (feature extraction, evaluation: everything in retrieval.py) runs under numerics_checked:
+    # the guard is synchronised behind the loop and a late trip re-runs the loop on the safe flow, so no feature of an
+    # unverified fast-flow pass reaches the caller
+    keep = keds_amd.build_model({k: v for k, v in sd.items()}, fp16=False).cuda()
+    keep._engine()
+    keep._guard_eager_left = 0
+    with pytest.warns(RuntimeWarning, match="numerics_late_trip"):
+        feats = keep.numerics_checked(lambda: [keep.encode_image(img.cuda()) for _ in range(3)])
+    assert keep.numerics_late_trip and all(torch.equal(f, got) for f in feats)
     for _ in range(keds_amd.model.GUARD_EAGER_PASSES + 3):  # a benign model crosses from eager to lazy checks without a trip
         ok.encode_image(img.cuda())
     assert ok.numerics_sync() is False and ok._guard_eager_left == 0

@@ -589,7 +589,8 @@ def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(M, K):
         finally:
             lib.keds_gemm_force_small(0)
     eight, four, deep = run(3 << 11), run(1 << 11), run(2 << 11)       # (2 << 11: the 4-wave kernel's persistent form)
+    default = run(0)                                                   # what the dispatcher picks by shape (quad_by_shape)
     want = xb.float() @ wb.float().t() + b
     assert rel_l2(four[0], want) <= 4e-3
-    for a, c, d in zip(eight, four, deep):
-        assert torch.equal(a, c) and torch.equal(a, d)
+    for a, c, d, e in zip(eight, four, deep, default):
+        assert torch.equal(a, c) and torch.equal(a, d) and torch.equal(a, e)

@@ -4,6 +4,7 @@ reference's checkpoint contract and fails loudly without a GPU, and the multi-ra
 import json
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -366,3 +367,17 @@ def test_bench_gpus_n_launches_its_own_ranks_before_touching_the_gpu():
     finally:
         import shutil
         shutil.rmtree(stub, ignore_errors=True)
+
+
+def test_quad_gemm_kernels_keep_their_accumulators_to_the_generated_statements():
+    """The 4-wave GEMM kernels keep 256 accumulators in fixed AGPRs that the compiler is not told about (gemm_quad_gen.h):
+    the gfx950 assembly of every instantiation must allocate exactly 256 AGPRs, touch them only in v_mfma / the 256
+    read-backs, and carry no scratch traffic in the forms the dispatcher uses (tools/check_quad_asm.py; hipcc -S, no GPU)."""
+    import shutil
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not (os.path.exists(hipcc) or shutil.which(hipcc)):
+        pytest.skip("hipcc not available")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_quad_asm.py")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+    assert "0 problem(s)" in res.stdout
