@@ -40,19 +40,73 @@ PEAK_FP8_MEASURED_TFLOPS = 3400.0    # register-only v_mfma_scale_f32_16x16x128_
 PEAK_BF16_MEASURED_TFLOPS = 2060.0   # tools/micro/mfma_peak.hip on the gpurun MI355X
 PEAK_HBM_MEASURED_GBPS = 7150.0      # tools/micro/hbm_stream.hip (read-only)
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes
+
+
+def evidence(kind):
+    """Newest committed measurement file profiles/r<NN>_<kind>.json (by round number) -- only while it still describes THIS
+    build: the file carries the digest of the kernel sources it was measured on (keds_amd._lib.source_digest, written by
+    tools/parse_pmc.py / tools/update_parity_baseline.py) and is dropped when csrc/ or include/ changed since.  Returns
+    (dict or None, note) where `note` names the file, its digest and -- when a .git is present -- the commit that last
+    touched it.  (No .git travels to the GPU box, so staleness is decided by the digest, not by `git diff`.)"""
+    import glob
+    import re
+    import subprocess
+    from keds_amd import _lib
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", f"r*_{kind}.json")):
+        m = re.match(r"r(\d+)_" + re.escape(kind) + r"\.json$", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    if best is None:
+        return None, f"no profiles/r*_{kind}.json committed"
+    f = best[1]
+    try:
+        d = json.load(open(f))
+    except Exception as e:                                            # noqa: BLE001
+        return None, f"{os.path.basename(f)} unreadable ({e})"
+    now = _lib.source_digest()
+    name = "profiles/" + os.path.basename(f)
+    commit = ""
+    try:
+        r = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", f], capture_output=True, text=True, timeout=10)
+        if r.returncode == 0 and r.stdout.strip():
+            commit = f", commit {r.stdout.strip()}"
+    except Exception:                                                 # noqa: BLE001  (no git on the GPU box)
+        pass
+    if d.get("csrc_sha16") != now:
+        return None, f"{name} is stale: measured on sources {d.get('csrc_sha16')}, this build is {now}{commit}"
+    return d, f"{name} (sources {now}{commit})"
 
 
 def pmc_traffic(kernel_key, batch, rows, world):
     """HBM bytes per launch of `kernel_key` from the committed PMC passes (tools/pmc_step.py + tools/parse_pmc.py:
     separate --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of this same workload, FETCH_SIZE doubled per the gfx950
-    rule of MI355X_MICROARCH.md).  Only valid for the configuration they were taken on; otherwise None."""
-    if batch != 128 or rows != 500000 or world != 1 or not os.path.exists(PMC_FILE):
-        return None
-    e = json.load(open(PMC_FILE)).get(kernel_key)
+    rule of MI355X_MICROARCH.md).  Only valid for the configuration and the sources they were taken on; otherwise None.
+    Returns (bytes or None, note)."""
+    if batch != 128 or rows != 500000 or world != 1:
+        return None, "PMC passes are of the 1-GPU B=128, 0.5 M-row configuration only"
+    d, note = evidence("pmc_traffic")
+    e = (d or {}).get(kernel_key)
     if not e:
-        return None
-    return e.get("hbm_read_bytes_per_launch", 0.0) + e.get("hbm_write_bytes_per_launch", 0.0)
+        return None, note
+    return e.get("hbm_read_bytes_per_launch", 0.0) + e.get("hbm_write_bytes_per_launch", 0.0), note
+
+
+def recall_parity():
+    """Recall@k parity with the reference's CPU path on identical inputs, from the newest committed parity file (measured by
+    tests/test_gpu_fullsize.py on the reference-minted ViT-L/14 1k-gallery fixture); None when that file does not describe
+    this build."""
+    d, note = evidence("parity")
+    if d is None:
+        return None, note
+    out = {}
+    for key, label in (("recall_vitl14", "default (bf16/fp16 operands)"), ("recall_vitl14.fp32", "set_precision('fp32')")):
+        r = d.get("other_metrics", {}).get(key)
+        if r:
+            ks = sorted(int(k[2:]) for k in r if k.startswith("R@"))
+            out[label] = {"outcomes_flipped_of_%d" % (256 * len(ks)): r.get("outcomes_flipped_inside_tolerance"),
+                          "recall": {f"R@{k}": r[f"R@{k}"] for k in ks}, "reference": {f"R@{k}": r[f"ref_R@{k}"] for k in ks}}
+    return (out or None), note
 
 
 def random_clip(device):
@@ -71,43 +125,49 @@ def random_clip(device):
     return model.eval()
 
 
+def cpu_threads():
+    """Fixed thread count of the CPU baseline: one thread per physical core (half the logical CPUs of an SMT-2 host), at most
+    128 -- oversubscribing a many-core host makes torch's CPU GEMMs slower, and a per-run pilot made the number wander
+    (1.1-3.7 query-images/s over three driver runs of round 3)."""
+    ncpu = os.cpu_count() or 1
+    return max(1, min(ncpu // 2 if ncpu >= 16 else ncpu, 128))
+
+
 def cpu_baseline(model, n_db, dim, k):
-    """Oracle (CPU restatement, fp32 torch) timed on this host's cores on a bounded sample (about 20-30 s):
-    2 images through ViT-L/14 and 128 queries against a 65,536-row slice, scaled to one
-    query-image = 1 encode + 1 top-k over n_db rows.  The thread count is the fastest of a short pilot
-    (one residual block) because oversubscribing a many-core host makes torch's CPU GEMMs slower."""
+    """Oracle (CPU restatement, fp32 torch) timed on this host's cores on a bounded sample, per BASELINE.md section 2: fixed
+    threads, 1 warm-up, median of 3 -- B = 8 images through ViT-L/14 and 128 queries against a 65,536-row slice, scaled to
+    one query-image = 1 encode + 1 top-k over n_db rows (about 15 s of CPU work)."""
+    import statistics
     from oracle import keds_oracle as O
     ncpu = os.cpu_count() or 1
+    threads = cpu_threads()
+    torch.set_num_threads(threads)
     sd = {k_: v.detach().float().cpu() for k_, v in model.state_dict().items() if k_.startswith("visual.")}
     for k_ in ("text_projection", "positional_embedding", "token_embedding.weight", "ln_final.weight"):
         sd[k_] = model.state_dict()[k_].detach().float().cpu()   # arch inference reads their shapes only
-    img = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(1))
+    nb = 8
+    img = torch.randn(nb, 3, 224, 224, generator=torch.Generator().manual_seed(1))
     with torch.no_grad():
-        x = torch.randn(2, 257, 1024)
-        best_t, threads = None, 1
-        for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128, ncpu)}):
-            torch.set_num_threads(th)
-            O.residual_block(x, sd, "visual.transformer.resblocks.0.", 16, False)
+        O.encode_image(sd, img[:2])                              # warm-up (thread pool, allocator)
+        ts = []
+        for _ in range(3):
             t0 = time.perf_counter()
-            O.residual_block(x, sd, "visual.transformer.resblocks.0.", 16, False)
-            dt = time.perf_counter() - t0
-            if best_t is None or dt < best_t:
-                best_t, threads = dt, th
-        torch.set_num_threads(threads)
-        t0 = time.perf_counter()
-        O.encode_image(sd, img)
-        t_img = (time.perf_counter() - t0) / img.shape[0]
+            O.encode_image(sd, img)
+            ts.append((time.perf_counter() - t0) / nb)
+        t_img = statistics.median(ts)
         rows = 65536
         db = torch.nn.functional.normalize(torch.randn(rows, dim, generator=torch.Generator().manual_seed(2)), dim=1)
         q = torch.nn.functional.normalize(torch.randn(128, dim, generator=torch.Generator().manual_seed(3)), dim=1)
         O.flat_l2_search_f32(db, q, k)
-        t0 = time.perf_counter()
-        reps = 3
-        for _ in range(reps):
+        tq = []
+        for _ in range(3):
+            t0 = time.perf_counter()
             O.flat_l2_search_f32(db, q, k)
-        t_q = (time.perf_counter() - t0) / reps / q.shape[0] * (n_db / rows)
+            tq.append((time.perf_counter() - t0) / q.shape[0] * (n_db / rows))
+        t_q = statistics.median(tq)
     return {"value": 1.0 / (t_img + t_q), "unit": "query-images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle fp32, {threads} of {ncpu} host threads: 2 images through ViT-L/14 ({t_img:.2f} s/image) "
+            "sample": f"oracle fp32, {threads} of {ncpu} host threads (fixed: one per physical core), 1 warm-up + median of 3: "
+                      f"{nb} images through ViT-L/14 ({t_img:.2f} s/image; runs {', '.join(f'{t:.2f}' for t in ts)}) "
                       f"+ 128 queries x {rows}-row slice scaled to {n_db} rows ({t_q * 1e3:.2f} ms/query)"}
 
 
@@ -130,7 +190,7 @@ def cpu_baseline_dual(model, s_img, s_txt, n_db, dim):
     two scans are scaled to n_db rows, the rest is per query."""
     from oracle import keds_oracle as O
     ncpu = os.cpu_count() or 1
-    threads = min(ncpu, 64)
+    threads = cpu_threads()
     torch.set_num_threads(threads)
     sd = {k_: v.detach().float().cpu() for k_, v in model.state_dict().items()}
     streams = []
@@ -155,13 +215,6 @@ def cpu_baseline_dual(model, s_img, s_txt, n_db, dim):
     return {"value": 1.0 / t_query, "unit": "queries/sec", "cores": threads, "kind": "port",
             "sample": f"oracle fp32, {threads} of {ncpu} host threads: 2 composed queries against two {rows}-row slices "
                       f"({t_all:.2f} s/query), the two scans scaled to {n_db} rows (+{2.0 * t_scan * (n_db / rows - 1.0) * 1e3:.1f} ms/query)"}
-
-
-# Recall@k parity statement carried in every bench line (measured by tests/test_gpu_fullsize.py on the committed
-# reference fixture; the numbers of the final build are in profiles/r03_parity.json)
-RECALL_PARITY = ("Recall@{1,5,10,50,100} on the reference's ViT-L/14 1k-gallery fixture (256 queries, 1,280 (query, k) outcomes): "
-                 "equal to the reference CPU path except outcomes the reference itself decides by a score gap < 5e-4 (bf16 operand "
-                 "rounding) -- measured: 1 of 1,280 (Recall@10 78.52 vs 78.13; R@1/5/50/100 identical), profiles/r03_parity.json")
 
 
 def self_launch(gpus, argv):
@@ -464,6 +517,10 @@ def main():
             workload = ("ViT-L/14 encode_image (224x224 synthetic, random-init weights) + exact top-%d over a synthetic "
                         "unit-norm %.1fM x 768 database" % (k, N / 1e6))
             par = f"dp{world} encoders + {world}-way row-sharded scan"
+        gemm_traffic, gemm_traffic_note = (None, "PMC passes are of the bf16 encode_search workload only") if (fp8 or dual) \
+            else pmc_traffic("gemm_256x256_all", B, N, world)
+        scan_traffic, scan_traffic_note = (None, "n/a") if dual else pmc_traffic("scan_topk_kernel<768, 16", B, N, world)
+        parity, parity_note = recall_parity()
         out = {
             "metric": metric,
             "value": world * B * steps / elapsed,
@@ -477,8 +534,9 @@ def main():
                        "db_shards": world, "parallelism": par},
             "roofline": {"kernel": ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_quad_kernel / gemm_bt_quad3_kernel / gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
                          "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
-                         "traffic": None if (fp8 or dual) else pmc_traffic("gemm_256x256_all", B, N, world), "traffic_unit": "bytes/launch (PMC, mean "
-                         "over the 256x256 GEMM launches; committed rocprofv3 --pmc passes of this workload, " + os.path.basename(PMC_FILE) + ")",
+                         "traffic": gemm_traffic, "traffic_unit": "bytes/launch (PMC, mean over the 256x256 GEMM launches; committed "
+                         "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; null when they are not of this build)",
+                         "traffic_source": gemm_traffic_note,
                          "launches": gemm_n, "avg_launch_ms": gemm_ms / max(gemm_n, 1),
                          "flops_counted_at_launch": gemm_work,
                          # practical ceiling of this chip, measured (profiles/r01_microbench.txt): a register-only
@@ -486,7 +544,7 @@ def main():
                          "peak_measured": peak_meas_tf, "frac_of_measured": ach / peak_meas_tf},
             "roofline_scan": {"kernel": "scan_topk_kernel", "bound": "hbm", "achieved": scan_ach,
                               "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": scan_ach / PEAK_HBM_GBPS,
-                              "traffic": None if dual else pmc_traffic("scan_topk_kernel<768, 16", B, N, world),
+                              "traffic": scan_traffic, "traffic_source": scan_traffic_note,
                               "algorithmic_bytes_per_search": (hi - lo) * D * 2.0,
                               "launches": scan_n, "searches": n_search, "ms_per_search": scan_ms / max(n_search, 1),
                               "whole_search": whole,
@@ -506,7 +564,7 @@ def main():
                                   "scan": scan_ms / psteps, "other": other_ms / psteps},
             # Recall@k parity with the reference's CPU path on identical inputs (tests/test_gpu_fullsize.py, fixture
             # recall_vitl14.npz: ViT-L/14, 1 k gallery, 256 queries x k in {1,5,10,50,100}); see profiles/r03_parity.json
-            "recall_parity": RECALL_PARITY,
+            "recall_parity": parity, "recall_parity_source": parity_note,
         }
         if world == 1 and not args.no_cpu_baseline and not dual:
             out["cpu_baseline"] = cpu_baseline(model, N, D, k)

@@ -30,7 +30,7 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 5
+#define KEDS_ABI_VERSION 6
 
 int keds_abi_version(void);
 const char* keds_last_error(void);
@@ -342,6 +342,11 @@ typedef struct {
     int last_cls_only;                              /* 1: after the LAST block only token 0 of every sample is
                                                        defined (ViT read-out): its attention queries, out-proj, ln_2
                                                        and MLP run on B rows instead of B*seq */
+    int f32;                                        /* 1: the fp32-ACCURATE flow (section 10; the reference's own eval
+                                                       arithmetic, eval_retrieval.py:108-109): qkv_w / out_w / fc_w / proj_w of
+                                                       every block -- and conv_w / proj_t of the enclosing vit / text struct --
+                                                       point to FP32 arrays of the same shapes; the folded / MXFP8 fields are
+                                                       unused; fp8 must be 0 */
 } keds_tower_params;
 
 typedef struct {
@@ -362,6 +367,7 @@ typedef struct {
 } keds_text_params;
 
 size_t keds_tower_workspace_bytes(int width, int seq, int B);
+size_t keds_tower_workspace_bytes_ex(const keds_tower_params* p, int B);   /* knows the fp32-accurate flow (p->f32) */
 /* Rows (B*seq mod 256) that a tower pass of keds_vit_run / keds_text_run runs as their own chain on a second, high-priority
  * stream beside the full 256-row tiles (0: one stream; always 0 with KEDS_SIDE_STREAM=0, and 0 with KEDS_TOWER_FILL=1, an
  * experiment that runs the ragged last row tile as a full tile on filler rows -- measured slower, off by default).
@@ -507,6 +513,28 @@ int keds_adamw_step(float* p, const float* g, float* m, float* v, int64_t n, flo
 int keds_rows_scatter(const float* src, const int32_t* map, float* dst, int64_t ld_dst, int rows, int dim, int accumulate,
                       void* stream);
 int keds_rows_gather(const float* src, int64_t ld_src, const int32_t* map, float* dst, int rows, int dim, void* stream);
+
+/* =====================================================================================
+ * 10. The fp32-accurate operating point (csrc/f32path.hip)
+ * =====================================================================================
+ * The reference evaluates in fp32 (src/eval_retrieval.py:108-109, flag src/params.py:227-232).  These kernels run the same
+ * path WITHOUT rounding any operand: products on the f32-input matrix instruction (exact fp32 products, fp32 accumulate),
+ * fp32 residual stream / LayerNorm output / q, k, v / probabilities / MLP hidden layer.  keds_vit_run / keds_text_run /
+ * keds_tower_forward take this flow when keds_tower_params.f32 = 1 (CLIP.set_precision("fp32"), KEDS_F32 compute of
+ * keds_vit_create / keds_text_create).  About 1/10 of the default flow's throughput: an accuracy reference, not the headline. */
+#define KEDS_F32_EPI_BIAS 0      /* out = acc + bias                                   */
+#define KEDS_F32_EPI_QGELU 1     /* out = quick_gelu(acc + bias)   (model.py:300-302)  */
+#define KEDS_F32_EPI_RESID 2     /* out += acc + bias                                  */
+#define KEDS_F32_EPI_RELU 3      /* out = max(acc + bias, 0)                           */
+#define KEDS_F32_EPI_PATCH 4     /* patch embedding: row remap + positional embedding (aux = pos_emb [G+1, N], aux_i = G) */
+/* out[M,N] (row stride ldc) = epilogue(A[M,K] (row stride lda) . W[N,K]^T + bias); all fp32; N % 128 == 0, K % 16 == 0,
+ * strides multiples of 4; bias nullable */
+int keds_gemm_f32(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M, int N, int K,
+                  int epilogue, const float* aux, int aux_i, void* stream);
+/* keds_attention_ex on fp32 qkv [B*S, 3*d] -> out fp32 [B*S, d]; q_limit <= 0: all rows; S <= 288 */
+int keds_attention_f32(const float* qkv, float* out, int B, int S, int heads, int causal, int q_limit, void* stream);
+/* keds_im2col with an fp32 patch matrix [B*G, Kpad] (Kpad % 16 == 0) */
+int keds_im2col_f32(const float* image, float* out, int B, int R, int P, int Kpad, void* stream);
 
 #ifdef __cplusplus
 }

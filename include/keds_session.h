@@ -53,7 +53,7 @@ int keds_ctx_create(int device, keds_ctx** out);
 int keds_ctx_destroy(keds_ctx* ctx);
 
 /* ---- image tower: keys "visual.*" of a CLIP state_dict (other keys are ignored) ------------- */
-int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute /* KEDS_BF16 | KEDS_FP8 */, keds_vit** out);
+int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute /* KEDS_BF16 | KEDS_FP8 | KEDS_F32 (the fp32-accurate flow, keds_hip.h section 10) */, keds_vit** out);
 int keds_vit_destroy(keds_vit* vit);
 /* width, layers, heads, resolution, patch, embed_dim inferred from the shapes */
 int keds_vit_info(const keds_vit* vit, int* width, int* layers, int* resolution, int* patch, int* embed_dim);

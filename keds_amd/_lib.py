@@ -17,12 +17,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 
 # ---- constants mirrored from keds_hip.h ------------------------------------------------------
-ABI_VERSION = 5
+ABI_VERSION = 6
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
 EPI_LN_BIAS_BF16_H, EPI_LN_QGELU_BF16_H = 10, 11
 EPI_BIAS_BF16_HEADF32 = 12
+F32_EPI_BIAS, F32_EPI_QGELU, F32_EPI_RESID, F32_EPI_RELU, F32_EPI_PATCH = range(5)
 FP8_EPI_BIAS_BF16, FP8_EPI_LN_BIAS_BF16, FP8_EPI_LN_QGELU_MX, FP8_EPI_RESID_STATS_MX, FP8_EPI_RESID_STATS_MX_H = range(5)
 PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
 SCAN_MAX_K = 128
@@ -39,7 +40,7 @@ class BlockParams(C.Structure):
 
 class TowerParams(C.Structure):
     _fields_ = [("width", i32), ("layers", i32), ("heads", i32), ("seq", i32), ("causal", i32),
-                ("blocks", C.POINTER(BlockParams)), ("fp8", i32), ("last_cls_only", i32)]
+                ("blocks", C.POINTER(BlockParams)), ("fp8", i32), ("last_cls_only", i32), ("f32", i32)]
 
 
 class VitParams(C.Structure):
@@ -188,6 +189,10 @@ SIGNATURES = {
     "keds_cast_bf16": (i32, [vp, vp, i64, vp]),
     "keds_tower_fill_enable": (i32, [i32]),
     "keds_tower_workspace_bytes": (sz, [i32, i32, i32]),
+    "keds_tower_workspace_bytes_ex": (sz, [C.POINTER(TowerParams), i32]),
+    "keds_gemm_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
+    "keds_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "keds_im2col_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_tokenizer_create": (i32, [C.c_char_p, C.POINTER(vp)]),
     "keds_tokenizer_destroy": (None, [vp]),
     "keds_tokenizer_special": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),
@@ -241,6 +246,24 @@ def load() -> C.CDLL:
         raise RuntimeError(f"libkeds_hip.so ABI {got} != expected {ABI_VERSION}")
     _lib = lib
     return lib
+
+
+def source_digest() -> str:
+    """First 16 hex digits of the SHA-256 over the kernel sources (csrc/*.hip, *.h, *.cpp, Makefile and include/*.h, in name
+    order).  Measurement files under profiles/ carry the digest of the sources they were taken on; bench.py quotes a
+    committed PMC / parity number only while this digest still matches (no .git travels to the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = []
+    for pat in ("csrc/*.hip", "csrc/*.h", "csrc/*.cpp", "csrc/Makefile"):
+        files += glob.glob(os.path.join(_HERE, pat))
+    files += glob.glob(os.path.join(os.path.dirname(_HERE), "include", "*.h"))
+    for f in sorted(files, key=lambda x: os.path.relpath(x, os.path.dirname(_HERE))):
+        h.update(os.path.relpath(f, os.path.dirname(_HERE)).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def last_error() -> str:

@@ -1,0 +1,345 @@
+// The fp32-ACCURATE operating point of the encoder path (CLIP.set_precision("fp32"), keds_tower_params.f32 = 1).
+//
+// The reference evaluates in fp32 (src/eval_retrieval.py:108-109, `--precision` src/params.py:227-232: the default `amp`
+// converts the model to fp32 and no autocast is entered in eval), and north_star asks for Recall@k EQUAL to that path.  The
+// default flow of this library rounds GEMM operands to bf16 / fp16 and differs from the reference by a
+// few 1e-3 in the embeddings -- enough to flip a (query, k) outcome the reference itself decides by a margin below 5e-4.  This
+// file is the flow without operand rounding: every product runs on the f32-input matrix instruction
+// (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32 accumulate = an fmaf chain, cdna_hip_programming.md section 3), the
+// residual stream, the LayerNorm output, q / k / v, the attention probabilities and the MLP hidden layer all stay fp32.
+// Throughput is secondary here (the f32 matrix rate is 1/16 of the bf16 one): simple tiles, no side lane, no fused LayerNorm.
+//
+//   gemm_f32_kernel       out[M,N] = epilogue(X[M,K] . W[N,K]^T + bias)      model.py:309-326 (in/out projections, MLP), :381 (conv1)
+//   attention_f32_kernel  softmax(q k^T / 8 [+ causal mask]) v per (sample, head) model.py:319-321, nn.MultiheadAttention
+//   im2col_f32            patch rows of the conv1-as-GEMM                     model.py:394-398
+#include "keds_common.h"
+#include <math.h>
+
+int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
+                        const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
+
+namespace {
+
+namespace g32 {
+constexpr int TM = 128, TN = 128, TK = 16;
+constexpr int LD = TM + 4;            // k-major LDS image [TK][LD]: fragment reads are consecutive dwords (conflict free)
+}  // namespace g32
+
+enum { F32_EPI_BIAS = 0, F32_EPI_QGELU = 1, F32_EPI_RESID = 2, F32_EPI_RELU = 3, F32_EPI_PATCH = 4 };
+
+// 128 x 128 x 16 tile, 4 waves (2 x 2), each wave 64 (n) x 64 (m) = 2 x 2 tiles of v_mfma_f32_32x32x2_f32.  W is the MFMA A
+// operand and X the B operand (as in gemm.hip): the accumulator then holds, per lane, ONE output row m and runs of four
+// consecutive n -> 16-byte stores.  Operand tiles go HBM -> registers -> LDS transposed to k-major ([k][row]: lane l of an
+// MFMA reads element (k = 2 kk + (l >> 5), row = l & 31), i.e. 32 consecutive dwords per half wave), register-prefetched
+// one K-tile ahead, two LDS buffers, one barrier per K-tile.
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ X, long long lda, const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ out, long long ldc,
+                                                       int M, int N, int K, const float* __restrict__ aux, int aux_i) {
+    using namespace g32;
+    __shared__ float sX[2][TK * LD];
+    __shared__ float sW[2][TK * LD];
+    const int n_tiles = N / TN;
+    const int tm = blockIdx.x / n_tiles, tn = blockIdx.x - tm * n_tiles;       // n fastest: neighbours share their X rows
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = t >> 2, kq = t & 3;                                           // staging: rows r, r + 64; k quarter kq
+    const float* xp[2];
+    const float* wp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + r + 64 * i;
+        m = m < M ? m : M - 1;                                                  // ragged last row tile: rows clamped, not stored
+        xp[i] = X + (size_t)m * lda + 4 * kq;
+        wp[i] = W + (size_t)(n0 + r + 64 * i) * K + 4 * kq;
+    }
+    f32x4 xr[2], wr[2];
+    auto load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            xr[i] = *reinterpret_cast<const f32x4*>(xp[i] + kt * TK);
+            wr[i] = *reinterpret_cast<const f32x4*>(wp[i] + kt * TK);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sX[buf][(4 * kq + j) * LD + r + 64 * i] = xr[i][j];
+                sW[buf][(4 * kq + j) * LD + r + 64 * i] = wr[i][j];
+            }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nk = K / TK;
+    const int h = lane >> 5, c = lane & 31;
+    load(0);
+    store(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < TK / 2; ++kk) {
+            const float* ws = sW[buf] + (2 * kk + h) * LD + 64 * wn + c;
+            const float* xs = sX[buf] + (2 * kk + h) * LD + 64 * wm + c;
+            const float a0 = ws[0], a1 = ws[32], b0 = xs[0], b1 = xs[32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store(buf ^ 1);
+        __syncthreads();
+    }
+    // C/D map of the 32 x 32 forms: column (here: m) = lane & 31, row (here: n) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int m = m0 + 64 * wm + 32 * j + c;
+        if (m >= M) continue;
+        size_t orow = (size_t)m;
+        const float* pos = nullptr;
+        if constexpr (EPI == F32_EPI_PATCH) {                                    // token row (m / G) (G + 1) + 1 + m % G, + positional embedding
+            const int G = aux_i, b = m / G, pidx = m - b * G;
+            orow = (size_t)b * (G + 1) + 1 + pidx;
+            pos = aux + (size_t)(1 + pidx) * N;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + 64 * wn + 32 * i + 8 * g + 4 * h;
+                f32x4 v = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (bias) v = v + *reinterpret_cast<const f32x4*>(bias + n);
+                float* o = out + orow * ldc + n;
+                if constexpr (EPI == F32_EPI_QGELU) {                            // x * sigmoid(1.702 x), model.py:300-302
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-1.702f * v[e]));
+                }
+                if constexpr (EPI == F32_EPI_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if constexpr (EPI == F32_EPI_RESID) v = v + *reinterpret_cast<const f32x4*>(o);
+                if constexpr (EPI == F32_EPI_PATCH) v = v + *reinterpret_cast<const f32x4*>(pos + n);
+                *reinterpret_cast<f32x4*>(o) = v;
+            }
+    }
+}
+
+// One workgroup (8 waves) per (sample, head): K (row stride 65 floats: lane j reads row j conflict free) and V in LDS as
+// fp32; a wave owns query rows w, w + 8, ...: lane j holds the scores of keys j, j + 64, ... (q broadcast by v_readlane),
+// softmax statistics by wave reductions, then lane d accumulates output dimension d over the keys (probabilities broadcast
+// by v_readlane).  expf / division in full precision.  S <= 288.
+constexpr int A32_MAXB = 5;                        // key blocks of 64: S <= 320 in registers (LDS limits S to 288)
+__global__ __launch_bounds__(512) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S,
+                                                            int heads, int causal, int q_limit) {
+    extern __shared__ __attribute__((aligned(16))) float a32_lds[];
+    float* Ks = a32_lds;                           // [S][65]
+    float* Vs = a32_lds + (size_t)S * 65;          // [S][64]   (S * 65 * 4 bytes is a multiple of 4, rows read as scalars)
+    const int b = blockIdx.x / heads, hd = blockIdx.x - b * heads;
+    const int d = heads * 64, ld = 3 * d;
+    const float* base = qkv + (size_t)b * S * ld + hd * 64;
+    for (int idx = threadIdx.x; idx < S * 16; idx += 512) {
+        const int row = idx >> 4, c4 = idx & 15;
+        const f32x4 kv = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + d + 4 * c4);
+        const f32x4 vv = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + 2 * d + 4 * c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Ks[row * 65 + 4 * c4 + e] = kv[e];
+            Vs[row * 64 + 4 * c4 + e] = vv[e];
+        }
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nq = q_limit < S ? q_limit : S;
+    for (int q = wave; q < nq; q += 8) {
+        const float qv = base[(size_t)q * ld + lane] * 0.125f;                  // 1 / sqrt(64): exact scaling
+        const int nkeys = causal ? q + 1 : S;
+        float sc[A32_MAXB];
+#pragma unroll
+        for (int jb = 0; jb < A32_MAXB; ++jb) {
+            sc[jb] = -INFINITY;
+            if (jb * 64 < nkeys) {                                               // (wave-uniform)
+                const int j = jb * 64 + lane;
+                const float* kr = Ks + (size_t)(j < S ? j : S - 1) * 65;
+                float s = 0.f;
+#pragma unroll
+                for (int dd = 0; dd < 64; ++dd)
+                    s = fmaf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(qv), dd)), kr[dd], s);
+                if (j < nkeys) sc[jb] = s;
+            }
+        }
+        float mx = sc[0];
+#pragma unroll
+        for (int jb = 1; jb < A32_MAXB; ++jb) mx = fmaxf(mx, sc[jb]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < A32_MAXB; ++jb) {
+            sc[jb] = sc[jb] == -INFINITY ? 0.f : expf(sc[jb] - mx);
+            sum += sc[jb];
+        }
+        sum = wave_sum(sum);
+        float o = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < A32_MAXB; ++jb) {
+            if (jb * 64 < nkeys) {
+#pragma unroll
+                for (int jj = 0; jj < 64; ++jj) {
+                    const int j = jb * 64 + jj;
+                    if (j < nkeys)                                               // (wave-uniform)
+                        o = fmaf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(sc[jb]), jj)), Vs[(size_t)j * 64 + lane], o);
+                }
+            }
+        }
+        out[((size_t)b * S + q) * d + hd * 64 + lane] = o / sum;
+    }
+}
+
+// one block per output row (b, patch); columns c*P*P + ky*P + kx, zero padded to Kpad (elementwise.hip's im2col in fp32)
+__global__ __launch_bounds__(256) void im2col_f32_kernel(const float* __restrict__ img, float* __restrict__ out, int R, int P,
+                                                         int Kpad) {
+    const int g = R / P;
+    const int row = blockIdx.x;
+    const int b = row / (g * g), pi = row % (g * g);
+    const int py = pi / g, px = pi % g;
+    const int kreal = 3 * P * P;
+    const float* base = img + (size_t)b * 3 * R * R;
+    for (int k = threadIdx.x; k < Kpad; k += 256) {
+        float v = 0.f;
+        if (k < kreal) {
+            const int ch = k / (P * P), rem = k % (P * P);
+            const int ky = rem / P, kx = rem % P;
+            v = base[(size_t)ch * R * R + (size_t)(py * P + ky) * R + px * P + kx];
+        }
+        out[(size_t)row * Kpad + k] = v;
+    }
+}
+
+__global__ void l2norm_rows_f32_kernel(float* __restrict__ x, int rows, int dim) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float* p = x + (size_t)r * dim;
+    float s = 0.f;
+    for (int i = lane; i < dim; i += 64) s = fmaf(p[i], p[i], s);
+    s = wave_sum(s);
+    const float nrm = sqrtf(s);                   // x / x.norm(dim=-1, keepdim=True), eval_utils.py:162,704-710
+    for (int i = lane; i < dim; i += 64) p[i] = p[i] / nrm;
+}
+
+template <int EPI>
+int launch_gemm_f32(const float* A, long long lda, const float* W, const float* bias, float* out, long long ldc, int M, int N,
+                    int K, const float* aux, int aux_i, hipStream_t st) {
+    const int tiles = ((M + g32::TM - 1) / g32::TM) * (N / g32::TN);
+    KedsProfScope prof(KEDS_PROF_GEMM, st);
+    prof.work(2.0 * M * N * (double)K);
+    gemm_f32_kernel<EPI><<<tiles, 256, 0, st>>>(A, lda, W, bias, out, ldc, M, N, K, aux, aux_i);
+    return keds_check_launch("gemm_f32_kernel");
+}
+
+}  // namespace
+
+extern "C" int keds_gemm_f32(const float* A, int64_t lda, const float* W, const float* bias, float* out, int64_t ldc, int M,
+                             int N, int K, int epilogue, const float* aux, int aux_i, void* stream) {
+    KEDS_REQUIRE(A && W && out && M > 0, "keds_gemm_f32: bad argument");
+    KEDS_REQUIRE(N > 0 && N % 128 == 0 && K > 0 && K % 16 == 0, "keds_gemm_f32: N must be a multiple of 128 and K of 16 (got N=%d K=%d)", N, K);
+    KEDS_REQUIRE(lda >= K && lda % 4 == 0 && ldc % 4 == 0, "keds_gemm_f32: row strides must be multiples of 4 floats");
+    KEDS_REQUIRE(epilogue != F32_EPI_PATCH || (aux && aux_i > 0), "keds_gemm_f32: the patch epilogue needs the positional embedding and G");
+    hipStream_t st = (hipStream_t)stream;
+    switch (epilogue) {
+        case F32_EPI_BIAS: return launch_gemm_f32<F32_EPI_BIAS>(A, lda, W, bias, out, ldc, M, N, K, aux, aux_i, st);
+        case F32_EPI_QGELU: return launch_gemm_f32<F32_EPI_QGELU>(A, lda, W, bias, out, ldc, M, N, K, aux, aux_i, st);
+        case F32_EPI_RESID: return launch_gemm_f32<F32_EPI_RESID>(A, lda, W, bias, out, ldc, M, N, K, aux, aux_i, st);
+        case F32_EPI_RELU: return launch_gemm_f32<F32_EPI_RELU>(A, lda, W, bias, out, ldc, M, N, K, aux, aux_i, st);
+        case F32_EPI_PATCH: return launch_gemm_f32<F32_EPI_PATCH>(A, lda, W, bias, out, ldc, M, N, K, aux, aux_i, st);
+    }
+    keds_set_error("keds_gemm_f32: unknown epilogue %d", epilogue);
+    return KEDS_E_ARG;
+}
+
+extern "C" int keds_attention_f32(const float* qkv, float* out, int B, int S, int heads, int causal, int q_limit, void* stream) {
+    KEDS_REQUIRE(qkv && out && B > 0 && heads > 0, "keds_attention_f32: bad argument");
+    KEDS_REQUIRE(S >= 1 && S <= 288, "keds_attention_f32: S must be in [1, 288] (got %d)", S);
+    const int lds = S * (65 + 64) * (int)sizeof(float);
+    int rc = keds_func_lds_once((const void*)attention_f32_kernel, lds, "attention_f32_kernel");
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    KedsProfScope prof(KEDS_PROF_ATTN, st);
+    attention_f32_kernel<<<B * heads, 512, lds, st>>>(qkv, out, S, heads, causal, q_limit > 0 ? q_limit : S);
+    return keds_check_launch("attention_f32_kernel");
+}
+
+extern "C" int keds_im2col_f32(const float* image, float* out, int B, int R, int P, int Kpad, void* stream) {
+    KEDS_REQUIRE(image && out && B > 0 && P > 0 && R % P == 0, "keds_im2col_f32: bad argument");
+    KEDS_REQUIRE(Kpad >= 3 * P * P && Kpad % 16 == 0, "keds_im2col_f32: Kpad must cover 3*P*P and be a multiple of 16");
+    const int g = R / P;
+    KedsProfScope prof(KEDS_PROF_OTHER, (hipStream_t)stream);
+    im2col_f32_kernel<<<B * g * g, 256, 0, (hipStream_t)stream>>>(image, out, R, P, Kpad);
+    return keds_check_launch("im2col_f32_kernel");
+}
+
+// ---- whole towers ----------------------------------------------------------------------------------------------------
+// scratch of one fp32 tower: ln [M,w] | qkv [M,3w] | att [M,w] | hid [M,4w], all fp32 (1.2 GB at B = 128, ViT-L/14)
+size_t keds_tower_f32_workspace_bytes(int width, int seq, int B) {
+    const size_t M = keds_align_up((size_t)B * seq, 256);
+    return keds_align_up(M * width * 4, 256) + keds_align_up(M * (size_t)width * 3 * 4, 256) + keds_align_up(M * (size_t)width * 4, 256) +
+           keds_align_up(M * (size_t)width * 4 * 4, 256);
+}
+
+int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st) {
+    const int w = p->width, S = p->seq, M = B * S;
+    const size_t Mp = keds_align_up((size_t)M, 256);
+    char* base = (char*)ws;
+    float* ln = (float*)base;
+    float* qkv = (float*)(base + keds_align_up(Mp * w * 4, 256));
+    float* att = (float*)((char*)qkv + keds_align_up(Mp * (size_t)w * 3 * 4, 256));
+    float* hid = (float*)((char*)att + keds_align_up(Mp * (size_t)w * 4, 256));
+    int rc;
+    for (int l = 0; l < p->layers; ++l) {
+        const keds_block_params& k = p->blocks[l];
+        const bool last = l == p->layers - 1;
+        const float *qkv_w = (const float*)k.qkv_w, *out_w = (const float*)k.out_w, *fc_w = (const float*)k.fc_w,
+                    *proj_w = (const float*)k.proj_w;
+        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, ln, 1, M, w, st))) return rc;
+        if ((rc = keds_gemm_f32(ln, w, qkv_w, k.qkv_b, qkv, 3 * w, M, 3 * w, w, F32_EPI_BIAS, nullptr, 0, st))) return rc;
+        if (last && p->last_cls_only) {
+            // after the last block only token 0 of every sample is read (model.py:412): its attention query, out-proj, ln_2
+            // and MLP run on those B rows (row stride S*w in x / att)
+            const long long ldr = (long long)S * w;
+            if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, 1, st))) return rc;
+            if ((rc = keds_gemm_f32(att, ldr, out_w, k.out_b, x, ldr, B, w, w, F32_EPI_RESID, nullptr, 0, st))) return rc;
+            if ((rc = keds_layernorm_impl(x, w, nullptr, S, k.ln2_g, k.ln2_b, ln, 1, B, w, st))) return rc;
+            if ((rc = keds_gemm_f32(ln, w, fc_w, k.fc_b, hid, 4 * w, B, 4 * w, w, F32_EPI_QGELU, nullptr, 0, st))) return rc;
+            return keds_gemm_f32(hid, 4 * w, proj_w, k.proj_b, x, ldr, B, w, 4 * w, F32_EPI_RESID, nullptr, 0, st);
+        }
+        if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
+        if ((rc = keds_gemm_f32(att, w, out_w, k.out_b, x, w, M, w, w, F32_EPI_RESID, nullptr, 0, st))) return rc;
+        if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, ln, 1, M, w, st))) return rc;
+        if ((rc = keds_gemm_f32(ln, w, fc_w, k.fc_b, hid, 4 * w, M, 4 * w, w, F32_EPI_QGELU, nullptr, 0, st))) return rc;
+        if ((rc = keds_gemm_f32(hid, 4 * w, proj_w, k.proj_b, x, w, M, w, 4 * w, F32_EPI_RESID, nullptr, 0, st))) return rc;
+    }
+    return KEDS_OK;
+}
+
+// ln_post / ln_final on the read-out rows + projection (+ L2 normalisation), fp32 (model.py:412-414, 586-589, 841-849)
+size_t keds_readout_f32_workspace_bytes(int B, int d) { return keds_align_up((size_t)B, 128) * d * 4; }
+
+int keds_readout_f32(const float* x, int S, const int32_t* row, const float* gamma, const float* beta, const float* proj_t,
+                     float* out, int B, int d, int E, int normalize, void* workspace, hipStream_t st) {
+    int rc = keds_layernorm_impl(x, d, row, S, gamma, beta, workspace, 1, B, d, st);
+    if (rc) return rc;
+    if ((rc = keds_gemm_f32((const float*)workspace, d, proj_t, nullptr, out, E, B, E, d, F32_EPI_BIAS, nullptr, 0, st))) return rc;
+    if (normalize) {
+        l2norm_rows_f32_kernel<<<(B + 3) / 4, 256, 0, st>>>(out, B, E);
+        rc = keds_check_launch("l2norm_rows_f32_kernel");
+    }
+    return rc;
+}

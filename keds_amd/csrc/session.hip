@@ -178,7 +178,7 @@ struct Loader {
 
 // resblocks of one tower (model.py:305-326): keys <prefix>transformer.resblocks.<i>.*
 int load_blocks(const Loader& L, const std::string& prefix, int width, int layers, std::vector<keds_block_params>& blocks,
-                bool fp8) {
+                bool fp8, bool f32 = false) {
     blocks.assign(layers, keds_block_params{});
     for (int i = 0; i < layers; ++i) {
         const std::string b = prefix + "transformer.resblocks." + std::to_string(i) + ".";
@@ -191,6 +191,18 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
             (rc = L.vec(b + "attn.out_proj.bias", width, &p.out_b)) ||
             (rc = L.vec(b + "mlp.c_fc.bias", 4 * width, &p.fc_b)) || (rc = L.vec(b + "mlp.c_proj.bias", width, &p.proj_b)))
             return rc;
+        if (f32) {   // KEDS_F32 compute (the fp32-accurate flow, f32path.hip): the four weights stay fp32, nothing is folded
+            const float* f;
+            if ((rc = L.mat<float>(b + "attn.in_proj_weight", 3 * width, width, &f))) return rc;
+            p.qkv_w = f;
+            if ((rc = L.mat<float>(b + "attn.out_proj.weight", width, width, &f))) return rc;
+            p.out_w = f;
+            if ((rc = L.mat<float>(b + "mlp.c_fc.weight", 4 * width, width, &f))) return rc;
+            p.fc_w = f;
+            if ((rc = L.mat<float>(b + "mlp.c_proj.weight", width, 4 * width, &f))) return rc;
+            p.proj_w = f;
+            continue;
+        }
         if ((rc = L.mat<bf16_t>(b + "attn.in_proj_weight", 3 * width, width, &m))) return rc;
         p.qkv_w = m;
         if ((rc = L.mat<bf16_t>(b + "attn.out_proj.weight", width, width, &m))) return rc;
@@ -384,7 +396,8 @@ extern "C" int keds_ctx_destroy(keds_ctx* ctx) {
 extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_vit** out) {
     const char* what = "keds_vit_create";
     KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
-    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8, "%s: compute dtype must be KEDS_BF16 or KEDS_FP8", what);
+    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8 || compute == KEDS_F32,
+                 "%s: compute dtype must be KEDS_BF16, KEDS_FP8 or KEDS_F32", what);
     int rc = use_device(ctx, what);
     if (rc) return rc;
     Weights W(weights, n);
@@ -416,7 +429,8 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
         keds_set_error("%s: KEDS_FP8 needs a width that is a multiple of 256", what);
         return fail(KEDS_E_ARG);
     }
-    if ((rc = load_blocks(L, "visual.", width, layers, v->blocks, fp8))) return fail(rc);
+    const bool f32 = compute == KEDS_F32;
+    if ((rc = load_blocks(L, "visual.", width, layers, v->blocks, fp8, f32))) return fail(rc);
     keds_vit_params& p = v->p;
     memset(&p, 0, sizeof(p));
     p.tower.width = width;
@@ -427,23 +441,32 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
     p.tower.blocks = v->blocks.data();
     p.tower.last_cls_only = 1;
     p.tower.fp8 = fp8 ? 1 : 0;
+    p.tower.f32 = f32 ? 1 : 0;
     p.resolution = grid * patch;
     p.patch = patch;
     const int kreal = 3 * patch * patch;
     p.kpad = (kreal + 63) / 64 * 64;
     p.embed_dim = embed;
-    bf16_t* conv_w;   // [width, 3*P*P] zero padded to kpad columns (im2col order == the conv weight's own order)
-    if ((rc = pack_tensor<bf16_t>(v->mem, conv, width, kreal, kreal, 1, p.kpad, &conv_w, what))) return fail(rc);
-    p.conv_w = conv_w;
-    const bf16_t* proj_t;
+    if (f32) {
+        float* conv_w;
+        if ((rc = pack_tensor<float>(v->mem, conv, width, kreal, kreal, 1, p.kpad, &conv_w, what))) return fail(rc);
+        p.conv_w = conv_w;
+    } else {
+        bf16_t* conv_w;   // [width, 3*P*P] zero padded to kpad columns (im2col order == the conv weight's own order)
+        if ((rc = pack_tensor<bf16_t>(v->mem, conv, width, kreal, kreal, 1, p.kpad, &conv_w, what))) return fail(rc);
+        p.conv_w = conv_w;
+    }
+    const bf16_t* proj_t = nullptr;
+    const float* proj_t32 = nullptr;
     if ((rc = L.vec("visual.class_embedding", width, &p.class_emb)) ||
         (rc = L.mat<float>("visual.positional_embedding", p.tower.seq, width, &p.pos_emb)) ||
         (rc = L.vec("visual.ln_pre.weight", width, &p.ln_pre_g)) || (rc = L.vec("visual.ln_pre.bias", width, &p.ln_pre_b)) ||
         (rc = L.vec("visual.ln_post.weight", width, &p.ln_post_g)) ||
         (rc = L.vec("visual.ln_post.bias", width, &p.ln_post_b)) ||
-        (rc = L.mat<bf16_t>("visual.proj", embed, width, &proj_t, /*transpose=*/true)))
+        (rc = f32 ? L.mat<float>("visual.proj", embed, width, &proj_t32, /*transpose=*/true)
+                  : L.mat<bf16_t>("visual.proj", embed, width, &proj_t, /*transpose=*/true)))
         return fail(rc);
-    p.proj_t = proj_t;
+    p.proj_t = f32 ? (const void*)proj_t32 : (const void*)proj_t;
     *out = v;
     return KEDS_OK;
 }
@@ -490,7 +513,8 @@ extern "C" int keds_vit_forward(keds_vit* vit, const void* image, int img_dtype,
 extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_text** out) {
     const char* what = "keds_text_create";
     KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
-    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8, "%s: compute dtype must be KEDS_BF16 or KEDS_FP8", what);
+    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8 || compute == KEDS_F32,
+                 "%s: compute dtype must be KEDS_BF16, KEDS_FP8 or KEDS_F32", what);
     int rc = use_device(ctx, what);
     if (rc) return rc;
     Weights W(weights, n);
@@ -516,7 +540,8 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
         return fail(KEDS_E_ARG);
     }
     const bool fp8 = compute == KEDS_FP8 && width % 256 == 0;
-    if ((rc = load_blocks(L, "", width, layers, t->blocks, fp8))) return fail(rc);
+    const bool f32 = compute == KEDS_F32;
+    if ((rc = load_blocks(L, "", width, layers, t->blocks, fp8, f32))) return fail(rc);
     keds_text_params& p = t->p;
     memset(&p, 0, sizeof(p));
     p.tower.width = width;
@@ -527,15 +552,18 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
     p.tower.blocks = t->blocks.data();
     p.tower.last_cls_only = 0;
     p.tower.fp8 = fp8 ? 1 : 0;
+    p.tower.f32 = f32 ? 1 : 0;
     p.vocab = vocab;
     p.embed_dim = embed;
-    const bf16_t* proj_t;
+    const bf16_t* proj_t = nullptr;
+    const float* proj_t32 = nullptr;
     if ((rc = L.mat<float>("token_embedding.weight", vocab, width, &p.token_emb)) ||
         (rc = L.mat<float>("positional_embedding", context, width, &p.pos_emb)) ||
         (rc = L.vec("ln_final.weight", width, &p.ln_final_g)) || (rc = L.vec("ln_final.bias", width, &p.ln_final_b)) ||
-        (rc = L.mat<bf16_t>("text_projection", embed, width, &proj_t, /*transpose=*/true)))
+        (rc = f32 ? L.mat<float>("text_projection", embed, width, &proj_t32, /*transpose=*/true)
+                  : L.mat<bf16_t>("text_projection", embed, width, &proj_t, /*transpose=*/true)))
         return fail(rc);
-    p.proj_t = proj_t;
+    p.proj_t = f32 ? (const void*)proj_t32 : (const void*)proj_t;
     *out = t;
     return KEDS_OK;
 }

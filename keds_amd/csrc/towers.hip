@@ -14,6 +14,13 @@ int keds_cast_rows_f16_f32_impl(const void* x16, float* x32, int rows, int dim, 
 
 bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
 
+// f32path.hip: the fp32-accurate flow (keds_tower_params.f32)
+size_t keds_tower_f32_workspace_bytes(int width, int seq, int B);
+int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st);
+size_t keds_readout_f32_workspace_bytes(int B, int d);
+int keds_readout_f32(const float* x, int S, const int32_t* row, const float* gamma, const float* beta, const float* proj_t,
+                     float* out, int B, int d, int E, int normalize, void* workspace, hipStream_t st);
+
 namespace {
 
 size_t pad_rows(size_t m) { return keds_align_up(m, 256); }     // (256: a tower may run its ragged last row tile as a full one)
@@ -316,11 +323,17 @@ extern "C" int keds_tower_forward(const keds_tower_params* p, float* x, int B, v
     int rc = check_tower(p, "keds_tower_forward");
     if (rc) return rc;
     KEDS_REQUIRE(x && workspace && B > 0, "keds_tower_forward: bad argument");
-    if (workspace_bytes < keds_tower_workspace_bytes(p->width, p->seq, B)) {
+    if (workspace_bytes < keds_tower_workspace_bytes_ex(p, B)) {
         keds_set_error("keds_tower_forward: workspace too small");
         return KEDS_E_WORKSPACE;
     }
+    if (p->f32) return keds_tower_forward_f32(p, x, B, workspace, (hipStream_t)stream);
     return tower_forward(p, x, B, workspace, (hipStream_t)stream, false);
+}
+
+extern "C" size_t keds_tower_workspace_bytes_ex(const keds_tower_params* p, int B) {
+    if (!p || B <= 0) return 0;
+    return p->f32 ? keds_tower_f32_workspace_bytes(p->width, p->seq, B) : keds_tower_workspace_bytes(p->width, p->seq, B);
 }
 
 // ---- ViT -------------------------------------------------------------------------------------
@@ -337,10 +350,10 @@ VitWs carve_vit(const keds_vit_params* p, int B, void* ws) {
     const int w = p->tower.width, S = p->tower.seq;
     const size_t Mp = pad_rows((size_t)B * S);
     const size_t xb = keds_align_up(Mp * w * sizeof(float), 256);
-    size_t tb = keds_tower_workspace_bytes(w, S, B);
-    const size_t colb = keds_align_up(pad_rows((size_t)B * (S - 1)) * p->kpad * 2, 256);
+    size_t tb = keds_tower_workspace_bytes_ex(&p->tower, B);
+    const size_t colb = keds_align_up(pad_rows((size_t)B * (S - 1)) * p->kpad * (p->tower.f32 ? 4 : 2), 256);
     if (colb > tb) tb = colb;
-    const size_t rb = keds_align_up(keds_readout_workspace_bytes(B, w), 256);
+    const size_t rb = keds_align_up(p->tower.f32 ? keds_readout_f32_workspace_bytes(B, w) : keds_readout_workspace_bytes(B, w), 256);
     v.x = (float*)base;
     v.tower = base ? base + xb : nullptr;
     v.ro = base ? base + xb + tb : nullptr;
@@ -371,6 +384,18 @@ extern "C" int keds_vit_run(const keds_vit_params* p, const float* image, int B,
     }
     hipStream_t st = (hipStream_t)stream;
     void* col = v.tower;
+    if (p->tower.f32) {
+        // the fp32-accurate flow (f32path.hip): every weight pointer of the structs is an fp32 array
+        if ((rc = keds_im2col_f32(image, (float*)col, B, p->resolution, p->patch, p->kpad, stream))) return rc;
+        if ((rc = keds_gemm_f32((const float*)col, p->kpad, (const float*)p->conv_w, nullptr, v.x, w, B * G, w, p->kpad,
+                                4 /* patch rows + positional embedding */, p->pos_emb, G, stream)))
+            return rc;
+        if ((rc = keds_cls_rows_impl(v.x, p->class_emb, p->pos_emb, B, S, w, st))) return rc;
+        if ((rc = keds_layernorm_impl(v.x, w, nullptr, 1, p->ln_pre_g, p->ln_pre_b, v.x, 1, B * S, w, st))) return rc;
+        if ((rc = keds_tower_forward_f32(&p->tower, v.x, B, v.tower, st))) return rc;
+        return keds_readout_f32(v.x, S, nullptr, p->ln_post_g, p->ln_post_b, (const float*)p->proj_t, out, B, w, p->embed_dim,
+                                normalize, v.ro, st);
+    }
     if ((rc = keds_im2col(image, col, B, p->resolution, p->patch, p->kpad, stream))) return rc;
     if ((rc = keds_gemm_bt(col, p->conv_w, nullptr, v.x, B * G, w, p->kpad, KEDS_EPI_PATCH_F32, p->pos_emb, G, stream)))
         return rc;
@@ -396,8 +421,8 @@ TextWs carve_text(const keds_text_params* p, int B, void* ws) {
     const int w = p->tower.width, S = p->tower.seq;
     const size_t Mp = pad_rows((size_t)B * S);
     const size_t xb = keds_align_up(Mp * w * sizeof(float), 256);
-    const size_t tb = keds_tower_workspace_bytes(w, S, B);
-    const size_t rb = keds_align_up(keds_readout_workspace_bytes(B, w), 256);
+    const size_t tb = keds_tower_workspace_bytes_ex(&p->tower, B);
+    const size_t rb = keds_align_up(p->tower.f32 ? keds_readout_f32_workspace_bytes(B, w) : keds_readout_workspace_bytes(B, w), 256);
     v.x = (float*)base;
     v.tower = base ? base + xb : nullptr;
     v.ro = base ? base + xb + tb : nullptr;
@@ -426,6 +451,11 @@ extern "C" int keds_text_run(const keds_text_params* p, const int32_t* tokens, c
     const int w = p->tower.width, L = p->tower.seq;
     if ((rc = keds_embed_tokens(tokens, p->token_emb, p->pos_emb, img_tokens, n_tok, insert_col, v.x, B, L, w, stream)))
         return rc;
+    if (p->tower.f32) {
+        if ((rc = keds_tower_forward_f32(&p->tower, v.x, B, v.tower, (hipStream_t)stream))) return rc;
+        return keds_readout_f32(v.x, L, readout_row, p->ln_final_g, p->ln_final_b, (const float*)p->proj_t, out, B, w,
+                                p->embed_dim, normalize, v.ro, (hipStream_t)stream);
+    }
     if ((rc = tower_forward(&p->tower, v.x, B, v.tower, (hipStream_t)stream, true))) return rc;
     return keds_readout(v.x, L, readout_row, p->ln_final_g, p->ln_final_b, p->proj_t, out, B, w, p->embed_dim, normalize,
                         v.ro, keds_readout_workspace_bytes(B, w), stream);

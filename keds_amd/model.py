@@ -82,13 +82,15 @@ class VisualTransformer(nn.Module):
 
 
 def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: bool = False,
-                fp8: bool = False, folded: bool = True) -> _lib.TowerParams:
+                fp8: bool = False, folded: bool = True, f32: bool = False) -> _lib.TowerParams:
     blocks = (_lib.BlockParams * tr.layers)()
+    wcast = _f32 if f32 else _bf16        # f32: the fp32-accurate flow (csrc/f32path.hip) multiplies the weights as stored
+    folded = folded and not f32
     for i, blk in enumerate(tr.resblocks):
         t = dict(
             ln1_g=_f32(blk.ln_1.weight), ln1_b=_f32(blk.ln_1.bias), ln2_g=_f32(blk.ln_2.weight), ln2_b=_f32(blk.ln_2.bias),
-            qkv_w=_bf16(blk.attn.in_proj_weight), out_w=_bf16(blk.attn.out_proj.weight),
-            fc_w=_bf16(blk.mlp.c_fc.weight), proj_w=_bf16(blk.mlp.c_proj.weight),
+            qkv_w=wcast(blk.attn.in_proj_weight), out_w=wcast(blk.attn.out_proj.weight),
+            fc_w=wcast(blk.mlp.c_fc.weight), proj_w=wcast(blk.mlp.c_proj.weight),
             qkv_b=_f32(blk.attn.in_proj_bias), out_b=_f32(blk.attn.out_proj.bias),
             fc_b=_f32(blk.mlp.c_fc.bias), proj_b=_f32(blk.mlp.c_proj.bias))
         # ln_1 folded into in_proj, ln_2 into c_fc (keds_fold_layernorm): the tower then runs without LayerNorm passes.
@@ -130,7 +132,7 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
         keep.append(t)
     keep.append(blocks)
     return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks, 1 if fp8 else 0,
-                            1 if cls_only else 0)
+                            1 if cls_only else 0, 1 if f32 else 0)
 
 
 class _Packed:
@@ -144,25 +146,30 @@ class _Packed:
         P = v.patch_size
         kreal = 3 * P * P
         self.kpad = (kreal + 63) // 64 * 64
-        conv = torch.zeros((width, self.kpad), dtype=torch.bfloat16, device=v.conv1.weight.device)
-        conv[:, :kreal] = v.conv1.weight.detach().reshape(width, kreal).to(torch.bfloat16)
+        f32 = getattr(clip, "precision", "bf16") == "fp32"
+        wdt = torch.float32 if f32 else torch.bfloat16
+        wcast = _f32 if f32 else _bf16
+        self.f32 = f32
+        conv = torch.zeros((width, self.kpad), dtype=wdt, device=v.conv1.weight.device)
+        conv[:, :kreal] = v.conv1.weight.detach().reshape(width, kreal).to(wdt)
         g = v.input_resolution // P
         t = dict(conv_w=conv, class_emb=_f32(v.class_embedding), pos_emb=_f32(v.positional_embedding),
                  ln_pre_g=_f32(v.ln_pre.weight), ln_pre_b=_f32(v.ln_pre.bias), ln_post_g=_f32(v.ln_post.weight),
-                 ln_post_b=_f32(v.ln_post.bias), proj_t=_bf16(v.proj.detach().t()))
+                 ln_post_b=_f32(v.ln_post.bias), proj_t=wcast(v.proj.detach().t()))
         self.keep.append(t)
         fp8 = getattr(clip, "precision", "bf16") == "fp8"
-        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep, cls_only=True, fp8=fp8, folded=folded),
+        self.vit = _lib.VitParams(_pack_tower(v.transformer, g * g + 1, False, self.keep, cls_only=True, fp8=fp8, folded=folded,
+                                              f32=f32),
                                   v.input_resolution, P,
                                   self.kpad, v.output_dim, *[ptr(t[k]) for k in (
                                       "conv_w", "class_emb", "pos_emb", "ln_pre_g", "ln_pre_b", "ln_post_g",
                                       "ln_post_b", "proj_t")])
         tt = dict(token_emb=_f32(clip.token_embedding.weight), pos_emb=_f32(clip.positional_embedding),
                   ln_final_g=_f32(clip.ln_final.weight), ln_final_b=_f32(clip.ln_final.bias),
-                  proj_t=_bf16(clip.text_projection.detach().t()))
+                  proj_t=wcast(clip.text_projection.detach().t()))
         self.keep.append(tt)
         self.text = _lib.TextParams(_pack_tower(clip.transformer, clip.context_length, True, self.keep,
-                                                fp8=fp8 and clip.transformer.width % 256 == 0, folded=folded),
+                                                fp8=fp8 and clip.transformer.width % 256 == 0, folded=folded, f32=f32),
                                     clip.vocab_size, clip.embed_dim,
                                     *[ptr(tt[k]) for k in ("token_emb", "pos_emb", "ln_final_g", "ln_final_b", "proj_t")])
         self.device = conv.device
@@ -252,11 +259,14 @@ class CLIP(nn.Module):
         self._packed = None
 
     def set_precision(self, precision: str = "bf16"):
-        """"bf16" (default: bf16 GEMM operands) or "fp8" (BASELINE config 5: the image tower's GEMMs on MXFP8 operands --
-        OCP e4m3 with an e8m0 scale per 32 elements; needs vision width % 256 == 0; the text tower follows when its width is
-        a multiple of 256 too, e.g. 768)."""
-        if precision not in ("bf16", "fp8"):
-            raise ValueError("precision must be 'bf16' or 'fp8'")
+        """"bf16" (default: bf16 / fp16 GEMM operands, fp32 accumulate), "fp8" (BASELINE config 5: the image tower's GEMMs on
+        MXFP8 operands -- OCP e4m3 with an e8m0 scale per 32 elements; needs vision width % 256 == 0; the text tower follows
+        when its width is a multiple of 256 too, e.g. 768), or "fp32": the reference's own evaluation arithmetic
+        (eval_retrieval.py:108-109, `--precision` params.py:227-232) -- no operand is rounded, every product runs on the
+        f32-input matrix instruction, residual stream / LayerNorm / attention stay fp32 (csrc/f32path.hip).  About a tenth
+        of the default flow's throughput; embeddings agree with the fp32 reference to ~1e-6 and Recall@k is equal."""
+        if precision not in ("bf16", "fp8", "fp32"):
+            raise ValueError("precision must be 'bf16', 'fp8' or 'fp32'")
         if precision == "fp8" and (self.visual.transformer.width % 256 != 0 or self.numerics == "safe"):
             raise ValueError("fp8 needs a vision width that is a multiple of 256 and the folded LayerNorm path")
         self.precision = precision
@@ -334,7 +344,7 @@ class CLIP(nn.Module):
             return run(self._engine())
         self._guard_poll(wait=False)
         eng = self._engine()
-        if self.numerics != "auto" or not eng.folded or self.precision == "fp8":
+        if self.numerics != "auto" or not eng.folded or self.precision in ("fp8", "fp32"):
             return run(eng)
         if self._guard is None or self._guard.device != eng.device:
             self._guard = torch.zeros(1, dtype=torch.int32, device=eng.device)

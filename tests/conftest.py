@@ -10,8 +10,48 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+EXCHANGE2 = None        # the two-process device-exchange job of tests/test_gpu_exchange2.py: {"procs": [...], "dir": path}
+
+
+def _start_exchange2(config):
+    """Start the two ranks of tests/test_gpu_exchange2.py NOW: pytest_configure runs before any test module is imported, so
+    this process has made no GPU call yet (torch.cuda.device_count() does not initialise the device on this image) -- a
+    process that HAS initialised the GPU must not start other programs on this pool.  The children share cuda:0 and talk
+    over a gloo group on 127.0.0.1; the test only reads their verdicts."""
+    global EXCHANGE2
+    expr = getattr(config.option, "markexpr", "") or ""
+    if "not gpu" in expr or os.environ.get("KEDS_NO_EXCHANGE2") == "1":
+        return
+    args = [str(a) for a in config.args]
+    if any(a.endswith(".py") or "::" in a for a in args) and not any("test_gpu_exchange2" in a for a in args):
+        return                                                   # a run of other test files only
+    try:
+        import torch
+        if torch.cuda.device_count() < 1:
+            return
+    except Exception:                                            # noqa: BLE001
+        return
+    import socket
+    import subprocess
+    import tempfile
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d = tempfile.mkdtemp(prefix="keds_exchange2_")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "4"
+    procs = []
+    for r in range(2):
+        log = open(os.path.join(d, f"rank{r}.log"), "w")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exchange2_worker.py"), str(r), "2", str(port), d],
+                                      env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT))
+    EXCHANGE2 = {"procs": procs, "dir": d}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _start_exchange2(config)
 
 
 LIB_PROBLEM = None

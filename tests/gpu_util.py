@@ -10,9 +10,16 @@ from tests.conftest import ROOT
 LOG = os.path.join(ROOT, "gpurun_out", "gpu_test_metrics.jsonl")
 
 
+_DIGEST = None
+
+
 def report(name, **metrics):
+    global _DIGEST
     os.makedirs(os.path.dirname(LOG), exist_ok=True)
-    rec = {"test": name}
+    if _DIGEST is None:                      # the kernel sources these numbers were measured on (keds_amd._lib.source_digest)
+        from keds_amd import _lib
+        _DIGEST = _lib.source_digest()
+    rec = {"test": name, "csrc_sha16": _DIGEST}
     rec.update({k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in metrics.items()})
     with open(LOG, "a") as f:
         f.write(json.dumps(rec) + "\n")

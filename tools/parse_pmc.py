@@ -28,5 +28,9 @@ if big:
     for f in ("hbm_read_bytes_per_launch", "hbm_write_bytes_per_launch"):
         if all(f in e for e in big):
             res["gemm_256x256_all"][f] = sum(e[f] * e["launches"] for e in big) / n
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from keds_amd import _lib      # noqa: E402  (the digest of the kernel sources these passes ran on; bench.py checks it)
+res["csrc_sha16"] = _lib.source_digest()
 json.dump(res, open(sys.argv[2], "w"), indent=1, sort_keys=True)
 print(json.dumps(res, indent=1, sort_keys=True))
