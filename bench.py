@@ -38,6 +38,8 @@ PEAK_BF16_TFLOPS = 2500.0     # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0      # dense MX-fp8 MFMA (--precision fp8 only; the headline is bf16 / fp16)
 PEAK_FP8_MEASURED_TFLOPS = 3400.0    # register-only v_mfma_scale_f32_16x16x128_f8f6f4 loop (profiles/r01_microbench.txt)
 PEAK_BF16_MEASURED_TFLOPS = 2060.0   # tools/micro/mfma_peak.hip on the gpurun MI355X
+PEAK_F32_TFLOPS = 157.3       # f32-input MFMA (--precision fp32 only), MI355X_MICROARCH.md
+PEAK_F32_MEASURED_TFLOPS = 155.0     # MI355X_MICROARCH.md, Matrix cores table
 PEAK_HBM_MEASURED_GBPS = 7150.0      # tools/micro/hbm_stream.hip (read-only)
 PEAK_HBM_GBPS = 8000.0        # HBM3E spec, MI355X_MICROARCH.md
 
@@ -292,9 +294,10 @@ def main():
                     help="encode_search = BASELINE configs 1-3, the headline (ViT-L/14 encode + top-10); dual = config 4: the "
                          "dual-stream composed query (encode + 2 x top-16 with rows over two databases + 2 knowledge streams + "
                          "2 text-tower passes + normalise / mixture)")
-    ap.add_argument("--precision", choices=["bf16", "fp8"], default="bf16",
-                    help="fp8 = BASELINE config 5 (MXFP8 GEMM operands in the towers; use with --db-rows 2000000); the headline "
-                         "metric is bf16")
+    ap.add_argument("--precision", choices=["bf16", "fp8", "fp32"], default="bf16",
+                    help="fp8 = BASELINE config 5 (MXFP8 GEMM operands in the towers; use with --db-rows 2000000); fp32 = the "
+                         "reference's own evaluation arithmetic (no operand rounding, f32-input MFMA: the accuracy operating "
+                         "point, Recall@k equal to the reference); the headline metric is bf16")
     ap.add_argument("--search-overlap", choices=["auto", "on", "off"], default=os.environ.get("KEDS_BENCH_OVERLAP", "auto"),
                     help="N > 1, encode_search: run the search of batch i (its two collectives and short launches) on a second "
                          "stream beside the encoder pass of batch i+1 (on), behind it on the encoder's stream (off), or time "
@@ -334,8 +337,8 @@ def main():
     B, N, D = args.batch, args.db_rows, 768
     k = 16 if dual else args.k                                 # the knowledge path takes the 16 nearest rows of each database
     model = random_clip(dev)
-    if args.precision == "fp8":
-        model.set_precision("fp8")
+    if args.precision != "bf16":
+        model.set_precision(args.precision)
     index, local_index, lo, hi = build_database(keds_amd, shard_bounds, N, D, world, rank, dev, 2002, dual and use_dist)
     images = torch.randn(B, 3, 224, 224, generator=torch.Generator(device=dev).manual_seed(1001 + rank), device=dev)
     if dual:
@@ -476,8 +479,8 @@ def main():
     if rank == 0:
         steps = args.steps
         psteps = max(prof_steps, 1)                              # timed steps whose launches carried event pairs
-        fp8 = args.precision == "fp8"
-        side_rows = _lib.load().keds_tower_side_rows(VITL["vision_width"], 257, B, int(fp8))
+        fp8, f32 = args.precision == "fp8", args.precision == "fp32"
+        side_rows = 0 if f32 else _lib.load().keds_tower_side_rows(VITL["vision_width"], 257, B, int(fp8))
         if dual:
             # every GEMM launch of the step that carried an event pair (image tower, the 2B-row text-tower pass, IM2TEXT /
             # CrossFormer GEMMs, read-outs) with its own 2*M*N*K, counted by the library at launch (keds_prof_read_work);
@@ -491,8 +494,8 @@ def main():
                 tower_mac = 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL
                 gemm_flops -= 2.0 * tower_mac * B * psteps * side_rows / (B * 257.0)
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        peak_tf = PEAK_FP8_TFLOPS if fp8 else PEAK_BF16_TFLOPS              # dense MFMA peak of the operand type
-        peak_meas_tf = PEAK_FP8_MEASURED_TFLOPS if fp8 else PEAK_BF16_MEASURED_TFLOPS
+        peak_tf = PEAK_FP8_TFLOPS if fp8 else PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS   # dense MFMA peak of the operand type
+        peak_meas_tf = PEAK_FP8_MEASURED_TFLOPS if fp8 else PEAK_F32_MEASURED_TFLOPS if f32 else PEAK_BF16_MEASURED_TFLOPS
         # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B), charged with the time of
         # every scan launch the search issues
         n_search = psteps * world * (2 if dual else 1)            # query blocks of 128 searched by this rank (profiled steps)
@@ -517,7 +520,7 @@ def main():
             workload = ("ViT-L/14 encode_image (224x224 synthetic, random-init weights) + exact top-%d over a synthetic "
                         "unit-norm %.1fM x 768 database" % (k, N / 1e6))
             par = f"dp{world} encoders + {world}-way row-sharded scan"
-        gemm_traffic, gemm_traffic_note = (None, "PMC passes are of the bf16 encode_search workload only") if (fp8 or dual) \
+        gemm_traffic, gemm_traffic_note = (None, "PMC passes are of the bf16 encode_search workload only") if (fp8 or f32 or dual) \
             else pmc_traffic("gemm_256x256_all", B, N, world)
         scan_traffic, scan_traffic_note = (None, "n/a") if dual else pmc_traffic("scan_topk_kernel<768, 16", B, N, world)
         parity, parity_note = recall_parity()
@@ -528,11 +531,13 @@ def main():
             "n_gpus": world, "steps": steps, "warmup": args.warmup,
             "ms_per_step": elapsed / steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16/fp16 operands, fp32 accumulate" if not fp8 else "fp8 (MXFP8 e4m3 operands, fp32 accumulate; config 5)", "data": "synthetic",
+            "dtype": ("fp8 (MXFP8 e4m3 operands, fp32 accumulate; config 5)" if fp8 else
+                      "f32 (f32-input MFMA, no operand rounding: the accuracy operating point)" if f32 else
+                      "bf16/fp16 operands, fp32 accumulate"), "data": "synthetic",
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "db_rows": N, "dim": D, "k": k,
                        "db_shards": world, "parallelism": par},
-            "roofline": {"kernel": ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_quad_kernel / gemm_bt_quad3_kernel / gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane GEMM launches of the step incl. the few 128x128-tile ones)", "bound": "mfma",
+            "roofline": {"kernel": ("gemm_f32_kernel (128x128 tiles, v_mfma_f32_32x32x2_f32)" if f32 else ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_quad_kernel / gemm_bt_quad3_kernel / gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane GEMM launches of the step incl. the few 128x128-tile ones)"), "bound": "mfma",
                          "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
                          "traffic": gemm_traffic, "traffic_unit": "bytes/launch (PMC, mean over the 256x256 GEMM launches; committed "
                          "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; null when they are not of this build)",

@@ -535,6 +535,11 @@ int keds_gemm_f32(const float* A, int64_t lda, const float* W, const float* bias
 int keds_attention_f32(const float* qkv, float* out, int B, int S, int heads, int causal, int q_limit, void* stream);
 /* keds_im2col with an fp32 patch matrix [B*G, Kpad] (Kpad % 16 == 0) */
 int keds_im2col_f32(const float* image, float* out, int B, int R, int P, int Kpad, void* stream);
+/* keds_knowledge_run with EVERY weight pointer of the params an FP32 array (per-layer weights; `fused` unused): one stream
+ * of the knowledge injection, tokens_out fp32 [B,3,dim]; K <= 64 */
+size_t keds_knowledge_f32_workspace_bytes(const keds_knowledge_params* p, int B, int K);
+int keds_knowledge_run_f32(const keds_knowledge_params* p, const float* q, const float* nbr_img, const float* nbr_txt, int B,
+                           int K, float* tokens_out, void* workspace, size_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -193,6 +193,8 @@ SIGNATURES = {
     "keds_gemm_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "keds_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
     "keds_im2col_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "keds_knowledge_f32_workspace_bytes": (sz, [C.POINTER(KnowledgeParams), i32, i32]),
+    "keds_knowledge_run_f32": (i32, [C.POINTER(KnowledgeParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),
     "keds_tokenizer_create": (i32, [C.c_char_p, C.POINTER(vp)]),
     "keds_tokenizer_destroy": (None, [vp]),
     "keds_tokenizer_special": (i32, [vp, C.POINTER(i32), C.POINTER(i32)]),

@@ -343,3 +343,132 @@ int keds_readout_f32(const float* x, int S, const int32_t* row, const float* gam
     }
     return rc;
 }
+
+// ---- knowledge injection in fp32 (IM2TEXT + 2 x CrossFormer, model.py:37-123, eval_utils.py:661-672) ------------------
+namespace {
+// single-query cross-attention core (model.py:56-79) on projected fp32 rows: one wave per (sample, head), lane = dim of the
+// 64-wide head; Q [B, inner], Kp / Vp [B*K, inner] -> out [B, inner]; K <= 64
+__global__ __launch_bounds__(256) void cross_core_f32_kernel(const float* __restrict__ Q, const float* __restrict__ Kp,
+                                                             const float* __restrict__ Vp, float* __restrict__ out, int B, int K,
+                                                             int heads) {
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wid >= B * heads) return;
+    const int b = wid / heads, h = wid - b * heads, inner = heads * 64;
+    const float q = Q[(size_t)b * inner + h * 64 + lane] * 0.125f;           // dim_head ** -0.5, exact
+    // one pass with a running maximum (K <= 64 keys: the rescales are exact to rounding, results within 1e-7 of the two-pass form)
+    float mx = -INFINITY, sum = 0.f, o = 0.f;
+    for (int j = 0; j < K; ++j) {
+        const float sj = wave_sum(q * Kp[((size_t)b * K + j) * inner + h * 64 + lane]);
+        if (sj > mx) {                                                       // (wave-uniform)
+            const float sc = expf(mx - sj);                                  // 0 on the first key
+            sum *= sc;
+            o *= sc;
+            mx = sj;
+        }
+        const float e = expf(sj - mx);
+        sum += e;
+        o = fmaf(e, Vp[((size_t)b * K + j) * inner + h * 64 + lane], o);
+    }
+    out[(size_t)b * inner + h * 64 + lane] = o / sum;
+}
+
+struct KnowF32Ws {
+    float *x, *h1, *h2, *y, *qp, *kp, *vp, *core, *qt;
+    size_t bytes;
+};
+KnowF32Ws carve_know_f32(const keds_knowledge_params* p, int B, int K, void* ws) {
+    const size_t R = (size_t)B + 2 * (size_t)B * K;
+    const int inner = p->fuse.heads * 64;
+    KnowF32Ws w;
+    char* base = (char*)ws;
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        float* r = base ? (float*)(base + off) : nullptr;
+        off += keds_align_up(n * sizeof(float), 256);
+        return r;
+    };
+    w.x = take(R * p->i2t.dim_in);
+    w.h1 = take(R * p->i2t.middle);
+    w.h2 = take(R * p->i2t.middle);
+    w.y = take(R * p->i2t.dim_out);
+    w.qp = take((size_t)B * inner);
+    w.kp = take((size_t)B * K * inner);
+    w.vp = take((size_t)B * K * inner);
+    w.core = take((size_t)B * inner);
+    w.qt = take((size_t)B * p->fuse.dim);
+    w.bytes = off;
+    return w;
+}
+
+// q chained through the layers, k and v fixed (model.py:98-101); the last layer's output lands in `out` (row stride ldo)
+int crossformer_f32(const keds_crossformer_params* p, const float* q, long long ldq, const float* kv, int B, int K, float* out,
+                    long long ldo, const KnowF32Ws& w, hipStream_t st) {
+    const int dim = p->dim, inner = p->heads * 64;
+    int rc;
+    for (int l = 0; l < p->layers; ++l) {
+        const keds_cross_layer_params& c = p->layer[l];
+        const bool last = l == p->layers - 1;
+        if ((rc = keds_gemm_f32(q, ldq, (const float*)c.wq, c.bq, w.qp, inner, B, inner, dim, F32_EPI_BIAS, nullptr, 0, st))) return rc;
+        if ((rc = keds_gemm_f32(kv, dim, (const float*)c.wk, c.bk, w.kp, inner, B * K, inner, dim, F32_EPI_BIAS, nullptr, 0, st))) return rc;
+        if ((rc = keds_gemm_f32(kv, dim, (const float*)c.wv, c.bv, w.vp, inner, B * K, inner, dim, F32_EPI_BIAS, nullptr, 0, st))) return rc;
+        cross_core_f32_kernel<<<(B * p->heads + 3) / 4, 256, 0, st>>>(w.qp, w.kp, w.vp, w.core, B, K, p->heads);
+        if ((rc = keds_check_launch("cross_core_f32_kernel"))) return rc;
+        float* dst = last ? out : w.qt;
+        const long long ldd = last ? ldo : dim;
+        if ((rc = keds_gemm_f32(w.core, inner, (const float*)c.wo, c.bo, dst, ldd, B, dim, inner, F32_EPI_BIAS, nullptr, 0, st))) return rc;
+        q = w.qt;
+        ldq = dim;
+    }
+    return KEDS_OK;
+}
+}  // namespace
+
+extern "C" size_t keds_knowledge_f32_workspace_bytes(const keds_knowledge_params* p, int B, int K) {
+    if (!p || B <= 0 || K <= 0) return 0;
+    return carve_know_f32(p, B, K, nullptr).bytes;
+}
+
+// One stream of the knowledge injection with EVERY weight pointer of the params an fp32 array (unfused per-layer weights):
+// tokens_out [B,3,dim] = [fuse(m, I, I), cond(m, T, T), m] with m = img2text(q), I / T = img2text(neighbours)
+extern "C" int keds_knowledge_run_f32(const keds_knowledge_params* p, const float* q, const float* nbr_img, const float* nbr_txt,
+                                      int B, int K, float* tokens_out, void* workspace, size_t workspace_bytes, void* stream) {
+    KEDS_REQUIRE(p && q && nbr_img && nbr_txt && tokens_out && workspace && B > 0, "keds_knowledge_run_f32: bad argument");
+    KEDS_REQUIRE(K >= 1 && K <= 64, "keds_knowledge_run_f32: K must be in [1, 64]");
+    const keds_im2text_params& m = p->i2t;
+    const int dim = p->fuse.dim;
+    KEDS_REQUIRE(m.dim_in == dim && m.dim_out == dim && p->cond.dim == dim && p->cond.heads == p->fuse.heads && m.n_layer >= 1 &&
+                     m.n_layer <= 4 && p->fuse.layer && p->cond.layer,
+                 "keds_knowledge_run_f32: inconsistent module shapes");
+    KnowF32Ws w = carve_know_f32(p, B, K, workspace);
+    if (workspace_bytes < w.bytes) {
+        keds_set_error("keds_knowledge_run_f32: workspace %zu < %zu", workspace_bytes, w.bytes);
+        return KEDS_E_WORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const size_t BK = (size_t)B * K, R = B + 2 * BK;
+    if (hipMemcpyAsync(w.x, q, (size_t)B * dim * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(w.x + (size_t)B * dim, nbr_img, BK * dim * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+        hipMemcpyAsync(w.x + ((size_t)B + BK) * dim, nbr_txt, BK * dim * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        keds_set_error("keds_knowledge_run_f32: %s", hipGetErrorString(hipGetLastError()));
+        return KEDS_E_LAUNCH;
+    }
+    int rc;
+    const float* cur = w.x;
+    int kdim = m.dim_in;
+    for (int i = 0; i < m.n_layer; ++i) {                                   // (Linear, Dropout = identity, ReLU) x n_layer
+        float* dst = (i & 1) ? w.h2 : w.h1;
+        if ((rc = keds_gemm_f32(cur, kdim, (const float*)m.w[i], m.b[i], dst, m.middle, (int)R, m.middle, kdim, F32_EPI_RELU, nullptr, 0, st)))
+            return rc;
+        cur = dst;
+        kdim = m.middle;
+    }
+    // fc_out: the mapped query rows go straight to token slot 2 (row stride 3 dim), the neighbours to y
+    float* mapped = tokens_out + 2 * (size_t)dim;
+    if ((rc = keds_gemm_f32(cur, m.middle, (const float*)m.out_w, m.out_b, mapped, 3LL * dim, B, dim, m.middle, F32_EPI_BIAS, nullptr, 0, st)))
+        return rc;
+    if ((rc = keds_gemm_f32(cur + (size_t)B * m.middle, m.middle, (const float*)m.out_w, m.out_b, w.y, dim, (int)(2 * BK), dim, m.middle,
+                            F32_EPI_BIAS, nullptr, 0, st)))
+        return rc;
+    if ((rc = crossformer_f32(&p->fuse, mapped, 3LL * dim, w.y, B, K, tokens_out, 3LL * dim, w, st))) return rc;
+    return crossformer_f32(&p->cond, mapped, 3LL * dim, w.y + BK * dim, B, K, tokens_out + dim, 3LL * dim, w, st);
+}

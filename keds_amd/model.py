@@ -535,24 +535,28 @@ class IM2TEXT(nn.Module):
         self._packed = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
-    def params(self) -> _lib.Im2TextParams:
+    def params(self, f32: bool = False) -> _lib.Im2TextParams:
+        """f32: the weights as fp32 arrays (the fp32-accurate flow, keds_knowledge_run_f32); default bf16 GEMM operands."""
         _lib.require_gpu()
         if not self.fc_out.weight.is_cuda:
             raise RuntimeError("keds_amd.IM2TEXT: move the module to the GPU first; no CPU path exists")
         if self._packed is None:
+            self._packed = {}
+        if f32 not in self._packed:
             keep = []
+            wcast = _f32 if f32 else _bf16
             p = _lib.Im2TextParams()
             p.dim_in, p.middle, p.dim_out, p.n_layer = self.embed_dim, self.middle_dim, self.output_dim, self.n_layer
             for i, blk in enumerate(self.layers):
-                w, b = _bf16(blk[0].weight), _f32(blk[0].bias)
+                w, b = wcast(blk[0].weight), _f32(blk[0].bias)
                 keep += [w, b]
                 p.w[i], p.b[i] = ptr(w), ptr(b)
-            ow, ob = _bf16(self.fc_out.weight), _f32(self.fc_out.bias)
+            ow, ob = wcast(self.fc_out.weight), _f32(self.fc_out.bias)
             keep += [ow, ob]
             p.out_w, p.out_b = ptr(ow), ptr(ob)
-            self._packed = (p, keep)
+            self._packed[f32] = (p, keep)
         _lib.ensure_gemm_workspace(self.fc_out.weight.device)
-        return self._packed[0]
+        return self._packed[f32][0]
 
     def forward(self, x: torch.Tensor):
         if self.training:
@@ -595,21 +599,34 @@ class CrossFormer(nn.Module):
         self._num_layers, self.dim, self.heads = num_layers, q_dim, heads
         self.cross_layers = nn.ModuleList([CrossAttention(q_dim, k_dim, v_dim, heads, dim_head, dropout)
                                            for _ in range(num_layers)])
-        self._packed = None
+        self._packed = self._packed32 = None
         self._ws = _lib.Workspace()
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self._packed = self._packed32 = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
-        self._packed = None
+        self._packed = self._packed32 = None
         return super().load_state_dict(state_dict, strict=strict, **kw)
 
-    def params(self) -> _lib.CrossFormerParams:
+    def params(self, f32: bool = False) -> _lib.CrossFormerParams:
+        """f32: the per-layer weights as fp32 arrays, nothing fused (keds_knowledge_run_f32); default bf16 GEMM operands."""
         _lib.require_gpu()
         if not self.cross_layers[0].to_q.weight.is_cuda:
             raise RuntimeError("keds_amd.CrossFormer: move the module to the GPU first; no CPU path exists")
+        if f32:
+            if getattr(self, "_packed32", None) is None:
+                keep = []
+                arr = (_lib.CrossLayerParams * self._num_layers)()
+                for i, l in enumerate(self.cross_layers):
+                    t = dict(wq=_f32(l.to_q.weight), wk=_f32(l.to_k.weight), wv=_f32(l.to_v.weight), wo=_f32(l.to_out[0].weight),
+                             bq=_f32(l.to_q.bias), bk=_f32(l.to_k.bias), bv=_f32(l.to_v.bias), bo=_f32(l.to_out[0].bias))
+                    for k, v in t.items():
+                        setattr(arr[i], k, ptr(v))
+                    keep.append(t)
+                self._packed32 = (_lib.CrossFormerParams(self.dim, self.heads, self._num_layers, arr, None), keep, arr)
+            return self._packed32[0]
         if self._packed is None:
             keep = []
             arr = (_lib.CrossLayerParams * self._num_layers)()
@@ -665,13 +682,23 @@ class KnowledgeStream:
         self.img2text, self.retrieval_fuse, self.text_condition = img2text, retrieval_fuse, text_condition
         self._ws = _lib.Workspace()
 
-    def __call__(self, q: torch.Tensor, nbr_img: torch.Tensor, nbr_txt: torch.Tensor) -> torch.Tensor:
-        kp = _lib.KnowledgeParams(self.img2text.params(), self.retrieval_fuse.params(), self.text_condition.params())
+    def __call__(self, q: torch.Tensor, nbr_img: torch.Tensor, nbr_txt: torch.Tensor, precision: str = "bf16") -> torch.Tensor:
+        """precision "fp32": the fp32-accurate flow (no operand rounding, keds_knowledge_run_f32) -- what
+        compose_query_features passes when the CLIP model is on set_precision("fp32")."""
+        f32 = precision == "fp32"
+        kp = _lib.KnowledgeParams(self.img2text.params(f32), self.retrieval_fuse.params(f32), self.text_condition.params(f32))
         lib = load()
         B, K, dim = nbr_img.shape
         qf = q.to(dtype=torch.float32).contiguous()
         ni = nbr_img.to(dtype=torch.float32).contiguous()
         nt = nbr_txt.to(dtype=torch.float32).contiguous()
+        if f32:
+            nbytes = lib.keds_knowledge_f32_workspace_bytes(C.byref(kp), B, K)
+            ws = self._ws.get(nbytes, qf.device)
+            out = torch.empty((B, 3, dim), dtype=torch.float32, device=qf.device)
+            check(lib.keds_knowledge_run_f32(C.byref(kp), ptr(qf), ptr(ni), ptr(nt), B, K, ptr(out), ptr(ws), ws.numel(), stream()),
+                  "keds_knowledge_run_f32")
+            return out
         nbytes = lib.keds_knowledge_workspace_bytes(C.byref(kp), B, K)
         ws = self._ws.get(nbytes, qf.device)
         out = torch.empty((B, 3, dim), dtype=torch.float32, device=qf.device)

@@ -399,6 +399,8 @@ class KnowledgeTrainer:
                                       self.steps, gscale, stream()), "keds_adamw_step")
         for mod in (self.i2t, self.fuse, self.cond):                      # the inference packs are stale now
             mod._packed = None
+            if hasattr(mod, "_packed32"):
+                mod._packed32 = None
 
 
 def gather_own_first(x: torch.Tensor, group=None) -> torch.Tensor:

@@ -189,3 +189,55 @@ def test_session_handles_run_the_fp32_flow_with_kedsf32_compute():
         txt.close()
     finally:
         ctx.close()
+
+
+def _streams(dim, middle, seed):
+    a = keds_amd.IM2TEXT(dim, middle, dim, 2).eval()
+    b = keds_amd.CrossFormer(dim, dim, dim, num_layers=3).eval()
+    c = keds_amd.CrossFormer(dim, dim, dim, num_layers=3).eval()
+    a.load_state_dict(O.synth_im2text_state_dict(dim, middle, dim, 2, seed=seed, tag="i2t"))
+    b.load_state_dict(O.synth_crossformer_state_dict(dim, 3, seed=seed, tag="fuse"))
+    c.load_state_dict(O.synth_crossformer_state_dict(dim, 3, seed=seed, tag="cond"))
+    return keds_amd.KnowledgeStream(a.cuda(), b.cuda(), c.cuda())
+
+
+def test_cirr_batch_composition_tiny_in_fp32_mode():
+    """The per-batch body of evaluate_cirr (src/eval_utils.py:652-714) with NOTHING rounded: encoder, exact search, the two
+    knowledge streams (keds_knowledge_run_f32), the two text passes, normalise / mixture -- against the reference's outputs."""
+    gt = dict(np.load(golden_path("clip_tiny.npz")))
+    g = dict(np.load(golden_path("cirr_batch_tiny.npz")))
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    m = keds_amd.build_model(dict(sd), fp16=False).cuda().set_precision("fp32")
+    n_db = int(g["n_db"])
+    database = keds_amd.build_database(O.synth_database(n_db, 128, seed=2002), O.synth_database(n_db, 128, seed=2003),
+                                       [str(i) for i in range(n_db)])
+    out = keds_amd.compose_query_features(m, _streams(128, 128, 21), _streams(128, 128, 22), torch.from_numpy(gt["image"]).cuda(),
+                                          torch.from_numpy(gt["text"]).cuda(), database, id_split=265)
+    for key in ("tokens_image_stream", "tokens_text_stream", "composed", "image", "mixture"):
+        _close32(f"fp32.cirr.{key}", out[key], g[key])
+    ti, _ = keds_amd.get_retrieved_features(out["query_image_features"], database)
+    same = (np.sort(ti.cpu().numpy(), axis=1) == g["topk_image_sorted"]).all(axis=2).sum(axis=1)
+    assert int(same.min()) == 16                                  # every retrieved row is the reference's
+
+
+def test_dual_stream_composed_query_full_size_in_fp32_mode():
+    """BASELINE config 4 at full size (ViT-L/14, 8 queries, two 0.5 M x 768 databases, two stream checkpoints) in fp32 mode:
+    the composed features within 1e-5 of the reference's, the 16 neighbours of every query in both databases the reference's."""
+    g = dict(np.load(golden_path("dual_vitl14_full.npz")))
+    B, n_db, dim, middle = int(g["batch"]), int(g["n_db"]), 768, 512
+    sd = O.synth_clip_state_dict(**VITL, seed=7)
+    m = keds_amd.build_model({k: v for k, v in sd.items()}, fp16=False).cuda().set_precision("fp32")
+    del sd
+    database = keds_amd.build_database(O.synth_database(n_db, dim, seed=2002), O.synth_database(n_db, dim, seed=2003, clustered=True),
+                                       None, device="cuda")
+    img = torch.from_numpy(np.random.RandomState(1001).standard_normal((B, 3, 224, 224)).astype(np.float32)).cuda()
+    txt = O.synth_tokens(B, seed=4004).cuda()
+    out = keds_amd.compose_query_features(m, _streams(dim, middle, 21), _streams(dim, middle, 22), img, txt, database, id_split=265)
+    _close32("fp32.dual_full.query_image_features", out["query_image_features"], g["query_image_features"])
+    for name, index, Iref in (("image", database[3], g["I_image"]), ("text", database[4], g["I_text"])):
+        _, I, _ = index.search_gather(out["query_image_features"], 16, normalize=True)
+        same = sum(set(I[r].tolist()) == set(Iref[r, :16].tolist()) for r in range(B))
+        report(f"fp32.dual_full.neighbour_sets_identical.{name}", rows=int(same), of=B)
+        assert same == B
+    for key in [k for k in ("composed", "image", "mixture", "tokens_image_stream", "tokens_text_stream") if k in g]:
+        _close32(f"fp32.dual_full.{key}", out[key], g[key])
