@@ -380,28 +380,10 @@ __device__ __forceinline__ void quad_flush_pending(const u32x4* __restrict__ pen
 // offsets for the read-modify-write of the fp16 stream, bias slice from the LDS side area), all 16 loads of the lane issued
 // before the first is used.
 // REDUCE = false (4-wave kernel: a wave runs this once per 64-column half): leave the partial sums in `red`, the caller adds them
-// the lane's 16 residual chunks of wave column wn (64 columns x the wave's 128 rows), as plain loads.  The 4-wave kernels call
-// this AHEAD of the tile's last K-steps (half 0) and ahead of half 0's arithmetic (half 1): in the step the residual stream was
-// last touched ~470 MB of other traffic ago -- more than the memory-side cache holds -- and requested at the top of the epilogue
-// its HBM round trip stood exposed twice per tile (tools/gemm_cold_matrix.py: out-proj +10 us with a cold residual).
-__device__ __forceinline__ void pair_resid_request(f16x8 (&r)[2][8], const void* __restrict__ out, int m0, int n0, int N, int wm,
-                                                   int wn, int g, int c) {
-    const int r0 = 128 * wm + c;
-    const char* tile = reinterpret_cast<const char*>(out) + ((size_t)m0 * N + n0) * 2;   // wave-uniform
-    const int nl = 64 * wn + 8 * g;
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
-            r[p][mi] = *reinterpret_cast<const f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
-}
-
-// PRE: the residual chunks were requested by the caller (pair_resid_request) and come in through `r`
-template <int DBG = 0, bool REDUCE = true, bool PRE = false>   // DBG, stamped diagnostic build only: 3 = no stores, 4 = no statistics atomics, 5 = neither (and no loads)
+template <int DBG = 0, bool REDUCE = true>   // DBG, stamped diagnostic build only: 3 = no stores, 4 = no statistics atomics, 5 = neither (and no loads)
 __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const char* __restrict__ side, void* __restrict__ out,
                                                     int m0, int n0, int N, int wm, int wn, int g, int c,
-                                                    keds_stat_t* __restrict__ stats, char* __restrict__ red,
-                                                    f16x8 (*pre)[8] = nullptr) {
+                                                    keds_stat_t* __restrict__ stats, char* __restrict__ red) {
     // `red`: 8 KiB of LDS nobody reads any more (the operand buffer of the last but one K-tile): the four waves that share
     // a row (wn = 0..3) leave their {sum, sum sq} of it there, and after one barrier threads 0-255 add ONE statistics pair
     // per row of the tile -- a quarter of the 64-bit atomics (they cost 5-7 k of this epilogue's ~21 k cycles).
@@ -412,12 +394,9 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            if constexpr (PRE) r[p][mi] = pre[p][mi];
-            else
-                r[p][mi] = DBG == 5 ? f16x8{0, 0, 0, 0, 0, 0, 0, 0}
-                                    : *reinterpret_cast<const f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
-        }
+        for (int mi = 0; mi < 8; ++mi)
+            r[p][mi] = DBG == 5 ? f16x8{0, 0, 0, 0, 0, 0, 0, 0}
+                                : *reinterpret_cast<const f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
     f32x4 b[2][2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -1542,7 +1521,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
 // (Measured, round 3: rotating the K walk per row panel -- panel tm starts at K-tile (s * tm) mod np and wraps, the vendor
 // kernels' "StaggerU" -- is SLOWER here: 234 us at s = 5, 8, 17 against 218, 223 at s = 32, 219 at s = 1; the workgroups share
 // the W panel's K-slices in L2 because they walk K together.)
-template <int EPI, bool RPRE = false>     // RPRE: residual chunks requested ahead of the last K-steps (pair_resid_request)
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                                const float* __restrict__ bias, void* __restrict__ out,
                                                                int M, int N, int K, int n_tiles,
@@ -1645,12 +1624,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __r
         ia = ia1;
         iw = iw1;
     }
-    [[maybe_unused]] f16x8 rq0[2][8], rq1[2][8];
     {                                                                   // p = np-2: nothing left to request
         const int ia1 = ia == 2 ? 0 : ia + 1, iw1 = iw ^ 1;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        // the residual chunks of the first 64-column half: three K-steps (~3.4 k cycles) of cover for their round trip
-        if constexpr (RPRE) pair_resid_request(rq0, out, m0, n0, N, wm, 2 * wn2 + 0, g, c);
         const char* ab = smem + ia1 * OP_BYTES;
         wrow = WRING + (iw1 - ia1) * OP_BYTES + wrow0;
         KEDS_QUAD_STEP(false, xb, wb, xa, wa, ab, slot0, false, 0, 0, true)                       // K-step (np-2, 1)
@@ -1666,21 +1642,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __r
     KEDS_QUAD_DRAIN
     f32x4 av[4][8];
     keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
-    if constexpr (RPRE) {
-        pair_resid_request(rq1, out, m0, n0, N, wm, 2 * wn2 + 1, g, c);      // the second half: under the first half's arithmetic
-        __builtin_amdgcn_sched_barrier(0);
-        KEDS_QUAD_READ_HALF0(av)
-        pair_resid_epilogue<0, false, true>(av, side, out, m0, n0, N, wm, 2 * wn2 + 0, g, c, stats, red, rq0);
-        __builtin_amdgcn_sched_barrier(0);
-        KEDS_QUAD_READ_HALF1(av)
-        pair_resid_epilogue<0, false, true>(av, side, out, m0, n0, N, wm, 2 * wn2 + 1, g, c, stats, red, rq1);
-    } else {
-        KEDS_QUAD_READ_HALF0(av)
-        pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + 0, g, c, stats, red);
-        __builtin_amdgcn_sched_barrier(0);
-        KEDS_QUAD_READ_HALF1(av)
-        pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + 1, g, c, stats, red);
-    }
+    KEDS_QUAD_READ_HALF0(av)
+    pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + 0, g, c, stats, red);
+    __builtin_amdgcn_sched_barrier(0);
+    KEDS_QUAD_READ_HALF1(av)
+    pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + 1, g, c, stats, red);
     if (stats) {                                                        // kernel-uniform
         __syncthreads();
         const f32x2* rr = reinterpret_cast<const f32x2*>(red) + tid;
@@ -1784,9 +1750,6 @@ bool quad_by_shape(int N, int K) {
 // epilogue saves (the loads themselves were never the epilogue's cost: round-2 note above).  Off; bit 10 of
 // keds_gemm_force_small's argument turns it on for an A/B.
 int g_resid_prologue = 0;
-// 4-wave residual GEMM (three-deep A ring): the residual chunks requested ahead of the tile's last K-steps / ahead of the first
-// half's arithmetic instead of at the top of each half's epilogue (bit 18 of keds_gemm_force_small's argument: off, for the A/B)
-int g_resid_request = 1;
 int g_pair_stamp = 0;     // diagnostic: stamped build of the qkv instantiation (aux2 = stamp buffer)
 
 template <int EPI>
@@ -1855,12 +1818,6 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         }
         if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
             if (g_quad3 && K >= 1024 && K / pr::TK >= 4) {               // long K: A operand through a three-deep ring
-                if (g_resid_request) {
-                    if (int rc = keds_func_lds_once((const void*)gemm_bt_quad3_kernel<EPI, true>, 5 * pr::OP_BYTES, "gemm_bt_quad3_kernel")) return rc;
-                    gemm_bt_quad3_kernel<EPI, true><<<ntiles, 256, 5 * pr::OP_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N,
-                                                                                          K, n_tiles, aux, ntiles);
-                    return keds_check_launch("gemm_bt_quad3_kernel");
-                }
                 if (int rc = keds_func_lds_once((const void*)gemm_bt_quad3_kernel<EPI>, 5 * pr::OP_BYTES, "gemm_bt_quad3_kernel")) return rc;
                 gemm_bt_quad3_kernel<EPI><<<ntiles, 256, 5 * pr::OP_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
                                                                                 n_tiles, aux, ntiles);
@@ -1942,7 +1899,6 @@ extern "C" int keds_gemm_force_small(int on) {
     g_quad = (on >> 11) & 3;            // bits 11-12: 256^2 tiles on the 4-wave kernel (1), its persistent form (2), 3 = never
     if (g_quad == 0) g_quad = -1;       // (0 = the default: by shape)
     if (g_quad == 3) g_quad = 0;
-    g_resid_request = !((on >> 18) & 1);  // bit 18: residual chunks requested at the top of each half's epilogue (the round-3 form)
     g_resid_prologue = (on >> 10) & 1;  // bit 10: fp16-residual GEMMs take residual + bias as the accumulators' initial value (A/B)
     g_pair_stamp = (on >> 13) & 7;      // bits 13-15: stamped diagnostic build of the qkv / residual GEMMs (2: no statistics loads, 3: no stores, 4: no atomics, 5: no residual traffic at all)
     return KEDS_OK;

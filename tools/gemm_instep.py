@@ -12,6 +12,9 @@ these arrangements (interleaved rounds in ONE process, medians):
              other classes)
   chain-na   the same chain without the attention launch (what the attention kernel's 270 MB of traffic displaces)
   chain+w    the chain with 24 distinct weight sets (as in the tower: weights are read once per step, 25 MB per block)
+  alone:q3 / chain:q3      the two residual GEMMs (out, proj) on the 4-wave kernel with the three-deep A ring and the residual
+                           tile staged through LDS (round 4); chain:q3r3 = the same kernel with the round-3 epilogue (16
+                           residual loads per lane at the top of each half); chain:8w = both on the 8-wave kernel
 
 Prints per-kernel medians for every arrangement; the side-lane share comes from rocprofv3 runs of bench.py with
 KEDS_SIDE_STREAM=0/1 (tools/kstats.sh)."""
@@ -66,17 +69,23 @@ def main():
     def k_att(w):
         check(lib.keds_attention(ptr(qkv), ptr(att), B, S, H, 0, stream()), "attention")
 
+    resid_flag = {"v": 0}                   # keds_gemm_force_small argument for the two residual GEMMs (A/B of their kernel forms)
+
     def k_out(w):
+        lib.keds_gemm_force_small(resid_flag["v"])
         check(lib.keds_gemm_bt_ex2(ptr(att), W_, ptr(w["out"]), ptr(w["out_b"]), ptr(h), W_, M, W_, W_,
                                    _lib.EPI_RESID_STATS_F16, ptr(st2), 0, None, stream()), "out")
+        lib.keds_gemm_force_small(0)
 
     def k_fc(w):
         check(lib.keds_gemm_bt_ex2(ptr(h), W_, ptr(w["fc"]), ptr(w["fc_b"]), ptr(hid), 4 * W_, M, 4 * W_, W_,
                                    _lib.EPI_LN_QGELU_BF16_H, ptr(st2), 0, ptr(st1), stream()), "fc")
 
     def k_proj(w):
+        lib.keds_gemm_force_small(resid_flag["v"])
         check(lib.keds_gemm_bt_ex2(ptr(hid), 4 * W_, ptr(w["proj"]), ptr(w["proj_b"]), ptr(h), W_, M, W_, 4 * W_,
                                    _lib.EPI_RESID_STATS_F16, ptr(st1), 0, None, stream()), "proj")
+        lib.keds_gemm_force_small(0)
     kern = {"qkv": k_qkv, "att": k_att, "out": k_out, "fc": k_fc, "proj": k_proj}
     order = ("qkv", "att", "out", "fc", "proj")
 
@@ -108,8 +117,20 @@ def main():
         torch.cuda.synchronize()
         return {n: statistics.median(a.elapsed_time(b) * 1e3 for a, b in v[2:]) for n, v in ev.items() if v}
 
+    def with_flag(flag, fn):
+        def run():
+            resid_flag["v"] = flag
+            try:
+                return fn()
+            finally:
+                resid_flag["v"] = 0
+        return run
+    Q3, OLD = 1 << 11, (1 << 11) | (1 << 18)       # residual GEMMs: 4 waves + three-deep A ring, residual via LDS / round-3 epilogue
     arrangements = (("alone", run_alone), ("chain", lambda: run_chain(False, False)), ("chain-na", lambda: run_chain(True, False)),
-                    ("chain+w", lambda: run_chain(False, True)))
+                    ("chain+w", lambda: run_chain(False, True)),
+                    ("alone:q3", with_flag(Q3, run_alone)), ("chain:q3", with_flag(Q3, lambda: run_chain(False, True))),
+                    ("chain:q3r3", with_flag(OLD, lambda: run_chain(False, True))),
+                    ("chain:8w", with_flag(3 << 11, lambda: run_chain(False, True))))
     res = {a: {n: [] for n in order} for a, _ in arrangements}
     for a, fn in arrangements:          # warm-up of every arrangement
         fn()
