@@ -850,7 +850,7 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
                 for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
                     for (int pr2 = 0; pr2 < 2; ++pr2)
-                        *reinterpret_cast<u32x4*>(op + 32 * tile + 16 * pr2) = st[2 * tile + pr2];
+                        keds_store16<KEDS_ST_ATTN>(st[2 * tile + pr2], op + 32 * tile + 16 * pr2);
             }
             break;
         }

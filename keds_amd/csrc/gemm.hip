@@ -357,7 +357,7 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
                     continue;
                 }
             }
-            __builtin_nontemporal_store(ov, reinterpret_cast<bf16x8*>(tile_out + off));
+            keds_store16<KEDS_ST_LN>(ov, tile_out + off);
         }
     }
 }
@@ -372,7 +372,7 @@ __device__ __forceinline__ void quad_flush_pending(const u32x4* __restrict__ pen
         if (i < i0 || i >= i1) continue;
         const int s_ = 32 - ND + i, h = s_ >> 4, p = (s_ >> 3) & 1, mi = s_ & 7;
         const unsigned off = ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(64 * (2 * wn2 + h) + 32 * p + 8 * g)) * 2u;
-        __builtin_nontemporal_store(pend[i], reinterpret_cast<u32x4*>(tile_out + off));
+        keds_store16<KEDS_ST_LN>(pend[i], tile_out + off);
     }
 }
 
@@ -419,8 +419,8 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
                 if (v[0] + v[1] + v[2] + v[3] == 12345.678f) reinterpret_cast<float*>(out)[0] = v[0];
             } else {
                 const f16x8 ov = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
-                f16x8* dst = reinterpret_cast<f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
-                *dst = ov;      // (a non-temporal store here is neutral: the stream is re-read by the very next GEMM)
+                // (a non-temporal store here is neutral: the stream is re-read by the very next GEMM)
+                keds_store16<KEDS_ST_RESID>(ov, tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
             }
             sv = sv + (v0 + v1);
             qv = qv + (v0 * v0 + v1 * v1);
@@ -1737,10 +1737,19 @@ int quad_env() {
 // out-proj 66.3 / 67.7 / -- : the 4-wave kernel wins where the K-loop dominates the tile and its persistent form where the
 // LayerNorm epilogues (no loads of their own) leave registers for the tile loop; out-proj (K = 1024, a tile that is mostly
 // read-modify-write epilogue, which one wave per SIMD runs with nothing beside it) stays on the 8-wave kernel.
+// residual GEMMs go to the 4-wave kernel (three-deep A ring) from this K on (KEDS_RESID_QUAD_K in the environment: A/B)
+static int resid_quad_min_k() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_RESID_QUAD_K");
+        v = e && e[0] ? atoi(e) : 2048;
+    }
+    return v;
+}
 template <int EPI>
 bool quad_by_shape(int N, int K) {
     if constexpr (epi_is_ln(EPI)) return K >= 512;
-    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) return K >= 2048;
+    if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) return K >= resid_quad_min_k();
     return false;
 }
 // fp16-residual GEMMs: residual + bias as the accumulators' initial value instead of 16 loads per lane in the epilogue (round 3,

@@ -84,6 +84,49 @@ void keds_splitk_scratch(float** p, size_t* bytes);   // innermost scope of this
 // ---- numerics guard (host): device int32 flag of the calling thread's current composite call, or nullptr -----------
 int* keds_numerics_guard();
 
+// ---- output-tile stores (device) -----------------------------------------------------------------------------------
+// 16-byte store of an output tile that ANOTHER kernel reads next.  Policy per site class, compile-time (same-box A/B:
+// tools/ab_nt.sh rebuilds with -DKEDS_ST_<class>=<policy>):
+//   0 plain (write-back: the line stays dirty in the XCD's L2 until it is evicted or the kernel ends)
+//   1 nt    (streaming hint; still write-back)
+//   2 sc0 sc1 (write-through at system scope: the bytes leave L2 with the store and the line is dropped -- nothing is left for
+//     the end-of-kernel write-back, whose cost the NEXT kernel's start pays: MI355X_MICROARCH.md price list, row "boundary":
+//     + B / 6 TB/s for B bytes left dirty)
+//   3 sc1 nt     4 sc1     5 sc0 sc1 nt     6 sc0     7 sc0 nt      (the remaining combinations of the three cache-policy bits)
+#ifndef KEDS_ST_LN
+#define KEDS_ST_LN 3        /* LayerNorm-epilogue outputs of the GEMMs (qkv, MLP hidden): read once by the next kernel.  Round 4,
+                               same-box A/B (profiles/r04_store_policy_ab_*.txt): sc1 nt 7,355 img/s against 6,637 with nt alone
+                               (GEMM class 14.6 vs 16.9 ms per step) -- written back lazily, the 201 / 268 MB output streams of
+                               qkv / c_fc sat dirty in the 4 MiB L2 of every XCD and pushed the operand panels out */
+#endif
+#ifndef KEDS_ST_RESID
+#define KEDS_ST_RESID 0     /* the fp16 residual stream, read-modify-written in place */
+#endif
+#ifndef KEDS_ST_ATTN
+#define KEDS_ST_ATTN 0      /* attention output */
+#endif
+template <int POLICY, typename T>
+__device__ __forceinline__ void keds_store16(T v, void* p) {
+    static_assert(sizeof(T) == 16, "16-byte stores only");
+    if constexpr (POLICY == 1) {
+        __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+    } else if constexpr (POLICY == 2) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else if constexpr (POLICY == 3) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else if constexpr (POLICY == 4) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else if constexpr (POLICY == 5) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else if constexpr (POLICY == 6) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else if constexpr (POLICY == 7) {
+        asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else {
+        *reinterpret_cast<T*>(p) = v;
+    }
+}
+
 // ---- device helpers ----------------------------------------------------------------------
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) {
     return __uint_as_float(((unsigned int)b) << 16);

@@ -25,8 +25,7 @@ lib = _lib.load()
 M = 32768
 NBUF = 6
 ITERS, ROUNDS = int(os.environ.get("ITERS", "18")), int(os.environ.get("ROUNDS", "3"))
-FORMS = (("8 waves", 3 << 11), ("4 waves, 3-deep A, resid via LDS", 1 << 11), ("4 waves, 3-deep A (r3 epilogue)", (1 << 11) | (1 << 18)),
-         ("4 waves, 2-deep A", (1 << 11) | (1 << 16)), ("4 waves, persistent", 2 << 11))
+FORMS = (("8 waves", 3 << 11), ("4 waves, 3-deep A", 1 << 11), ("4 waves, 2-deep A", (1 << 11) | (1 << 16)), ("4 waves, persistent", 2 << 11))
 if os.environ.get("FORMS"):
     FORMS = tuple(f for f in FORMS if f[0] in os.environ["FORMS"].split(";"))
 
