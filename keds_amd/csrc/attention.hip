@@ -550,9 +550,9 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
             const int fk = (row >> 1) & 7, fv = ((row >> 1) & 1) << 2;
             const bf16_t* src = base + (size_t)row * ld;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + d + ((slot ^ fk) << 3)),
-                                             (__attribute__((address_space(3))) void*)(smem + K_OFF + piece * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + K_OFF + piece * 1024), 16, 0, KEDS_LD_ATTN_AUX);
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 2 * d + ((slot ^ fv) << 3)),
-                                             (__attribute__((address_space(3))) void*)(smem + V_OFF + piece * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + V_OFF + piece * 1024), 16, 0, KEDS_LD_ATTN_AUX);
         }
     }
     // tail image: [q row 256 | k row 256 | v row 256], 128 B each, unswizzled; the last-query arrival counter
@@ -845,12 +845,12 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
                 }
             }
             if (query < q_limit) {
-                bf16_t* op = obase + (size_t)query * d + 8 * hh;            // hh = 0: groups 0, 2; hh = 1: groups 1, 3
+                // (row `query`, element 8 hh: hh = 0 holds groups 0, 2; hh = 1 groups 1, 3)
 #pragma unroll
                 for (int tile = 0; tile < 2; ++tile)
 #pragma unroll
                     for (int pr2 = 0; pr2 < 2; ++pr2)
-                        keds_store16<KEDS_ST_ATTN>(st[2 * tile + pr2], op + 32 * tile + 16 * pr2);
+                        keds_store16<KEDS_ST_ATTN>(st[2 * tile + pr2], obase, (unsigned)(((size_t)query * d + 8 * hh + 32 * tile + 16 * pr2) * 2));
             }
             break;
         }

@@ -357,7 +357,7 @@ __device__ __forceinline__ void pair_ln_epilogue(f32x4 (&acc)[4][8], const char*
                     continue;
                 }
             }
-            keds_store16<KEDS_ST_LN>(ov, tile_out + off);
+            keds_store16<KEDS_ST_LN>(ov, tile_out, off);
         }
     }
 }
@@ -372,7 +372,7 @@ __device__ __forceinline__ void quad_flush_pending(const u32x4* __restrict__ pen
         if (i < i0 || i >= i1) continue;
         const int s_ = 32 - ND + i, h = s_ >> 4, p = (s_ >> 3) & 1, mi = s_ & 7;
         const unsigned off = ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(64 * (2 * wn2 + h) + 32 * p + 8 * g)) * 2u;
-        keds_store16<KEDS_ST_LN>(pend[i], tile_out + off);
+        keds_store16<KEDS_ST_LN>(pend[i], tile_out, off);
     }
 }
 
@@ -391,12 +391,21 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
     char* tile = reinterpret_cast<char*>(out) + ((size_t)m0 * N + n0) * 2;               // wave-uniform
     const int nl = 64 * wn + 8 * g;
     f16x8 r[2][8];
+#if KEDS_LD_RESID_AUX
+    const auto trs = __builtin_amdgcn_make_buffer_rsrc(tile, 0, 0x7FFFFFFF, 0x00020000);
+#endif
 #pragma unroll
     for (int p = 0; p < 2; ++p)
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi)
+        for (int mi = 0; mi < 8; ++mi) {
+#if KEDS_LD_RESID_AUX
+            r[p][mi] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(
+                           trs, (int)(((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u), 0, KEDS_LD_RESID_AUX));
+#else
             r[p][mi] = DBG == 5 ? f16x8{0, 0, 0, 0, 0, 0, 0, 0}
                                 : *reinterpret_cast<const f16x8*>(tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
+#endif
+        }
     f32x4 b[2][2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
@@ -420,7 +429,7 @@ __device__ __forceinline__ void pair_resid_epilogue(f32x4 (&acc)[4][8], const ch
             } else {
                 const f16x8 ov = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3], (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
                 // (a non-temporal store here is neutral: the stream is re-read by the very next GEMM)
-                keds_store16<KEDS_ST_RESID>(ov, tile + ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
+                keds_store16<KEDS_ST_RESID>(ov, tile, ((unsigned)(r0 + 16 * mi) * (unsigned)N + (unsigned)(nl + 32 * p)) * 2u);
             }
             sv = sv + (v0 + v1);
             qv = qv + (v0 * v0 + v1 * v1);
@@ -1209,10 +1218,11 @@ __device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_til
     const int m8 = m_tiles & ~7;
     if (m8 && (n_tiles & 3) == 0 && bid < m8 * n_tiles) {
         const int grp = bid >> 5, within = bid & 31;
-        const int grows = m8 >> 3;
+        constexpr int SM = 1 << KEDS_SUPER_M_LOG2, SN = 32 >> KEDS_SUPER_M_LOG2;     // 8 x 4 by default
+        const int grows = m8 / SM;
         const int gn = grp / grows, gm = grp - gn * grows;
-        tm = gm * 8 + (within & 7);
-        tn = gn * 4 + (within >> 3);
+        tm = gm * SM + (within & (SM - 1));
+        tn = gn * SN + (within >> KEDS_SUPER_M_LOG2);
     } else if (m8 && (n_tiles & 3) == 0) {
         const int r = bid - m8 * n_tiles;
         tm = m8 + r / n_tiles;
@@ -1549,7 +1559,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __r
     auto issue_a = [&](int kt, int buf, int i) {                       // A piece i (0..7) of K-tile kt into A buffer buf
         char* dst = smem + buf * OP_BYTES + (wave + 4 * i) * 1024;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff,
-                                                 i * rstride + (unsigned)kt * (TK * 2), 0, 0);
+                                                 i * rstride + (unsigned)kt * (TK * 2), 0, KEDS_LD_A3_AUX);
     };
     auto issue_w = [&](int kt, int buf, int i) {
         char* dst = smem + WRING + buf * OP_BYTES + (wave + 4 * i) * 1024;

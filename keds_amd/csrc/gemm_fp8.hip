@@ -403,9 +403,10 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
                            ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
             }
             if constexpr (EPI == 0 || EPI == 1) {
-                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + (size_t)m * N + n) =
-                    bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
-                           (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]};
+                keds_store16<KEDS_ST_FP8_BF16>(bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                                                       (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]},
+                                               reinterpret_cast<bf16_t*>(out) + (size_t)m0 * N + n0,
+                                               (unsigned)(((size_t)(m - m0) * N + (n - n0)) * 2));
             } else {                                              // MXFP8 copy: one 32-column block per (row, pp)
                 const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
                 float amax = 0.f;
@@ -425,8 +426,11 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
                     const auto s0 = __builtin_amdgcn_permlane16_swap(mxk[mi].x, pk.x, false, false);
                     const auto s1 = __builtin_amdgcn_permlane16_swap(mxk[mi].y, pk.y, false, false);
                     const int blk = g & 1, half = g >> 1;          // after the swap: this lane's block and 16-column half
-                    *reinterpret_cast<u32x4*>(qout + (size_t)m * N + (n0 + 64 * wn + 32 * blk + 16 * half)) =
-                        u32x4{s0[0], s1[0], s0[1], s1[1]};
+                    const unsigned qoff = (unsigned)((size_t)(m - m0) * N + (64 * wn + 32 * blk + 16 * half));
+                    if constexpr (EPI == 2)       // MLP hidden (MXFP8): read once by c_proj
+                        keds_store16<KEDS_ST_FP8_MX>(u32x4{s0[0], s1[0], s0[1], s1[1]}, qout + (size_t)m0 * N + n0, qoff);
+                    else                           // MXFP8 copy of the residual stream: the next GEMM's A operand
+                        keds_store16<KEDS_ST_FP8_MXR>(u32x4{s0[0], s1[0], s0[1], s1[1]}, qout + (size_t)m0 * N + n0, qoff);
                     if (g == 0)
                         *reinterpret_cast<unsigned short*>(qscale + mx_scale_index((n0 + 64 * wn) >> 5, m, q_pad)) =
                             (unsigned short)((mxe[mi] + 127) | ((e + 127) << 8));

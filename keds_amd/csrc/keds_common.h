@@ -94,10 +94,12 @@ int* keds_numerics_guard();
 //     + B / 6 TB/s for B bytes left dirty)
 //   3 sc1 nt     4 sc1     5 sc0 sc1 nt     6 sc0     7 sc0 nt      (the remaining combinations of the three cache-policy bits)
 #ifndef KEDS_ST_LN
-#define KEDS_ST_LN 3        /* LayerNorm-epilogue outputs of the GEMMs (qkv, MLP hidden): read once by the next kernel.  Round 4,
-                               same-box A/B (profiles/r04_store_policy_ab_*.txt): sc1 nt 7,355 img/s against 6,637 with nt alone
-                               (GEMM class 14.6 vs 16.9 ms per step) -- written back lazily, the 201 / 268 MB output streams of
-                               qkv / c_fc sat dirty in the 4 MiB L2 of every XCD and pushed the operand panels out */
+#define KEDS_ST_LN 3        /* LayerNorm-epilogue outputs of the GEMMs (qkv, MLP hidden): read once by the next kernel.  nt since
+                               round 2 (+0.55 ms of 21.7 against plain stores); round 4: sc1 nt as a buffer-store builtin, +0.4 %
+                               same-box (profiles/r04_store_policy_ab_3.txt).  WARNING kept for the next reader: as an inline-asm
+                               global_store_dwordx4 WITHOUT the s_nop 1 hazard pad the same policy "gained" 10 % -- the compiler
+                               overwrote the data registers before the store had read them, the garbage it wrote toggles fewer
+                               bits, and at the power cap fewer toggles are clock (profiles/r04_store_policy_ab_1/2.txt) */
 #endif
 #ifndef KEDS_ST_RESID
 #define KEDS_ST_RESID 0     /* the fp16 residual stream, read-modify-written in place */
@@ -105,25 +107,54 @@ int* keds_numerics_guard();
 #ifndef KEDS_ST_ATTN
 #define KEDS_ST_ATTN 0      /* attention output */
 #endif
+#ifndef KEDS_ST_FP8_BF16
+#define KEDS_ST_FP8_BF16 0  /* MXFP8 GEMM: bf16 output (qkv) */
+#endif
+#ifndef KEDS_ST_FP8_MX
+#define KEDS_ST_FP8_MX 0    /* MXFP8 GEMM: MXFP8 output (MLP hidden) */
+#endif
+#ifndef KEDS_ST_FP8_MXR
+#define KEDS_ST_FP8_MXR 0   /* MXFP8 GEMM: MXFP8 copy of the residual stream */
+#endif
+// cache-policy bits of the LDS-DMA / buffer-load builtins' `aux` operand on gfx950: 1 = sc0, 2 = nt, 16 = sc1
+#ifndef KEDS_LD_ATTN_AUX
+#define KEDS_LD_ATTN_AUX 0  /* attention: K / V rows of one (sample, head), read once by one workgroup */
+#endif
+#ifndef KEDS_LD_A3_AUX
+#define KEDS_LD_A3_AUX 0    /* A operand of the 4-wave residual GEMM's three-deep ring (attention output / MLP hidden: read by the
+                               four column tiles of one XCD group, then dead) */
+#endif
+#ifndef KEDS_LD_RESID_AUX
+#define KEDS_LD_RESID_AUX 0 /* the residual tile the fp16-residual epilogue reads, modifies and writes back */
+#endif
+#ifndef KEDS_SUPER_M_LOG2
+#define KEDS_SUPER_M_LOG2 3 /* 256 x 256 GEMM tile walk: an XCD's 32 concurrent tiles form a (1 << L) x (32 >> L) block of tiles */
+#endif
+// `base` is wave-uniform (the tile's first byte), `off` the lane's 32-bit byte offset inside it: policies other than 0 go out
+// as a buffer store whose `aux` operand carries the cache-policy bits -- a builtin, so the compiler counts the store and pads
+// its data-register hazard (an inline-asm global_store_dwordx4 gets neither: cdna_hip_programming.md section 5.7).
 template <int POLICY, typename T>
-__device__ __forceinline__ void keds_store16(T v, void* p) {
+__device__ __forceinline__ void keds_store16(T v, void* base, unsigned off) {
     static_assert(sizeof(T) == 16, "16-byte stores only");
-    if constexpr (POLICY == 1) {
-        __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
-    } else if constexpr (POLICY == 2) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
-    } else if constexpr (POLICY == 3) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
-    } else if constexpr (POLICY == 4) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
-    } else if constexpr (POLICY == 5) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
-    } else if constexpr (POLICY == 6) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
-    } else if constexpr (POLICY == 7) {
-        asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    if constexpr (POLICY == 0) {
+        *reinterpret_cast<T*>(reinterpret_cast<char*>(base) + off) = v;
+    } else if constexpr (POLICY >= 10 && POLICY < 20) {
+        // experiment: the store as an inline-asm statement the compiler cannot move (s_nop 1: the store-data hazard pad hipcc
+        // does not add for asm, cdna_hip_programming.md section 5.7); 10 plain, 11 nt, 12 sc0 sc1, 13 sc1 nt, 14 sc1
+        void* p = reinterpret_cast<char*>(base) + off;
+        if constexpr (POLICY == 10) asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+        else if constexpr (POLICY == 11) asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+        else if constexpr (POLICY == 12) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+        else if constexpr (POLICY == 13) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(__builtin_bit_cast(u32x4, v)) : "memory");
+    } else if constexpr (POLICY >= 20) {
+        // experiment: the builtin store of policy POLICY - 20, pinned in program order by a scheduling barrier
+        keds_store16<POLICY - 20>(v, base, off);
+        __builtin_amdgcn_sched_barrier(0);
     } else {
-        *reinterpret_cast<T*>(p) = v;
+        constexpr int aux = POLICY == 1 ? 2 : POLICY == 2 ? 17 : POLICY == 3 ? 18 : POLICY == 4 ? 16 : POLICY == 5 ? 19 : POLICY == 6 ? 1 : 3;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)off, 0, aux);
     }
 }
 

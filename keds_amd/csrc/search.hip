@@ -413,13 +413,41 @@ constexpr int MERGE_SLOTS = 4 * LISTK;    // pairs per segment at most (64)
 constexpr int MERGE_LDS_PAIRS = 4096;
 constexpr int MERGE_SPEC = 16;            // segment slots loaded before the segment's count is known
 
+// FUSED (round 4: the final merge of a search): the block that has merged a query's lists also re-ranks its `ncand` candidates
+// with the exact fp32 distance (its four waves take the candidates in turn, four rows in flight each) and runs the selection
+// + certificate on them -- what rerank_kernel and certify_select_kernel did as two more launches (6.4 + 10 us, each a grid
+// of short dependent round trips, + two kernel boundaries): one launch less to wait for, and the candidate ids / scores never
+// leave the CU.  Same arithmetic in the same order as the two kernels (they remain: the threshold pass's merge is unfused,
+// and KEDS_SEARCH_UNFUSED=1 / keds_scan_debug bit 10 selects the three-launch tail for an A/B).
+struct TailArgs {
+    const float* db;
+    const float* qn;
+    const f32x4* qstat;
+    const DbBounds* bounds;
+    float* D;
+    long long* I;
+    int* counters;
+    int* fail_ids;
+    int* fslot;
+    float* dk;
+    int* status;
+    long long id_base;
+    int dim, metric, k, force_fail;
+};
+
+template <bool FUSED>
 __global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsigned long long* __restrict__ pairs,
                                                                     const uint2* __restrict__ meta, int nwg, int slots,
                                                                     int* __restrict__ cand_idx, float* __restrict__ cand_val,
                                                                     float* __restrict__ thr_out, int ncand,
                                                                     const float* __restrict__ thr_in,
-                                                                    float* __restrict__ sbound_out) {
+                                                                    float* __restrict__ sbound_out, TailArgs ta) {
     __shared__ unsigned long long lp[MERGE_LDS_PAIRS];
+    [[maybe_unused]] __shared__ int s_cid[FUSED ? NCAND_WIDE : 1];
+    [[maybe_unused]] __shared__ float s_cd[FUSED ? NCAND_WIDE : 1];
+    [[maybe_unused]] __shared__ float s_sb;
+    [[maybe_unused]] __shared__ int s_nvalid;
+    [[maybe_unused]] __shared__ float s_dk;
     __shared__ unsigned s_red[4][MERGE_WAVES];
     __shared__ unsigned s_T, s_rem, s_out, s_eq;
     __shared__ __attribute__((aligned(16))) unsigned hist[256];
@@ -503,8 +531,11 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsign
         const int id = (int)(unsigned)(p2 & 0xFFFFFFFFu);
         if (V <= (unsigned)ncand || k > Tc) {
             const unsigned o = atomicAdd(&s_out, 1u);
-            cand_idx[q * ncand + o] = id;
-            cand_val[q * ncand + o] = key_float(k);
+            if constexpr (FUSED) s_cid[o] = id;
+            else {
+                cand_idx[q * ncand + o] = id;
+                cand_val[q * ncand + o] = key_float(k);
+            }
         } else if (k == Tc) {
             const unsigned o = atomicAdd(&s_eq, 1u);
             if (o < 256) {
@@ -606,23 +637,126 @@ __global__ __launch_bounds__(MERGE_THREADS) void merge_pairs_kernel(const unsign
             unsigned rank = 0;
             for (unsigned j = 0; j < neq; ++j) rank += eq_idx[j] < my ? 1u : 0u;
             if (rank < rem) {
-                cand_idx[q * ncand + base + rank] = my;
-                cand_val[q * ncand + base + rank] = eq_val[tid];
+                if constexpr (FUSED) s_cid[base + rank] = my;
+                else {
+                    cand_idx[q * ncand + base + rank] = my;
+                    cand_val[q * ncand + base + rank] = eq_val[tid];
+                }
             }
         }
     }
     for (int o = (int)want + tid; o < ncand; o += MERGE_THREADS) {       // fillers when fewer than ncand valid entries
-        cand_idx[q * ncand + o] = -1;
-        cand_val[q * ncand + o] = -INFINITY;
+        if constexpr (FUSED) s_cid[o] = -1;
+        else {
+            cand_idx[q * ncand + o] = -1;
+            cand_val[q * ncand + o] = -INFINITY;
+        }
     }
     KEDS_MSTAMP(6)
     if (mst && tid == 0) mst[(size_t)blockIdx.x * 8 + 7] = V;
     if (tid == 0) {
         if (thr_out) thr_out[q] = V > (unsigned)ncand ? key_float(T) : -INFINITY;
-        if (sbound_out) {
+        if (sbound_out || FUSED) {
             float b2 = V > (unsigned)ncand ? key_float(T) : (thr_in ? thr_in[q] : -INFINITY);
             if (lastkey) b2 = fmaxf(b2, key_float(lastkey));
-            sbound_out[q] = b2;
+            if (sbound_out) sbound_out[q] = b2;
+            if constexpr (FUSED) s_sb = b2;
+        }
+        if constexpr (FUSED) {
+            s_nvalid = 0;
+            s_dk = ta.metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+        }
+    }
+    if constexpr (FUSED) {
+        __syncthreads();
+        // ---- rerank_kernel's arithmetic: exact fp32 distance of every candidate, one wave each, four rows requested at a time
+        const int dim = ta.dim, metric = ta.metric;
+        const float* qq = ta.qn + (size_t)q * dim;
+        for (int c0 = 4 * wv; c0 < ncand; c0 += 4 * MERGE_WAVES) {
+            float acc[4];
+            int ids[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ids[u] = c0 + u < ncand ? s_cid[c0 + u] : -1;
+                acc[u] = 0.f;
+            }
+            for (int i = lane * 4; i < dim; i += 256) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(qq + i);
+                f32x4 b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    b[u] = ids[u] >= 0 ? *reinterpret_cast<const f32x4*>(ta.db + (size_t)ids[u] * dim + i) : a;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (metric == KEDS_METRIC_L2) {
+                        const f32x4 d = a - b[u];
+                        acc[u] += d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3];
+                    } else {
+                        acc[u] += a[0] * b[u][0] + a[1] * b[u][1] + a[2] * b[u][2] + a[3] * b[u][3];
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float sum = wave_sum(acc[u]);
+                if (lane == 0 && c0 + u < ncand)
+                    s_cd[c0 + u] = ids[u] >= 0 ? sum : (metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY);
+            }
+        }
+        __syncthreads();
+        // ---- certify_select_kernel's body on the block's own candidates (threads 0 .. ncand-1)
+        const int k = ta.k;
+        const int t = tid;
+        const bool act = t < ncand;
+        const float d = act ? s_cd[t] : 0.f;
+        const int id = act ? s_cid[t] : -1;
+        const f32x4 qs = ta.qstat[q];
+        const float xt = ta.bounds->xt, rm = ta.bounds->r;
+        const float key = metric == KEDS_METRIC_L2 ? d : -d;           // smaller is better
+        int rank = 0;
+        if (act) {
+            for (int j = 0; j < ncand; ++j) {
+                const float dj = s_cd[j];
+                const float kj = metric == KEDS_METRIC_L2 ? dj : -dj;
+                const int ij = s_cid[j];
+                const bool before = ij >= 0 && (id < 0 || kj < key || (kj == key && ij < id));
+                rank += (before && j != t) ? 1 : 0;
+            }
+            if (id >= 0) atomicAdd(&s_nvalid, 1);
+            if (id < 0) rank = ncand + t;                              // never selected before a valid one
+            if (rank < k) {
+                ta.D[(size_t)q * k + rank] = d;
+                ta.I[(size_t)q * k + rank] = id + ta.id_base;
+            }
+            if (id >= 0 && rank == k - 1) s_dk = d;
+        }
+        __syncthreads();
+        const int nvalid = s_nvalid;
+        if (t >= nvalid && t < k) {                                    // fewer than k valid candidates: fillers like faiss
+            ta.D[(size_t)q * k + t] = metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY;
+            ta.I[(size_t)q * k + t] = -1;
+        }
+        if (t == 0) {
+            const float sb = s_sb;
+            bool ok = sb == -INFINITY;                                 // nothing was ever left out of the candidate set
+            if (ta.force_fail) ok = false;
+            else if (!ok && nvalid >= k) {
+                const float tk = metric == KEDS_METRIC_L2 ? 0.5f * (qs[0] - s_dk) : s_dk;
+                const float eps = (qs[1] * xt + qs[2] * rm + qs[1] * rm + 2e-4f * qs[2] * xt) * 1.01f +
+                                  1e-6f * (fabsf(tk) + qs[0] + 1.0f);
+                ok = tk - eps > sb;
+            }
+            if (ok) {
+                ta.fslot[q] = -1;
+                if (ta.status) atomicAdd(ta.status + 0, 1);
+            } else {
+                const int f = atomicAdd(ta.counters, 1);
+                ta.fail_ids[f] = q;
+                ta.fslot[q] = f;
+                ta.counters[8 + f] = 0;                                // chunks of this query the exact pass has finished
+                ta.dk[q] = nvalid >= k ? s_dk : (metric == KEDS_METRIC_L2 ? INFINITY : -INFINITY);
+                if (ta.status) atomicAdd(ta.status + 1, 1);
+            }
         }
     }
 }
@@ -1038,6 +1172,15 @@ int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresho
 int g_force_exact = 0;  // test hook: 1 sends every query through the exact fallback
 int g_scan_nt = 1;      // non-temporal LDS-DMA for the D = 768 candidate pass (A/B hook: keds_scan_debug bit 6 turns it off)
 int g_thr_depth = 0;    // threshold-pass list depth: 0 = by launch shape, 1 / 4 forced (A/B hook: keds_scan_debug bits 7-9)
+int g_tail_unfused = 0; // keds_scan_debug bit 10: merge / rerank / certify as three launches (the round-3 tail; A/B, tests)
+bool search_tail_fused() {
+    static int env = -1;
+    if (env < 0) {
+        const char* e = getenv("KEDS_SEARCH_UNFUSED");
+        env = e && e[0] == '1';
+    }
+    return !env && !g_tail_unfused;
+}
 
 template <int D, int L>
 int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr,
@@ -1116,6 +1259,7 @@ extern "C" int keds_scan_debug(int variant) {
     g_scan_nt = (variant >> 6) & 1 ? 0 : 1;   // bit 6: default-policy key stream instead of non-temporal (A/B)
     g_thr_depth = (variant >> 7) & 7;         // bits 7-9: threshold-pass list depth 1 or 4 forced (0: by launch shape)
     if (g_thr_depth != 1 && g_thr_depth != 4) g_thr_depth = 0;
+    g_tail_unfused = (variant >> 10) & 1;     // bit 10: merge / rerank / certify as three launches (A/B, tests)
     return KEDS_OK;
 }
 
@@ -1248,8 +1392,8 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
             // inserts are rare for ANY data.
             if ((rc = scan_thr())) return rc;
             KedsProfScope prof(KEDS_PROF_OTHER, st);
-            merge_pairs_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgA, 4 * depthA, w.aidx, w.aval, w.thr, ncand, nullptr,
-                                                             nullptr);
+            merge_pairs_kernel<false><<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgA, 4 * depthA, w.aidx, w.aval, w.thr, ncand,
+                                                                    nullptr, nullptr, TailArgs{});
             if ((rc = keds_check_launch("merge_pairs_kernel(thr)"))) return rc;
         }
         if ((rc = scan_all(two_phase ? w.thr : nullptr))) return rc;
@@ -1257,15 +1401,23 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
             KedsProfScope prof(KEDS_PROF_OTHER, st);
             float* Dq = D + (size_t)q0 * k;
             long long* Iq = (long long*)I + (size_t)q0 * k;
-            merge_pairs_kernel<<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgB, 4 * LISTK, w.cidx, w.cval, nullptr, ncand,
-                                                             two_phase ? w.thr : nullptr, w.sbound);
-            if ((rc = keds_check_launch("merge_pairs_kernel"))) return rc;
-            rerank_kernel<<<(nb * ncand + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * ncand, ncand);
-            if ((rc = keds_check_launch("rerank_kernel"))) return rc;
-            certify_select_kernel<<<nb, ncand, 0, st>>>(w.cidx, w.cdist, ncand, metric, k, (long long)id_base, Dq, Iq, w.qstat,
-                                                        w.sbound, bounds, w.counters, w.fail_ids, w.fslot, w.dk, status,
-                                                        g_force_exact);
-            if ((rc = keds_check_launch("certify_select_kernel"))) return rc;
+            if (search_tail_fused()) {       // merge + exact re-rank + selection + certificate: one launch
+                const TailArgs ta{db, qn, w.qstat, bounds, Dq, Iq, w.counters, w.fail_ids, w.fslot, w.dk, status, (long long)id_base,
+                                  dim, metric, k, g_force_exact};
+                merge_pairs_kernel<true><<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgB, 4 * LISTK, w.cidx, w.cval, nullptr, ncand,
+                                                                       two_phase ? w.thr : nullptr, w.sbound, ta);
+                if ((rc = keds_check_launch("merge_pairs_kernel<fused>"))) return rc;
+            } else {
+                merge_pairs_kernel<false><<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgB, 4 * LISTK, w.cidx, w.cval, nullptr, ncand,
+                                                                        two_phase ? w.thr : nullptr, w.sbound, TailArgs{});
+                if ((rc = keds_check_launch("merge_pairs_kernel"))) return rc;
+                rerank_kernel<<<(nb * ncand + 3) / 4, 256, 0, st>>>(db, dim, metric, qn, w.cidx, w.cdist, nb * ncand, ncand);
+                if ((rc = keds_check_launch("rerank_kernel"))) return rc;
+                certify_select_kernel<<<nb, ncand, 0, st>>>(w.cidx, w.cdist, ncand, metric, k, (long long)id_base, Dq, Iq, w.qstat,
+                                                            w.sbound, bounds, w.counters, w.fail_ids, w.fslot, w.dk, status,
+                                                            g_force_exact);
+                if ((rc = keds_check_launch("certify_select_kernel"))) return rc;
+            }
             // exact fallback for the queries whose certificate failed (both kernels return at once when none did)
             const size_t lds = (size_t)dim * 4 + (size_t)w.chunk_rows * 8;
             if ((rc = keds_func_lds_once((const void*)exact_chunk_kernel, (int)lds, "exact_chunk_kernel"))) return rc;

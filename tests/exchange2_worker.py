@@ -47,7 +47,9 @@ def main():
     try:
         import torch
         import torch.distributed as dist
-        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        import datetime
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=240))      # a peer that died must not hang the suite
         host_staged_transport(dist)
         import keds_amd
         from keds_amd import _lib

@@ -20,7 +20,7 @@ def test_device_exchange_between_two_processes_equals_single_index():
         pytest.skip("the two-process job was not started (no GPU visible at pytest_configure, or -m excludes gpu)")
     for p in job["procs"]:
         try:
-            p.wait(timeout=900)
+            p.wait(timeout=420)
         except Exception:                                               # noqa: BLE001
             p.kill()
             raise

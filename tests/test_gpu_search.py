@@ -174,6 +174,37 @@ def test_two_phase_thresholds_equal_single_phase():
         assert torch.equal(I2.cpu(), Io), name
 
 
+@pytest.mark.parametrize("metric,dim,k", [("l2", 768, 10), ("l2", 768, 16), ("ip", 256, 101), ("l2", 128, 40)])
+def test_fused_search_tail_equals_the_three_launch_tail(metric, dim, k):
+    """Round 4: the final merge of a search also re-ranks its candidates and runs selection + certificate in the same launch
+    (merge_pairs_kernel<true>).  Same arithmetic as merge -> rerank_kernel -> certify_select_kernel (keds_scan_debug bit 10):
+    distances, ids and the certificate verdicts must be identical -- on iid data, on clustered data with ties at the cut, and
+    with fewer valid candidates than k."""
+    lib = _lib.load()
+    n = 70000
+    db = O.synth_database(n, dim, seed=51, clustered=True, n_centroids=32)
+    db[100:140] = db[100]                                        # 40 identical rows: ties in the scan score and the distance
+    q = torch.cat([O.synth_database(70, dim, seed=52), db[100:103] + 1e-4])
+    for rows in (n, 37):                                         # 37 rows: fewer candidates than k = 40 / 101
+        idx = keds_amd.FlatIndex(dim, metric)
+        idx.add(db[:rows])
+        idx.certificate_counts(reset=True)
+        D2, I2, _ = idx.search_device(q.cuda(), k)
+        c2 = idx.certificate_counts(reset=True)
+        lib.keds_scan_debug(1 << 10)
+        try:
+            D1, I1, _ = idx.search_device(q.cuda(), k)
+            c1 = idx.certificate_counts(reset=True)
+        finally:
+            lib.keds_scan_debug(0)
+        assert torch.equal(I1, I2) and torch.equal(D1, D2) and c1 == c2, (rows, c1, c2)
+    Do, Io = (O.flat_l2_search if metric == "l2" else O.flat_ip_search)(db, q, k)
+    idx = keds_amd.FlatIndex(dim, metric)
+    idx.add(db)
+    D, I, _ = idx.search_device(q.cuda(), k)
+    assert max_abs(D, Do) <= 2e-6
+
+
 def test_full_size_half_million_properties():
     """BASELINE size: 0.5 M x 768.  Self-retrieval, sortedness, top-10 prefix of top-16, oracle on a subset."""
     n, dim = 500000, 768
