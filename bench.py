@@ -316,6 +316,12 @@ def main():
         raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # KEDS_BENCH_SHARED_GPU=1 (diagnostic, never a measurement of scaling): all ranks of `--gpus N` share cuda:0 and talk over
+    # gloo with host-staged collectives (keds_amd.index.install_host_staged_transport) -- the whole N > 1 flow of this file
+    # (packed exchange, overlap pilot, per-rank report) on a box with one GPU
+    shared_gpu = os.environ.get("KEDS_BENCH_SHARED_GPU") == "1"
+    if shared_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -326,7 +332,12 @@ def main():
             for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("MASTER_ADDR", "127.0.0.1"),
                              ("MASTER_PORT", str(29500 + os.getpid() % 2000))):
                 os.environ.setdefault(key, val)
-        dist.init_process_group("nccl", device_id=dev)         # "nccl" is RCCL on ROCm
+        if shared_gpu:
+            dist.init_process_group("gloo")
+            from keds_amd.index import install_host_staged_transport
+            install_host_staged_transport(dist)
+        else:
+            dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
     import keds_amd
     from keds_amd import _lib
@@ -409,13 +420,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    red_dev = torch.device("cpu") if shared_gpu else dev       # (gloo reduces host tensors)
+
     def timed_run(n):
         fence()
         t0 = time.perf_counter()
         for _ in range(n):
             step()
         fence()
-        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        t = torch.tensor([time.perf_counter() - t0], device=red_dev, dtype=torch.float64)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()) / n * 1e3
@@ -456,7 +469,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     guard_tripped = bool(model.numerics_sync())                 # the lazily checked numerics guard of the timed passes
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed], device=red_dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -534,6 +547,8 @@ def main():
             "dtype": ("fp8 (MXFP8 e4m3 operands, fp32 accumulate; config 5)" if fp8 else
                       "f32 (f32-input MFMA, no operand rounding: the accuracy operating point)" if f32 else
                       "bf16/fp16 operands, fp32 accumulate"), "data": "synthetic",
+            **({"diagnostic": "KEDS_BENCH_SHARED_GPU=1: all ranks share ONE GPU over a host-staged gloo transport -- a test of the "
+                              "N > 1 flow, not a scaling measurement"} if shared_gpu else {}),
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "db_rows": N, "dim": D, "k": k,
                        "db_shards": world, "parallelism": par},

@@ -456,7 +456,8 @@ constexpr int K_OFF = 0, V_OFF = 32768, TAIL_OFF = 65536;    // tail: row 256's 
 constexpr int SC_OFF = TAIL_OFF + 384;                        // last query: f32 scores [264]
 constexpr int PART_OFF = SC_OFF + 264 * 4;                    // last query: per wave {max, sum, -, ..., partial output [64]}: 72 floats
 constexpr int CNT_OFF = PART_OFF + 8 * 72 * 4;                // last query: arrival counter
-constexpr int LDS = CNT_OFF + 16;                             // 69,296 B -> two workgroups per CU
+constexpr int DUMP_OFF = CNT_OFF + 16;                        // 256 B nobody reads: target of the L2 prefetch (KEDS_ATTN_PREFETCH)
+constexpr int LDS = DUMP_OFF + 256;                           // 69,552 B -> two workgroups per CU
 }  // namespace s257
 
 __device__ __forceinline__ float halves_max(float x) {
@@ -705,6 +706,28 @@ __global__ __launch_bounds__(512, 4) void attention_s257_kernel(const bf16_t* __
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // a recomputing wave does not come here again)
                     __syncthreads();
                     if constexpr (DBG == 8) t_lastq = __builtin_amdgcn_s_memtime();
+#if KEDS_ATTN_PREFETCH
+                    {
+                        // L2 prefetch for the workgroup that follows this one on the XCD (block id + KEDS_ATTN_PREFETCH: a multiple
+                        // of 8 keeps the XCD): its 771 lines (257 rows x {q, k, v} x 128 B) as 4-byte LDS-DMA requests, one line per
+                        // lane, into a dump area -- no register, nothing waits for them but this workgroup's last vmcnt(0).  A
+                        // workgroup spends ~4.5 of its ~16 us waiting for the first byte of its rows.
+                        const int nb = (int)blockIdx.x + KEDS_ATTN_PREFETCH;
+                        if (nb < (int)gridDim.x) {
+                            const int b2 = nb / heads, h2 = nb - b2 * heads;
+                            const bf16_t* base2 = qkv + (size_t)b2 * S * ld + h2 * DH;
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) {
+                                const int line = 64 * (2 * wave + i) + lane;
+                                if (line < 3 * S) {
+                                    const int row = line / 3, part = line - 3 * row;
+                                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base2 + (size_t)row * ld + part * d),
+                                                                     (__attribute__((address_space(3))) void*)(smem + DUMP_OFF), 4, 0, 0);
+                                }
+                            }
+                        }
+                    }
+#endif
                     if (do_last) last_query_partial();
                 }
                 const char* kb = smem + half * 16384;

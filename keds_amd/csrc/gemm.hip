@@ -1218,11 +1218,10 @@ __device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_til
     const int m8 = m_tiles & ~7;
     if (m8 && (n_tiles & 3) == 0 && bid < m8 * n_tiles) {
         const int grp = bid >> 5, within = bid & 31;
-        constexpr int SM = 1 << KEDS_SUPER_M_LOG2, SN = 32 >> KEDS_SUPER_M_LOG2;     // 8 x 4 by default
-        const int grows = m8 / SM;
+        const int grows = m8 >> 3;
         const int gn = grp / grows, gm = grp - gn * grows;
-        tm = gm * SM + (within & (SM - 1));
-        tn = gn * SN + (within >> KEDS_SUPER_M_LOG2);
+        tm = gm * 8 + (within & 7);          // (round 4 re-measured 16 x 2 on the round-3 kernels: 1 % slower, as in round 2)
+        tn = gn * 4 + (within >> 3);
     } else if (m8 && (n_tiles & 3) == 0) {
         const int r = bid - m8 * n_tiles;
         tm = m8 + r / n_tiles;
@@ -1752,7 +1751,8 @@ static int resid_quad_min_k() {
     static int v = -1;
     if (v < 0) {
         const char* e = getenv("KEDS_RESID_QUAD_K");
-        v = e && e[0] ? atoi(e) : 2048;
+        v = e && e[0] ? atoi(e) : 1024;       // round 4: out-proj too (+0.35 % on the headline in four same-box pairs: its A operand,
+                                              // the attention output, is cold in the step and the three-deep ring tolerates that)
     }
     return v;
 }

@@ -127,8 +127,10 @@ int* keds_numerics_guard();
 #ifndef KEDS_LD_RESID_AUX
 #define KEDS_LD_RESID_AUX 0 /* the residual tile the fp16-residual epilogue reads, modifies and writes back */
 #endif
-#ifndef KEDS_SUPER_M_LOG2
-#define KEDS_SUPER_M_LOG2 3 /* 256 x 256 GEMM tile walk: an XCD's 32 concurrent tiles form a (1 << L) x (32 >> L) block of tiles */
+#ifndef KEDS_ATTN_PREFETCH
+#define KEDS_ATTN_PREFETCH 0 /* S = 257 attention: block distance of an L2 prefetch of a later workgroup's rows (0 = off).  Measured,
+                                round 4 (profiles/r04_attn_prefetch_ab.txt): 256 / 512 / 1024 all cost the kernel 27 % (1.74 -> 2.2 ms
+                                per step): 771 four-byte requests per workgroup are dearer than the first-byte latency they hide */
 #endif
 // `base` is wave-uniform (the tile's first byte), `off` the lane's 32-bit byte offset inside it: policies other than 0 go out
 // as a buffer store whose `aux` operand carries the cache-policy bits -- a builtin, so the compiler counts the store and pads

@@ -417,8 +417,7 @@ constexpr int MERGE_SPEC = 16;            // segment slots loaded before the seg
 // with the exact fp32 distance (its four waves take the candidates in turn, four rows in flight each) and runs the selection
 // + certificate on them -- what rerank_kernel and certify_select_kernel did as two more launches (6.4 + 10 us, each a grid
 // of short dependent round trips, + two kernel boundaries): one launch less to wait for, and the candidate ids / scores never
-// leave the CU.  Same arithmetic in the same order as the two kernels (they remain: the threshold pass's merge is unfused,
-// and KEDS_SEARCH_UNFUSED=1 / keds_scan_debug bit 10 selects the three-launch tail for an A/B).
+// leave the CU.  Same arithmetic in the same order as the two kernels.  Measured neutral (see search_tail_fused): an A/B form.
 struct TailArgs {
     const float* db;
     const float* qn;
@@ -1172,14 +1171,17 @@ int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresho
 int g_force_exact = 0;  // test hook: 1 sends every query through the exact fallback
 int g_scan_nt = 1;      // non-temporal LDS-DMA for the D = 768 candidate pass (A/B hook: keds_scan_debug bit 6 turns it off)
 int g_thr_depth = 0;    // threshold-pass list depth: 0 = by launch shape, 1 / 4 forced (A/B hook: keds_scan_debug bits 7-9)
-int g_tail_unfused = 0; // keds_scan_debug bit 10: merge / rerank / certify as three launches (the round-3 tail; A/B, tests)
+int g_tail_unfused = 0; // keds_scan_debug bit 10: merge + re-rank + certificate in ONE launch (A/B, tests; see search_tail_fused)
+// (Measured, round 4, same box, tools/search_profile.py: fused 234-242 us per search, three launches 237 -- one block per
+// query re-ranks its 64 candidates on four waves where rerank_kernel spreads 8,192 waves over the chip; the two kernel
+// boundaries it saves cost less than that.  OFF by default; KEDS_SEARCH_FUSED=1 / keds_scan_debug bit 10 select it.)
 bool search_tail_fused() {
     static int env = -1;
     if (env < 0) {
-        const char* e = getenv("KEDS_SEARCH_UNFUSED");
+        const char* e = getenv("KEDS_SEARCH_FUSED");
         env = e && e[0] == '1';
     }
-    return !env && !g_tail_unfused;
+    return env || g_tail_unfused;
 }
 
 template <int D, int L>
@@ -1259,7 +1261,7 @@ extern "C" int keds_scan_debug(int variant) {
     g_scan_nt = (variant >> 6) & 1 ? 0 : 1;   // bit 6: default-policy key stream instead of non-temporal (A/B)
     g_thr_depth = (variant >> 7) & 7;         // bits 7-9: threshold-pass list depth 1 or 4 forced (0: by launch shape)
     if (g_thr_depth != 1 && g_thr_depth != 4) g_thr_depth = 0;
-    g_tail_unfused = (variant >> 10) & 1;     // bit 10: merge / rerank / certify as three launches (A/B, tests)
+    g_tail_unfused = (variant >> 10) & 1;     // bit 10: merge + re-rank + certificate in one launch (A/B, tests)
     return KEDS_OK;
 }
 

@@ -280,6 +280,30 @@ def exchange_merge_gather(D_p: torch.Tensor, I_p: torch.Tensor, rows_p: torch.Te
     return D, I, rows
 
 
+def install_host_staged_transport(dist) -> None:
+    """DIAGNOSTIC transport for several ranks that share ONE GPU (RCCL refuses two ranks on a device): patches the two
+    collectives the packed exchange uses so that device tensors travel device -> host -> the process group (gloo) -> host
+    -> device.  Everything around the collectives stays the product's device branch (pack / merge kernels, shard scans).
+    Used by tests/exchange2_worker.py and by `KEDS_BENCH_SHARED_GPU=1 python bench.py --gpus N`; never on a real node."""
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        w = dist.get_world_size(group)
+        h = inp.detach().cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(w)]
+        dist.all_gather(parts, h, group=group)
+        out.copy_(torch.cat(parts).view(out.shape).to(out.device))
+
+    def all_to_all_single(out, inp, group=None, **kw):
+        w, r = dist.get_world_size(group), dist.get_rank(group)
+        h = inp.detach().cpu().contiguous()
+        parts = [torch.empty_like(h) for _ in range(w)]
+        dist.all_gather(parts, h, group=group)
+        n = h.shape[0] // w                                   # equal splits: block r of every rank comes to rank r
+        out.copy_(torch.cat([p[r * n:(r + 1) * n] for p in parts]).view(out.shape).to(out.device))
+
+    dist.all_gather_into_tensor = all_gather_into_tensor
+    dist.all_to_all_single = all_to_all_single
+
+
 class PackedExchange:
     """The two collectives of one data-parallel sharded search, on preallocated buffers:
 

@@ -18,29 +18,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def host_staged_transport(dist):
-    """Patch the two collectives the packed exchange uses: device tensors travel device -> host -> gloo -> host -> device."""
-    import torch
-
-    def all_gather_into_tensor(out, inp, group=None, async_op=False):
-        w = dist.get_world_size(group)
-        h = inp.detach().cpu().contiguous()
-        parts = [torch.empty_like(h) for _ in range(w)]
-        dist.all_gather(parts, h, group=group)
-        out.copy_(torch.cat(parts).view(out.shape).to(out.device))
-
-    def all_to_all_single(out, inp, group=None, **kw):
-        w, r = dist.get_world_size(group), dist.get_rank(group)
-        h = inp.detach().cpu().contiguous()
-        parts = [torch.empty_like(h) for _ in range(w)]
-        dist.all_gather(parts, h, group=group)
-        n = h.shape[0] // w                                   # equal splits: block r of every rank comes to rank r
-        out.copy_(torch.cat([p[r * n:(r + 1) * n] for p in parts]).view(out.shape).to(out.device))
-
-    dist.all_gather_into_tensor = all_gather_into_tensor
-    dist.all_to_all_single = all_to_all_single
-
-
 def main():
     rank, world, port, out_dir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     res = {"rank": rank, "ok": False}
@@ -50,10 +27,10 @@ def main():
         import datetime
         dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world,
                                 timeout=datetime.timedelta(seconds=240))      # a peer that died must not hang the suite
-        host_staged_transport(dist)
         import keds_amd
         from keds_amd import _lib
-        from keds_amd.index import PackedExchange, ShardedFlatIndex, shard_bounds
+        from keds_amd.index import PackedExchange, ShardedFlatIndex, install_host_staged_transport, shard_bounds
+        install_host_staged_transport(dist)
         from oracle import keds_oracle as O
         _lib.load()
         torch.cuda.set_device(0)

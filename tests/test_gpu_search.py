@@ -176,8 +176,9 @@ def test_two_phase_thresholds_equal_single_phase():
 
 @pytest.mark.parametrize("metric,dim,k", [("l2", 768, 10), ("l2", 768, 16), ("ip", 256, 101), ("l2", 128, 40)])
 def test_fused_search_tail_equals_the_three_launch_tail(metric, dim, k):
-    """Round 4: the final merge of a search also re-ranks its candidates and runs selection + certificate in the same launch
-    (merge_pairs_kernel<true>).  Same arithmetic as merge -> rerank_kernel -> certify_select_kernel (keds_scan_debug bit 10):
+    """Round 4 (an A/B form, measured neutral, off by default): the final merge of a search can also re-rank its candidates and
+    run selection + certificate in the same launch (merge_pairs_kernel<true>, keds_scan_debug bit 10).  Same arithmetic as
+    merge -> rerank_kernel -> certify_select_kernel:
     distances, ids and the certificate verdicts must be identical -- on iid data, on clustered data with ties at the cut, and
     with fewer valid candidates than k."""
     lib = _lib.load()

@@ -4,9 +4,7 @@
 B="python bench.py --steps 40 --warmup 4 --no-cpu-baseline $BENCH_ARGS"
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -Wno-unused-result"
 OBJS="build/gemm.o build/gemm_fp8.o build/attention.o build/search.o"
-run() { for i in $(seq ${RUNS:-2}); do $B 2>/dev/null | tail -1 | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('   %.0f img/s  %.3f ms/step  gemm %.3f ms  frac %.4f  guard tripped: %s' % (d['value'], d['ms_per_step'], d['stage_ms_per_step']['gemm'], d['roofline']['frac'], d['numerics_guard']['tripped']))"; done
+run() { for i in $(seq ${RUNS:-2}); do $B 2>/dev/null | tail -1 | python3 tools/ab_line.py; done
   # a variant that computes garbage can be FASTER (fewer toggling bits at the power cap): every variant must also reproduce the embeddings
   python - <<'PY'
 import torch, bench, keds_amd
