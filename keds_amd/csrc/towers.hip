@@ -139,6 +139,17 @@ int cls_rows_tail(const keds_tower_params* p, const keds_block_params& k, const 
     return keds_gemm_bt_ex(t.hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st);
 }
 
+// KEDS_TAIL_ATTN=1 in the environment: the tail samples' attention on the side lane (round-4 experiment, OFF by default:
+// bit-identical and neutral -- 6,759-6,770 vs 6,770-6,776 img/s in four same-box pairs, profiles/r04_tail_attention_ab.txt)
+bool tail_attention_on_side() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_TAIL_ATTN");
+        v = e && e[0] == '1';
+    }
+    return v != 0;
+}
+
 bool bf16_rows_split(int M, int w) {
     return keds_gemm_splits_rows(M, 3 * w, w) && keds_gemm_splits_rows(M, w, w) && keds_gemm_splits_rows(M, 4 * w, w) &&
            keds_gemm_splits_rows(M, w, 4 * w);
@@ -248,15 +259,37 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         }
         if ((rc = keds_rowstats_cast_ex(x, t.h, 1, (float*)t.st1, M + fill, w, st))) return rc;
         if ((rc = lanes.to_side())) return rc;
+        // Round-4 experiment (KEDS_TAIL_ATTN=1; off): the samples whose rows reach into the remainder ("tail" samples: b >= Mm / S;
+        // one of 128 at ViT-L/14) get their attention ON THE SIDE LANE.  A kernel trace shows the main lane waiting 9 us per block
+        // on average at its join in front of the attention launch (profiles/r04_trace_gaps.txt): the side chain's last launch
+        // (the remainder rows' in_proj) cannot get a CU while the main lane's PERSISTENT in_proj holds all of them, so it runs
+        // behind it.  Here the main lane's attention covers the samples that live in full tiles only and needs no join; the side
+        // lane waits for the main in_proj, runs the tail samples' attention beside the main attention launch, and the main lane
+        // waits for THAT in front of out-proj.  Bit-identical -- and neutral: the side launches (128 KiB of LDS each) do not fit
+        // beside an attention workgroup either, so the wait only moves.
+        const int b_tail = lanes.split && tail_attention_on_side() ? Mm / S : B;      // first tail sample (B: none)
+        const bool tail_side = b_tail > 0 && b_tail < B;
         for (int l = 0; l < p->layers; ++l) {
             const keds_block_params& k = p->blocks[l];
             const bool last = l == p->layers - 1;
             if ((rc = qkv_rows(t, k, w, body))) return rc;
             if (rem.n && (rc = qkv_rows(t, k, w, rem))) return rc;
-            if ((rc = lanes.to_main())) return rc;
-            if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, t.h, B, st);
-            if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
-            if ((rc = lanes.to_side())) return rc;
+            if (last && p->last_cls_only) {
+                if ((rc = lanes.to_main())) return rc;
+                return cls_rows_tail(p, k, t, x, t.h, B, st);
+            }
+            if (tail_side) {
+                if ((rc = lanes.to_side())) return rc;               // side: behind the main in_proj
+                if ((rc = keds_attention(t.qkv, t.att, b_tail, S, p->heads, p->causal, st))) return rc;
+                if ((rc = keds_attention(t.qkv + (size_t)b_tail * S * 3 * w, t.att + (size_t)b_tail * S * w, B - b_tail, S, p->heads,
+                                         p->causal, lanes.side)))
+                    return rc;
+                if ((rc = lanes.to_main())) return rc;               // main: behind the tail samples' attention
+            } else {
+                if ((rc = lanes.to_main())) return rc;
+                if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
+                if ((rc = lanes.to_side())) return rc;
+            }
             if ((rc = out_rows(t, k, w, body))) return rc;
             if (rem.n && (rc = out_rows(t, k, w, rem))) return rc;
             if ((rc = fc_rows(t, k, w, body))) return rc;
