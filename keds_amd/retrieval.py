@@ -90,7 +90,8 @@ def extract_feature_database_sharded(model: CLIP, n_rows: int, image_rows, text_
                     idx = FlatIndex(f.shape[1], "l2", device=f.device, row0=lo)
                 idx.add(f)                                        # chunked add: packs only the new stages
             return idx
-        idx = model.numerics_checked(encode_shard)                # (re-encoded on the safe flow if the guard tripped late)
+        # (re-encoded on the safe flow if the guard tripped late; a caller that brings its own encoders passes model = None)
+        idx = model.numerics_checked(encode_shard) if model is not None else encode_shard()
         if idx is None:
             raise RuntimeError(f"rank {rank} of {world} owns no rows of a {n_rows}-row database")
         idx.save(os.path.join(out_dir, f"cc_{name}_index.shard{rank}-of-{world}.pt"))
