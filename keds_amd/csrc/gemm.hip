@@ -814,7 +814,6 @@ constexpr int LDS_BYTES = SIDE_OFF + 4096;      // 132 KiB
 // STAMP (diagnostic build of one instantiation, tools/stamp_gemm.py): s_memtime stamps around the prologue, every
 // K-tile's wait and barrier, the loop and the epilogue; aux2 then receives 8 counters per wave instead of its usual role.
 // RP (KEDS_EPI_RESID_STATS_F16 only): residual tile + bias as the accumulators' initial value (pair_resid_epilogue_acc)
-__device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_tiles, int& tm, int& tn);   // (defined below)
 template <int EPI, int STAMP = 0, int RP = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __restrict__ X, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, void* __restrict__ out,
@@ -1210,27 +1209,6 @@ constexpr int SIDE0 = pr::SIDE_OFF;                 // two side areas (tile i us
 constexpr int RED_OFF = pr::SIDE_OFF + 2 * 4096;    // ... and 8 KiB for the statistics pre-reduction of the residual epilogue
 constexpr int LDS_BYTES = RED_OFF + 8192;           // 144 KiB
 }  // namespace qd
-
-// logical tile id -> (tm, tn): the 8 x 4 supertiles per XCD of the 8-wave kernel, m fastest
-// (m_tiles need not be a multiple of 8 -- a tower's ragged 129th row tile: the first m_tiles & ~7 row tiles form the
-// supertiles, the rest follow in plain order)
-__device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_tiles, int& tm, int& tn) {
-    const int m8 = m_tiles & ~7;
-    if (m8 && (n_tiles & 3) == 0 && bid < m8 * n_tiles) {
-        const int grp = bid >> 5, within = bid & 31;
-        const int grows = m8 >> 3;
-        const int gn = grp / grows, gm = grp - gn * grows;
-        tm = gm * 8 + (within & 7);          // (round 4 re-measured 16 x 2 on the round-3 kernels: 1 % slower, as in round 2)
-        tn = gn * 4 + (within >> 3);
-    } else if (m8 && (n_tiles & 3) == 0) {
-        const int r = bid - m8 * n_tiles;
-        tm = m8 + r / n_tiles;
-        tn = r - (tm - m8) * n_tiles;
-    } else {
-        tm = bid / n_tiles;
-        tn = bid - tm * n_tiles;
-    }
-}
 
 // PERSIST: gridDim.x workgroups (one per CU) walk the tiles id = blockIdx.x, + gridDim.x, ... (the ids the dispatcher would
 // have dealt them, so the XCD grouping of the walk is unchanged).  Behind a tile's K-loop and one barrier the workgroup

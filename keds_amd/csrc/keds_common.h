@@ -201,6 +201,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return base + (bid >> 3);
 }
 
+// logical tile id -> (tm, tn): the 8 x 4 supertiles per XCD of the 256 x 256 tile kernels (gemm.hip, gemm_fp8.hip), m fastest
+// (m_tiles need not be a multiple of 8 -- a tower's ragged 129th row tile: the first m_tiles & ~7 row tiles form the
+// supertiles, the rest follow in plain order)
+__device__ __forceinline__ void quad_tile_coords(int bid, int m_tiles, int n_tiles, int& tm, int& tn) {
+    const int m8 = m_tiles & ~7;
+    if (m8 && (n_tiles & 3) == 0 && bid < m8 * n_tiles) {
+        const int grp = bid >> 5, within = bid & 31;
+        const int grows = m8 >> 3;
+        const int gn = grp / grows, gm = grp - gn * grows;
+        tm = gm * 8 + (within & 7);          // (round 4 re-measured 16 x 2 on the round-3 kernels: 1 % slower, as in round 2)
+        tn = gn * 4 + (within >> 3);
+    } else if (m8 && (n_tiles & 3) == 0) {
+        const int r = bid - m8 * n_tiles;
+        tm = m8 + r / n_tiles;
+        tn = r - (tm - m8) * n_tiles;
+    } else {
+        tm = bid / n_tiles;
+        tn = bid - tm * n_tiles;
+    }
+}
+
 // ---- LayerNorm row statistics {sum, sum of squares} accumulated across workgroups ---------------------------------
 // Stored as 64-bit FIXED POINT (value * 2^28) and added with integer atomics: integer addition is associative, so the
 // result does not depend on the order in which tiles arrive and every run produces the same bits (fp32 atomics did

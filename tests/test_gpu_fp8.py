@@ -305,3 +305,60 @@ def test_text_tower_and_session_handles_in_fp8():
         txt.close()
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("epi,M,N,K", [("bias", 8448, 1024, 1024), ("ln", 8448, 3072, 1024), ("ln_gelu", 8192, 4096, 1024),
+                                       ("resid_h", 8448, 1024, 4096), ("resid_h", 8448, 1024, 1024), ("resid", 4352, 1024, 512),
+                                       ("ln", 512, 768, 768)])
+def test_mxfp8_four_wave_kernel_is_bit_identical_to_the_eight_wave_kernel(epi, M, N, K):
+    """The 4-wave persistent kernel (gemm_mxfp8_quad_kernel: 128 x 128 wave tiles, accumulators in fixed AGPRs, W fragments refilled
+    in place, the next tile's K-tiles requested before the epilogue) against the 8-wave kernel (keds_mxfp8_debug(16)) on the same
+    operands: every output byte, scale byte and statistic equal -- per accumulator both run the same chain of block-scaled MFMAs in
+    K order and share the epilogue code.  Shapes: more tiles than CUs (the persistent walk, ragged 33-row-tile counts), K = 512 (the
+    shortest K the 4-wave form takes) ... 4096."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device="cuda") * torch.exp(0.5 * torch.randn(M, 1, generator=g, device="cuda"))
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    aq, as_ = _quantize(a)
+    res = {}
+    for form in (16, 0):
+        lib.keds_mxfp8_debug(form)
+        try:
+            q = torch.zeros((M, N), dtype=torch.uint8, device="cuda")
+            qs = torch.full((N // 128, M, 4), 127, dtype=torch.uint8, device="cuda")
+            other = torch.full((M + 8, 2), 7, dtype=torch.int64, device="cuda")
+            if epi in ("ln", "ln_gelu"):
+                gamma = 1 + 0.2 * torch.randn(K, generator=torch.Generator(device="cuda").manual_seed(1), device="cuda")
+                beta = 0.1 * torch.randn(K, generator=torch.Generator(device="cuda").manual_seed(2), device="cuda")
+                wq, ws, bc = _fold_fp8(w, b, gamma, beta)
+                stats = (torch.stack([a.sum(1), (a * a).sum(1)], dim=1).double() * 2.0 ** 28).round().to(torch.int64).contiguous()
+                out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+                code = _lib.FP8_EPI_LN_QGELU_MX if epi == "ln_gelu" else _lib.FP8_EPI_LN_BIAS_BF16
+                _lib.check(lib.keds_gemm_mxfp8_ex(_lib.ptr(aq), _lib.ptr(as_), as_.shape[1], _lib.ptr(wq), _lib.ptr(ws), ws.shape[1],
+                                                  _lib.ptr(bc), None if epi == "ln_gelu" else _lib.ptr(out), M, N, K, code, _lib.ptr(stats),
+                                                  _lib.ptr(other), _lib.ptr(q), _lib.ptr(qs), M, _lib.stream()), "gemm fp8 ln")
+                res[form] = (out, q, qs, other)
+            elif epi == "bias":
+                wq, ws = _quantize(w)
+                out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+                _lib.check(lib.keds_gemm_mxfp8(_lib.ptr(aq), _lib.ptr(as_), as_.shape[1], _lib.ptr(wq), _lib.ptr(ws), ws.shape[1],
+                                               _lib.ptr(b), _lib.ptr(out), M, N, K, _lib.stream()), "gemm_mxfp8")
+                res[form] = (out,)
+            else:
+                wq, ws = _quantize(w)
+                x = 3 * torch.randn(M, N, generator=torch.Generator(device="cuda").manual_seed(3), device="cuda")
+                x = x.half() if epi == "resid_h" else x
+                stats = torch.zeros((M, 2), dtype=torch.int64, device="cuda")
+                code = _lib.FP8_EPI_RESID_STATS_MX_H if epi == "resid_h" else _lib.FP8_EPI_RESID_STATS_MX
+                _lib.check(lib.keds_gemm_mxfp8_ex(_lib.ptr(aq), _lib.ptr(as_), as_.shape[1], _lib.ptr(wq), _lib.ptr(ws), ws.shape[1],
+                                                  _lib.ptr(b), _lib.ptr(x), M, N, K, code, _lib.ptr(stats), None, _lib.ptr(q),
+                                                  _lib.ptr(qs), M, _lib.stream()), "gemm fp8 resid")
+                res[form] = (x, q, qs, stats)
+            torch.cuda.synchronize()
+        finally:
+            lib.keds_mxfp8_debug(0)
+    for t8, t4 in zip(res[16], res[0]):
+        assert torch.equal(t8.view(torch.uint8), t4.view(torch.uint8))
+    assert float(res[0][1 if epi == "ln_gelu" else 0].float().abs().max()) > 0.1     # (not two all-zero tensors)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Build-time check of the 4-wave GEMM kernels' register discipline (runs without a GPU: hipcc -S of gemm.hip, ~30 s).
 
-The 256 accumulators of gemm_bt_quad_kernel / gemm_bt_quad3_kernel live in the fixed AGPRs a0..a255 that ONLY the literal-
-register inline asm of csrc/gemm_quad_gen.h touches; the compiler is not told about them (no operand, no clobber), so the
-kernels are correct only while the compiler itself places nothing there.  This script compiles gemm.hip to gfx950 assembly
+The 256 accumulators of gemm_bt_quad_kernel / gemm_bt_quad3_kernel (gemm.hip) and gemm_mxfp8_quad_kernel (gemm_fp8.hip) live in
+the fixed AGPRs a0..a255 that ONLY the literal-register inline asm of csrc/gemm_quad_gen.h / gemm_fp8_quad_gen.h touches; the compiler is not told about them (no operand, no clobber), so the
+kernels are correct only while the compiler itself places nothing there.  This script compiles gemm.hip and gemm_fp8.hip to gfx950 assembly
 and asserts, for every instantiation:
 
   * exactly 256 AGPRs are allocated (next_free_vgpr - accum_offset == 256): the compiler allocated none of its own;
@@ -29,7 +29,7 @@ ALLOW_SCRATCH = (re.compile(r"gemm_bt_quad_kernelILi9ELi0ELi1E"),)     # persist
 def kernels(asm: str):
     for chunk in re.split(r"\n\s*\.globl\s+", asm)[1:]:
         name = chunk.split("\n", 1)[0].strip()
-        if "gemm_bt_quad" in name:
+        if "gemm_bt_quad" in name or "gemm_mxfp8_quad" in name:
             yield name, chunk
 
 
@@ -70,15 +70,21 @@ def check(asm: str):
 
 def main():
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
+    n, errors = 0, []
     with tempfile.TemporaryDirectory() as td:
-        out = keep or os.path.join(td, "gemm.s")
-        src = os.path.join(ROOT, "keds_amd", "csrc", "gemm.hip")
-        res = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--offload-device-only", "-S", src, "-o", out],
-                             capture_output=True, text=True)
-        if res.returncode != 0:
-            print(res.stderr[-3000:])
-            return 2
-        n, errors = check(open(out).read())
+        for fname in ("gemm", "gemm_fp8"):
+            out = (keep + "." + fname if keep else os.path.join(td, fname + ".s"))
+            src = os.path.join(ROOT, "keds_amd", "csrc", fname + ".hip")
+            res = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--offload-device-only", "-S", src, "-o", out],
+                                 capture_output=True, text=True)
+            if res.returncode != 0:
+                print(res.stderr[-3000:])
+                return 2
+            k, e = check(open(out).read())
+            if k == 0:
+                e.append(f"{fname}.hip: no 4-wave kernel found")
+            n += k
+            errors += e
     for e in errors:
         print("FAIL", e)
     print(f"{n} quad kernel instantiations checked, {len(errors)} problem(s)")
