@@ -114,150 +114,178 @@ __global__ __launch_bounds__(256) void fold_quantize_mxfp8_kernel(const float* _
 }
 
 // ---- the epilogues of one wave's 128 x 64 block of accumulators (both tile kernels): wave row wm (0..1), wave column wn (0..3)
-// State a 64-column block carries between its two 32-column quarters (the 4-wave kernel reads its accumulators back one
-// quarter at a time: with all 128 live beside the residual chunks and this state the allocator ran out and parked values in AGPRs)
-struct MxCarry {
-    float rs[8], rss[8];          // row {sum, sum of squares} partials (residual epilogues)
-    uint2 mxk[8];                 // the lane's 8 bytes of MX block pp = 0 ...
-    int mxe[8];                   // ... and that block's exponent, kept until pp = 1 for the 16-byte stores
+// timing-only ablations of the 4-wave kernel (tools/fp8_ablate.sh rebuilds with -DKEDS_FQ_ABL=n; results are wrong), bits:
+// 1: no epilogue (read-back only)   2: the K-loop runs its first two and last two K-tiles only
+// residual epilogues:  4: no statistics atomics   8: no MXFP8 copy / scale stores   16: no residual store   32: no residual load
+#ifndef KEDS_FQ_ABL
+#define KEDS_FQ_ABL 0
+#endif
+// ---- the epilogues, one ROW GROUP at a time: the 16 rows 16 mi + c of one wave's 128 x 64 block, lane (g, c) owning row c and
+// the columns 64 wn + 32 pp + 8 g + 0..7 (a[2 pp], a[2 pp + 1]) of both 32-column MX blocks pp.  The four lanes g = 0..3 of a row
+// hold exactly one MX block per pp, so block amax / row sums are two xor-shuffles.  (Row groups outermost since round 4: the
+// 4-wave kernel reads its accumulators back 16 registers at a time -- with a 64-register quarter, the residual chunks and the
+// state carried between the two blocks of all eight row groups the allocator ran out and parked values in accumulator AGPRs.)
+struct MxSide {                   // per MX block pp: bias' (or bias) and the LayerNorm column sums of the lane's 8 columns
+    f32x4 b0[2], b1[2], c0[2], c1[2];
 };
-// quarters PP0 .. PP1 - 1 of the block: <EPI, 0, 2> = the whole block in one call
-template <int EPI, int PP0 = 0, int PP1 = 2>
-__device__ __forceinline__ void mx_epilogue(f32x4 (&acc)[4][8], MxCarry& cy, const char* side, const float* __restrict__ bias,
-                                            void* __restrict__ out, int m0, int n0, int N, int wm, int wn, int g, int c,
-                                            float* __restrict__ aux, float* __restrict__ aux2, unsigned char* __restrict__ qout,
-                                            unsigned char* __restrict__ qscale, int q_pad) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    // ---- epilogue: lane (g,c) owns rows m0 + 128*wm + 16*mi + c, columns n0 + 64*wn + 32*pp + 8*g + 0..7.  The four lanes
-    // g = 0..3 of a row hold exactly one 32-column MX block per pp, so block amax / row sums are two xor-shuffles.
-    float rstd[8], nmr[8];
-    if constexpr (EPI == 1 || EPI == 2) {
+template <int EPI>
+__device__ __forceinline__ void mx_side(MxSide& sd, const char* side, const float* __restrict__ bias, int n0, int wn, int g) {
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + 128 * wm + 16 * mi + c;
-            const f32x2 cf = *reinterpret_cast<const f32x2*>(side + (128 * wm + 16 * mi + c) * 8);
-            rstd[mi] = cf[0];
-            nmr[mi] = cf[1];
-            if (PP0 == 0 && aux2 && n0 == 0 && wn == 0 && g == 0) keds_stat_zero(reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)m);
-        }
-    }
-    float (&rs)[8] = cy.rs;
-    float (&rss)[8] = cy.rss;
-    uint2 (&mxk)[8] = cy.mxk;
-    int (&mxe)[8] = cy.mxe;
-    if constexpr (PP0 == 0) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) rs[mi] = rss[mi] = 0.f;
-    }
-#pragma unroll
-    for (int pp = PP0; pp < PP1; ++pp) {
-        const int n = n0 + 64 * wn + 32 * pp + 8 * g;
-        f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0, c0 = b0, c1 = b0;
+    for (int pp = 0; pp < 2; ++pp) {
+        sd.b0[pp] = sd.b1[pp] = sd.c0[pp] = sd.c1[pp] = f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (EPI == 1 || EPI == 2) {
             const char* sb = side + 2048 + (64 * wn + 32 * pp + 8 * g) * 4;
-            b0 = *reinterpret_cast<const f32x4*>(sb);
-            b1 = *reinterpret_cast<const f32x4*>(sb + 16);
-            c0 = *reinterpret_cast<const f32x4*>(sb + 1024);
-            c1 = *reinterpret_cast<const f32x4*>(sb + 1024 + 16);
+            sd.b0[pp] = *reinterpret_cast<const f32x4*>(sb);
+            sd.b1[pp] = *reinterpret_cast<const f32x4*>(sb + 16);
+            sd.c0[pp] = *reinterpret_cast<const f32x4*>(sb + 1024);
+            sd.c1[pp] = *reinterpret_cast<const f32x4*>(sb + 1024 + 16);
         } else if (bias) {
-            b0 = *reinterpret_cast<const f32x4*>(bias + n);
-            b1 = *reinterpret_cast<const f32x4*>(bias + n + 4);
+            const int n = n0 + 64 * wn + 32 * pp + 8 * g;
+            sd.b0[pp] = *reinterpret_cast<const f32x4*>(bias + n);
+            sd.b1[pp] = *reinterpret_cast<const f32x4*>(bias + n + 4);
         }
+    }
+}
+// PRE: `pre[pp]` holds the row group's fp16 residual chunks (EPI 4), loaded by the caller ahead of time; stores go through
+//      32-bit offsets from the tile's base (no pointer pair per row)
+// STAT (residual epilogues): 2 = one atomic pair per row and 64-column block; 4 = the partials go to LDS instead
+//      (`red`: [wave column 0..3][row] {sum, sum sq}; the caller adds the four and issues ONE atomic pair per row and tile:
+//      2,048 -> 512 atomics per tile, 7 us of out-proj's 69)
+template <int EPI, bool PRE = false, int STAT = 2>
+__device__ __forceinline__ void mx_epilogue_rows(const f32x4 (&a)[4], int mi, const MxSide& sd, const char* side, void* __restrict__ out,
+                                                 int m0, int n0, int N, int wm, int wn, int g, int c, float* __restrict__ aux,
+                                                 float* __restrict__ aux2, unsigned char* __restrict__ qout,
+                                                 unsigned char* __restrict__ qscale, int q_pad, const f16x8 (&pre)[2],
+                                                 float* red = nullptr) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int m = m0 + 128 * wm + 16 * mi + c;                   // M is a multiple of 256: every row is valid
+    [[maybe_unused]] float rstd = 1.f, nmr = 0.f;
+    if constexpr (EPI == 1 || EPI == 2) {
+        const f32x2 cf = *reinterpret_cast<const f32x2*>(side + (128 * wm + 16 * mi + c) * 8);
+        rstd = cf[0];
+        nmr = cf[1];
+        if (aux2 && n0 == 0 && wn == 0 && g == 0) keds_stat_zero(reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)m);
+    }
+    [[maybe_unused]] float rs = 0.f, rss = 0.f;
+    [[maybe_unused]] uint2 mxk = uint2{0u, 0u};
+    [[maybe_unused]] int mxe = 0;
 #pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + 128 * wm + 16 * mi + c;           // M is a multiple of 256: every row is valid
-            f32x4 v0, v1;
-            if constexpr (EPI == 1 || EPI == 2) {
-                v0 = acc[2 * pp][mi] * rstd[mi] + (c0 * nmr[mi] + b0);
-                v1 = acc[2 * pp + 1][mi] * rstd[mi] + (c1 * nmr[mi] + b1);
+    for (int pp = 0; pp < 2; ++pp) {
+        const int n = n0 + 64 * wn + 32 * pp + 8 * g;
+        f32x4 v0, v1;
+        if constexpr (EPI == 1 || EPI == 2) {
+            v0 = a[2 * pp] * rstd + (sd.c0[pp] * nmr + sd.b0[pp]);
+            v1 = a[2 * pp + 1] * rstd + (sd.c1[pp] * nmr + sd.b1[pp]);
+        } else {
+            v0 = a[2 * pp] + sd.b0[pp];
+            v1 = a[2 * pp + 1] + sd.b1[pp];
+        }
+        if constexpr (EPI == 2) {
+            // x * sigmoid(1.702 x)  (src/model/model.py:300-302) on whole vectors: the scale, the + 1 and the product are packed
+            // operations (gemm.hip, pair_ln_epilogue: the scalar form compiled to twice the issue slots)
+            f32x4 z0 = v0 * -2.4554669595930157f, z1 = v1 * -2.4554669595930157f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                z0[j] = __builtin_amdgcn_exp2f(z0[j]);
+                z1[j] = __builtin_amdgcn_exp2f(z1[j]);
+            }
+            z0 = z0 + 1.0f;
+            z1 = z1 + 1.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                z0[j] = __builtin_amdgcn_rcpf(z0[j]);
+                z1[j] = __builtin_amdgcn_rcpf(z1[j]);
+            }
+            v0 = v0 * z0;
+            v1 = v1 * z1;
+        }
+        if constexpr (EPI == 3 || EPI == 4) {
+            if constexpr (EPI == 3) {
+                float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
+                v0 += *reinterpret_cast<const f32x4*>(o);
+                v1 += *reinterpret_cast<const f32x4*>(o + 4);
+                *reinterpret_cast<f32x4*>(o) = v0;
+                *reinterpret_cast<f32x4*>(o + 4) = v1;
+            } else {                                          // fp16 residual stream (cf. KEDS_EPI_RESID_STATS_F16)
+                f16x8* o = reinterpret_cast<f16x8*>(reinterpret_cast<f16_t*>(out) + (size_t)m * N + n);
+                f16x8 r;
+                if constexpr (PRE && !(KEDS_FQ_ABL & 32)) r = pre[pp];
+                else if constexpr ((KEDS_FQ_ABL & 32) != 0) r = f16x8{(f16_t)1.f, (f16_t)2.f, (f16_t)-1.f, (f16_t)0.5f, (f16_t)1.f, (f16_t)2.f, (f16_t)-1.f, (f16_t)0.5f};
+                else r = *o;
+                v0 += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+                v1 += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
+                const f16x8 nr = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3],
+                                       (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
+                if constexpr ((KEDS_FQ_ABL & 16) != 0) { if (nr[0] == (f16_t)123.25f) *o = nr; }
+                else if constexpr (PRE)
+                    keds_store16<8>(nr, reinterpret_cast<f16_t*>(out) + (size_t)m0 * N + n0, (unsigned)(((size_t)(m - m0) * N + (n - n0)) * 2));
+                else
+                    *o = nr;
+            }
+            rs += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
+            rss += ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) +
+                   ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
+        }
+        if constexpr (EPI == 0 || EPI == 1) {
+            keds_store16<KEDS_ST_FP8_BF16>(bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
+                                                   (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]},
+                                           reinterpret_cast<bf16_t*>(out) + (size_t)m0 * N + n0,
+                                           (unsigned)(((size_t)(m - m0) * N + (n - n0)) * 2));
+        } else {                                              // MXFP8 copy: one 32-column block per (row, pp)
+            const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+            float amax = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
+            amax = rows_max(amax);
+            const int e = mx_block_exp(amax);
+            const uint2 pk = mx_pack8(v, e);
+            // 16-byte stores: the lane's 8 bytes of block pp = 0 are kept until pp = 1, then the four lanes of the row
+            // swap (v_permlane16_swap: the odd 16-lane rows of the first operand against the even rows of the second)
+            // so that g = 0 / 2 own columns 0-15 / 16-31 of block 0 and g = 1 / 3 those of block 1; the two scale
+            // bytes of the row (blocks 2 wn and 2 wn + 1 of its dword) go out as one 16-bit store
+            if (pp == 0) {      // (8-byte + 1-byte stores per block: +0.35 ms of the 16.5 ms fp8 step, same-box A/B)
+                mxk = pk;
+                mxe = e;
             } else {
-                v0 = acc[2 * pp][mi] + b0;
-                v1 = acc[2 * pp + 1][mi] + b1;
-            }
-            if constexpr (EPI == 2) {
-                // x * sigmoid(1.702 x)  (src/model/model.py:300-302) on whole vectors: the scale, the + 1 and the product are packed
-                // operations (gemm.hip, pair_ln_epilogue: the scalar form compiled to twice the issue slots)
-                f32x4 z0 = v0 * -2.4554669595930157f, z1 = v1 * -2.4554669595930157f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    z0[j] = __builtin_amdgcn_exp2f(z0[j]);
-                    z1[j] = __builtin_amdgcn_exp2f(z1[j]);
-                }
-                z0 = z0 + 1.0f;
-                z1 = z1 + 1.0f;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    z0[j] = __builtin_amdgcn_rcpf(z0[j]);
-                    z1[j] = __builtin_amdgcn_rcpf(z1[j]);
-                }
-                v0 = v0 * z0;
-                v1 = v1 * z1;
-            }
-            if constexpr (EPI == 3 || EPI == 4) {
-                if constexpr (EPI == 3) {
-                    float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
-                    v0 += *reinterpret_cast<const f32x4*>(o);
-                    v1 += *reinterpret_cast<const f32x4*>(o + 4);
-                    *reinterpret_cast<f32x4*>(o) = v0;
-                    *reinterpret_cast<f32x4*>(o + 4) = v1;
-                } else {                                          // fp16 residual stream (cf. KEDS_EPI_RESID_STATS_F16)
-                    f16x8* o = reinterpret_cast<f16x8*>(reinterpret_cast<f16_t*>(out) + (size_t)m * N + n);
-                    const f16x8 r = *o;
-                    v0 += f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
-                    v1 += f32x4{(float)r[4], (float)r[5], (float)r[6], (float)r[7]};
-                    *o = f16x8{(f16_t)v0[0], (f16_t)v0[1], (f16_t)v0[2], (f16_t)v0[3],
-                               (f16_t)v1[0], (f16_t)v1[1], (f16_t)v1[2], (f16_t)v1[3]};
-                }
-                rs[mi] += ((v0[0] + v0[1]) + (v0[2] + v0[3])) + ((v1[0] + v1[1]) + (v1[2] + v1[3]));
-                rss[mi] += ((v0[0] * v0[0] + v0[1] * v0[1]) + (v0[2] * v0[2] + v0[3] * v0[3])) +
-                           ((v1[0] * v1[0] + v1[1] * v1[1]) + (v1[2] * v1[2] + v1[3] * v1[3]));
-            }
-            if constexpr (EPI == 0 || EPI == 1) {
-                keds_store16<KEDS_ST_FP8_BF16>(bf16x8{(bf16_t)v0[0], (bf16_t)v0[1], (bf16_t)v0[2], (bf16_t)v0[3],
-                                                       (bf16_t)v1[0], (bf16_t)v1[1], (bf16_t)v1[2], (bf16_t)v1[3]},
-                                               reinterpret_cast<bf16_t*>(out) + (size_t)m0 * N + n0,
-                                               (unsigned)(((size_t)(m - m0) * N + (n - n0)) * 2));
-            } else {                                              // MXFP8 copy: one 32-column block per (row, pp)
-                const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                float amax = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(v[j]));
-                amax = rows_max(amax);
-                const int e = mx_block_exp(amax);
-                const uint2 pk = mx_pack8(v, e);
-                // 16-byte stores: the lane's 8 bytes of block pp = 0 are kept until pp = 1, then the four lanes of the row
-                // swap (v_permlane16_swap: the odd 16-lane rows of the first operand against the even rows of the second)
-                // so that g = 0 / 2 own columns 0-15 / 16-31 of block 0 and g = 1 / 3 those of block 1; the two scale
-                // bytes of the row (blocks 2 wn and 2 wn + 1 of its dword) go out as one 16-bit store
-                if (pp == 0) {      // (8-byte + 1-byte stores per block: +0.35 ms of the 16.5 ms fp8 step, same-box A/B)
-                    mxk[mi] = pk;
-                    mxe[mi] = e;
-                } else {
-                    const auto s0 = __builtin_amdgcn_permlane16_swap(mxk[mi].x, pk.x, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane16_swap(mxk[mi].y, pk.y, false, false);
-                    const int blk = g & 1, half = g >> 1;          // after the swap: this lane's block and 16-column half
-                    const unsigned qoff = (unsigned)((size_t)(m - m0) * N + (64 * wn + 32 * blk + 16 * half));
-                    if constexpr (EPI == 2)       // MLP hidden (MXFP8): read once by c_proj
-                        keds_store16<KEDS_ST_FP8_MX>(u32x4{s0[0], s1[0], s0[1], s1[1]}, qout + (size_t)m0 * N + n0, qoff);
-                    else                           // MXFP8 copy of the residual stream: the next GEMM's A operand
-                        keds_store16<KEDS_ST_FP8_MXR>(u32x4{s0[0], s1[0], s0[1], s1[1]}, qout + (size_t)m0 * N + n0, qoff);
-                    if (g == 0)
-                        *reinterpret_cast<unsigned short*>(qscale + mx_scale_index((n0 + 64 * wn) >> 5, m, q_pad)) =
-                            (unsigned short)((mxe[mi] + 127) | ((e + 127) << 8));
-                }
-
+                const auto s0 = __builtin_amdgcn_permlane16_swap(mxk.x, pk.x, false, false);
+                const auto s1 = __builtin_amdgcn_permlane16_swap(mxk.y, pk.y, false, false);
+                const int blk = g & 1, half = g >> 1;          // after the swap: this lane's block and 16-column half
+                const unsigned qoff = (unsigned)((size_t)(m - m0) * N + (64 * wn + 32 * blk + 16 * half));
+                if constexpr ((KEDS_FQ_ABL & 8) != 0) {
+                    if (s0[0] == 0x12345678u) qout[0] = 1;
+                } else if constexpr (EPI == 2)       // MLP hidden (MXFP8): read once by c_proj
+                    keds_store16<KEDS_ST_FP8_MX>(u32x4{s0[0], s1[0], s0[1], s1[1]}, qout + (size_t)m0 * N + n0, qoff);
+                else                           // MXFP8 copy of the residual stream: the next GEMM's A operand
+                    keds_store16<(PRE && KEDS_ST_FP8_MXR == 0) ? 8 : KEDS_ST_FP8_MXR>(u32x4{s0[0], s1[0], s0[1], s1[1]}, qout + (size_t)m0 * N + n0, qoff);
+                if (g == 0 && !(KEDS_FQ_ABL & 8))
+                    *reinterpret_cast<unsigned short*>(qscale + mx_scale_index((n0 + 64 * wn) >> 5, m, q_pad)) =
+                        (unsigned short)((mxe + 127) | ((e + 127) << 8));
             }
         }
     }
-    if constexpr ((EPI == 3 || EPI == 4) && PP1 == 2) {
-#pragma unroll
-        for (int mi = 0; mi < 8; ++mi) {
-            const int m = m0 + 128 * wm + 16 * mi + c;
-            float a = rs[mi], b2 = rss[mi];
-            a = rows_sum(a);
-            b2 = rows_sum(b2);
-            if (g == 0) keds_stat_add(reinterpret_cast<keds_stat_t*>(aux) + 2 * (size_t)m, a, b2);
+    if constexpr (EPI == 3 || EPI == 4) {
+        rs = rows_sum(rs);
+        rss = rows_sum(rss);
+        if constexpr (STAT == 4) {
+            if (g == 0) *reinterpret_cast<f32x2*>(red + (wn * 256 + 128 * wm + 16 * mi + c) * 2) = f32x2{rs, rss};
+        } else {
+            if (g == 0 && !(KEDS_FQ_ABL & 4)) keds_stat_add(reinterpret_cast<keds_stat_t*>(aux) + 2 * (size_t)m, rs, rss);
         }
+    }
+}
+// a wave's whole 128 x 64 block from acc[ni][mi] (8-wave kernel)
+template <int EPI>
+__device__ __forceinline__ void mx_epilogue(f32x4 (&acc)[4][8], const char* side, const float* __restrict__ bias, void* __restrict__ out,
+                                            int m0, int n0, int N, int wm, int wn, int g, int c, float* __restrict__ aux,
+                                            float* __restrict__ aux2, unsigned char* __restrict__ qout,
+                                            unsigned char* __restrict__ qscale, int q_pad) {
+    MxSide sd;
+    mx_side<EPI>(sd, side, bias, n0, wn, g);
+    const f16x8 none[2] = {};
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const f32x4 a4[4] = {acc[0][mi], acc[1][mi], acc[2][mi], acc[3][mi]};
+        mx_epilogue_rows<EPI>(a4, mi, sd, side, out, m0, n0, N, wm, wn, g, c, aux, aux2, qout, qscale, q_pad, none);
     }
 }
 
@@ -472,8 +500,7 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
         }
         return;
     }
-    MxCarry cy;
-    mx_epilogue<EPI>(acc, cy, smem + SIDE_OFF, bias, out, m0, n0, N, wm, wn, g, c, aux, aux2, qout, qscale, q_pad);
+    mx_epilogue<EPI>(acc, smem + SIDE_OFF, bias, out, m0, n0, N, wm, wn, g, c, aux, aux2, qout, qscale, q_pad);
 }
 
 
@@ -737,13 +764,35 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
         // K-tiles 0 | 1 | [2j, 2j + 1] | np - 2 | np - 1
         KEDS_FQ_STEP(true, xa, sxa, swa, xb, sxb, swb, 1, true, true, 2, true)
         KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, true, true, 3, true)
-        for (int p = 2; p + 2 < np; p += 2) {
+        for (int p = 2; p + 2 < np && !(KEDS_FQ_ABL & 2); p += 2) {
             KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, true, true, p + 2, true)
             KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, true, true, p + 3, true)
         }
         KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, true, false, 0, true)
         KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, false, false, 0, false)
 
+        // (the lane coordinates through an opaque move: everything the epilogue derives from them is otherwise loop invariant, and
+        // hoisted out of the tile loop it is ~60 registers the K-loop does not have)
+        int ge = g, ce = c;
+        asm volatile("" : "+v"(ge), "+v"(ce));
+        // fp16 residual epilogue: the tile's residual chunks are requested HERE, in front of the next tile's 34 DMA pieces (vmcnt
+        // retires in order: behind them a chunk waits for all of them, and loaded one by one between the stores of the epilogue --
+        // the compiler cannot move a load above a store to the same array -- each chunk pays its own round trip: a cold
+        // residual tile cost this kernel 15-20 us per launch against 5-7 for the 8-wave kernel, tools/fp8_cold_matrix.py).
+        // The fragment registers are dead by now, but all 32 chunks (128 registers) beside a read-back quarter and the carry do
+        // not fit (the allocator loaded chunks straight into accumulator AGPRs).
+        // One 64-column half (16 chunks, 64 registers) goes out here, the other right behind the next tile's requests.
+        [[maybe_unused]] f16x8 rpre[2][8][2];
+        auto resid_request = [&](int h) {               // buffer loads: tile base in SGPRs, one lane offset, a scalar per chunk
+            const auto ors = make_rs(reinterpret_cast<const f16_t*>(out) + (size_t)m0 * N + n0);
+            const int voff = ((128 * wm + ce) * N + 128 * wn2 + 8 * ge) * 2;
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+                for (int pp = 0; pp < 2; ++pp)
+                    rpre[h][mi][pp] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(ors, voff, (16 * mi * N + 64 * h + 32 * pp) * 2, 0));
+        };
+        if constexpr (EPI == 4) resid_request(0);
         if (more) {
             // every wave has issued its last fragment reads (they completed before its last step's MFMAs could start): both
             // buffers are free for the next tile's K-tiles 0, 1
@@ -757,23 +806,36 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
             for (int q = 0; q < 16; ++q) issue(1, q);
             issue_scales(1);
         }
-        // ---- epilogue: the 8-wave kernel's, once per 64-column half (its wave column 2 wn2 + h) read back from the AGPRs
+        if constexpr (EPI == 4) resid_request(1);
+        // ---- epilogue: the 8-wave kernel's (its wave column 2 wn2 + h), one row group of 16 accumulator registers at a time
         KEDS_QUAD_DRAIN
-        // (the lane coordinates through an opaque move: everything the epilogue derives from them is otherwise loop invariant, and
-        // hoisted out of the tile loop it is ~60 registers the K-loop does not have)
-        int ge = g, ce = c;
-        asm volatile("" : "+v"(ge), "+v"(ce));
-        f32x4 av[4][8];
-        MxCarry cy;
-#define KEDS_FQ_EPQ(h, p)                                                                                                \
-    KEDS_QUAD_READ_Q##h##p(av)                                                                                           \
-    mx_epilogue<EPI, p, p + 1>(av, cy, side, bias, out, m0, n0, N, wm, 2 * wn2 + h, ge, ce, aux, aux2, qout, qscale, q_pad); \
-    __builtin_amdgcn_sched_barrier(0);
-        KEDS_FQ_EPQ(0, 0)
-        KEDS_FQ_EPQ(0, 1)
-        KEDS_FQ_EPQ(1, 0)
-        KEDS_FQ_EPQ(1, 1)
-#undef KEDS_FQ_EPQ
+        constexpr bool RES = EPI == 3 || EPI == 4;      // (their row partials meet the other three wave columns' in LDS)
+        float* red = reinterpret_cast<float*>(smem + fq::SIDE0);
+        MxSide sd;
+#define KEDS_FQ_EPG(h, mi)                                                                                               \
+    {                                                                                                                    \
+        f32x4 av[4];                                                                                                     \
+        KEDS_QUAD_READ_G##h##mi(av)                                                                                      \
+        if constexpr (!(KEDS_FQ_ABL & 1))                                                                                \
+            mx_epilogue_rows<EPI, EPI == 4, RES ? 4 : 2>(av, mi, sd, side, out, m0, n0, N, wm, 2 * wn2 + h, ge, ce, aux, aux2, qout,   \
+                                                         qscale, q_pad, rpre[h][mi], red);                               \
+    }
+#define KEDS_FQ_EPH(h)                                                                                                   \
+    mx_side<EPI>(sd, side, bias, n0, 2 * wn2 + h, ge);                                                                   \
+    KEDS_FQ_EPG(h, 0) KEDS_FQ_EPG(h, 1) KEDS_FQ_EPG(h, 2) KEDS_FQ_EPG(h, 3)                                              \
+    KEDS_FQ_EPG(h, 4) KEDS_FQ_EPG(h, 5) KEDS_FQ_EPG(h, 6) KEDS_FQ_EPG(h, 7)
+        KEDS_FQ_EPH(0)
+        KEDS_FQ_EPH(1)
+#undef KEDS_FQ_EPH
+#undef KEDS_FQ_EPG
+        if constexpr (RES && !(KEDS_FQ_ABL & 1)) {      // row t: the four wave columns' partials (the side areas: unused by these epilogues)
+            __syncthreads();
+            const f32x2* rr = reinterpret_cast<const f32x2*>(red) + tid;
+            const f32x2 p0 = rr[0], p1 = rr[256], p2 = rr[512], p3 = rr[768];
+            if (!(KEDS_FQ_ABL & 4))
+                keds_stat_add(reinterpret_cast<keds_stat_t*>(aux) + 2 * (size_t)(m0 + tid), (p0[0] + p1[0]) + (p2[0] + p3[0]),
+                              (p0[1] + p1[1]) + (p2[1] + p3[1]));
+        }
         if (!more) break;
         id = nid;
         m0 = nm0;
@@ -854,11 +916,13 @@ extern "C" int keds_gemm_mxfp8_ex(const void* Aq, const void* As, int m_pad, con
     hipStream_t st = (hipStream_t)stream;
     KedsProfScope prof(KEDS_PROF_GEMM, st);
     prof.work(2.0 * M * N * K);
-    // keds_mxfp8_debug(16): the 8-wave kernel whatever the shape (the bit-identity test's reference)
+    // keds_mxfp8_debug(16): the 8-wave kernel whatever the shape (the bit-identity test's reference).  The fp32-residual epilogue
+    // (3: API only, the towers keep their stream in fp16) stays on the 8-wave kernel: beside its 256-bit residual chunks the
+    // 4-wave K-loop has no registers left
     const bool quad = g_fp8_debug == 0 && fp8_quad_enabled() && K % (2 * TKB) == 0 && K >= 4 * TKB;
 #define KEDS_FP8_GO(E, D)                                                                                                         \
     {                                                                                                                             \
-        if (quad && (D) == 0) return launch_mxfp8_quad<E>(Aq, As, m_pad, Wq, Ws, n_pad, bias, out, M, N, K, aux, aux2, qout, qscale, q_pad, st); \
+        if (quad && (D) == 0 && (E) != 3) return launch_mxfp8_quad<(E) == 3 ? 4 : (E)>(Aq, As, m_pad, Wq, Ws, n_pad, bias, out, M, N, K, aux, aux2, qout, qscale, q_pad, st); \
         return launch_mxfp8<E, D>(Aq, As, m_pad, Wq, Ws, n_pad, bias, out, M, N, K, aux, aux2, qout, qscale, q_pad, st);              \
     }
     switch (epilogue) {

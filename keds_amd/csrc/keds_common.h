@@ -154,7 +154,8 @@ __device__ __forceinline__ void keds_store16(T v, void* base, unsigned off) {
         keds_store16<POLICY - 20>(v, base, off);
         __builtin_amdgcn_sched_barrier(0);
     } else {
-        constexpr int aux = POLICY == 1 ? 2 : POLICY == 2 ? 17 : POLICY == 3 ? 18 : POLICY == 4 ? 16 : POLICY == 5 ? 19 : POLICY == 6 ? 1 : 3;
+        // (8: the plain policy as a buffer store -- uniform base in SGPRs + a 32-bit lane offset instead of a 64-bit pointer per store)
+        constexpr int aux = POLICY == 1 ? 2 : POLICY == 2 ? 17 : POLICY == 3 ? 18 : POLICY == 4 ? 16 : POLICY == 5 ? 19 : POLICY == 6 ? 1 : POLICY == 8 ? 0 : 3;
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7FFFFFFF, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)off, 0, aux);
     }

@@ -313,8 +313,8 @@ def test_text_tower_and_session_handles_in_fp8():
 def test_mxfp8_four_wave_kernel_is_bit_identical_to_the_eight_wave_kernel(epi, M, N, K):
     """The 4-wave persistent kernel (gemm_mxfp8_quad_kernel: 128 x 128 wave tiles, accumulators in fixed AGPRs, W fragments refilled
     in place, the next tile's K-tiles requested before the epilogue) against the 8-wave kernel (keds_mxfp8_debug(16)) on the same
-    operands: every output byte, scale byte and statistic equal -- per accumulator both run the same chain of block-scaled MFMAs in
-    K order and share the epilogue code.  Shapes: more tiles than CUs (the persistent walk, ragged 33-row-tile counts), K = 512 (the
+    operands: every output byte and scale byte equal (the row statistics up to the order of three fp32 additions) -- per accumulator
+    both run the same chain of block-scaled MFMAs in K order and share the epilogue code.  Shapes: more tiles than CUs (the persistent walk, ragged 33-row-tile counts), K = 512 (the
     shortest K the 4-wave form takes) ... 4096."""
     lib = _lib.load()
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
@@ -359,6 +359,13 @@ def test_mxfp8_four_wave_kernel_is_bit_identical_to_the_eight_wave_kernel(epi, M
             torch.cuda.synchronize()
         finally:
             lib.keds_mxfp8_debug(0)
-    for t8, t4 in zip(res[16], res[0]):
-        assert torch.equal(t8.view(torch.uint8), t4.view(torch.uint8))
+    for k, (t8, t4) in enumerate(zip(res[16], res[0])):
+        if epi.startswith("resid") and k == 3:
+            # row statistics: the 8-wave kernel adds four fixed-point conversions per row and tile (one per wave column), the 4-wave
+            # kernel adds the four fp32 partials in LDS and converts once: equal up to the rounding of those three fp32 additions
+            a, b = t8.double() / 2.0 ** 28, t4.double() / 2.0 ** 28
+            assert float(((a[:, 1] - b[:, 1]).abs() / a[:, 1]).max()) <= 2e-6                        # sum of squares: relative
+            assert float(((a[:, 0] - b[:, 0]).abs() / ((N * a[:, 1]).sqrt() + 1.0)).max()) <= 1e-6   # sum: against sum |x| <= sqrt(N ss)
+        else:
+            assert torch.equal(t8.view(torch.uint8), t4.view(torch.uint8))
     assert float(res[0][1 if epi == "ln_gelu" else 0].float().abs().max()) > 0.1     # (not two all-zero tensors)
