@@ -723,9 +723,20 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
     for (int q = 0; q < 16; ++q) issue(1, q);
     issue_scales(1);
 
+#ifdef KEDS_FQ_STAMP
+    // diagnostic build (tools/fp8_stamp.py; EPI 1 only: qout carries a buffer of 8 x 64-bit words per (workgroup, wave)): core-clock
+    // ticks of the phases of the workgroup's SECOND tile -- wait for its K-tiles | fragment reads of K-tile 0 | K-loop | requests of the
+    // next tile | epilogue
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+#define KEDS_FQ_TS(i) if (it == 1) ts[i] = __builtin_amdgcn_s_memtime();
+#else
+#define KEDS_FQ_TS(i)
+#endif
     for (int it = 0;; ++it) {
+        KEDS_FQ_TS(0)
         // this tile's K-tiles 0 and 1 and its raw side data have landed (requested before the previous tile's epilogue)
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        KEDS_FQ_TS(1)
         char* side = smem + fq::SIDE0 + (it & 1) * 4096;
         side_write(side);                                          // (read in the epilogue, a dozen barriers from here)
         const int nid = id + step;
@@ -762,6 +773,10 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
             }
         }
         // K-tiles 0 | 1 | [2j, 2j + 1] | np - 2 | np - 1
+#ifdef KEDS_FQ_STAMP
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+        KEDS_FQ_TS(2)
         KEDS_FQ_STEP(true, xa, sxa, swa, xb, sxb, swb, 1, true, true, 2, true)
         KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, true, true, 3, true)
         for (int p = 2; p + 2 < np && !(KEDS_FQ_ABL & 2); p += 2) {
@@ -771,6 +786,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
         KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, true, false, 0, true)
         KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, false, false, 0, false)
 
+        KEDS_FQ_TS(3)
         // (the lane coordinates through an opaque move: everything the epilogue derives from them is otherwise loop invariant, and
         // hoisted out of the tile loop it is ~60 registers the K-loop does not have)
         int ge = g, ce = c;
@@ -807,6 +823,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
             issue_scales(1);
         }
         if constexpr (EPI == 4) resid_request(1);
+        KEDS_FQ_TS(4)
         // ---- epilogue: the 8-wave kernel's (its wave column 2 wn2 + h), one row group of 16 accumulator registers at a time
         KEDS_QUAD_DRAIN
         constexpr bool RES = EPI == 3 || EPI == 4;      // (their row partials meet the other three wave columns' in LDS)
@@ -836,11 +853,23 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
                 keds_stat_add(reinterpret_cast<keds_stat_t*>(aux) + 2 * (size_t)(m0 + tid), (p0[0] + p1[0]) + (p2[0] + p3[0]),
                               (p0[1] + p1[1]) + (p2[1] + p3[1]));
         }
+#ifdef KEDS_FQ_STAMP
+        if constexpr (EPI == 1) {
+            if (it == 1) {
+                const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+                if (lane == 0 && qout) {
+                    unsigned long long* o = reinterpret_cast<unsigned long long*>(qout) + ((size_t)blockIdx.x * 4 + wave) * 8;
+                    o[0] = ts[1] - ts[0]; o[1] = ts[2] - ts[1]; o[2] = ts[3] - ts[2]; o[3] = ts[4] - ts[3]; o[4] = t5 - ts[4]; o[5] = ts[0]; o[6] = t5;
+                }
+            }
+        }
+#endif
         if (!more) break;
         id = nid;
         m0 = nm0;
         n0 = nn0;
     }
+#undef KEDS_FQ_TS
 #undef make_rs
 }
 

@@ -370,9 +370,11 @@ def test_bench_gpus_n_launches_its_own_ranks_before_touching_the_gpu():
 
 
 def test_quad_gemm_kernels_keep_their_accumulators_to_the_generated_statements():
-    """The 4-wave GEMM kernels keep 256 accumulators in fixed AGPRs that the compiler is not told about (gemm_quad_gen.h):
-    the gfx950 assembly of every instantiation must allocate exactly 256 AGPRs, touch them only in v_mfma / the 256
-    read-backs, and carry no scratch traffic in the forms the dispatcher uses (tools/check_quad_asm.py; hipcc -S, no GPU)."""
+    """The 4-wave GEMM kernels (bf16: gemm.hip, MXFP8: gemm_fp8.hip) keep 256 accumulators in fixed AGPRs that the compiler is
+    not told about (gemm_quad_gen.h, gemm_fp8_quad_gen.h): in the gfx950 assembly of every instantiation exactly 256 AGPRs are
+    allocated, the compiler touches one only between its read-back and the next tile's first MFMA on it, and there is no scratch
+    traffic inside the K-loop (tools/check_quad_asm.py; hipcc -S, no GPU).  The checker itself is tested on a doctored listing:
+    a compiler write to a live accumulator must be reported."""
     import shutil
     import subprocess
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -381,3 +383,33 @@ def test_quad_gemm_kernels_keep_their_accumulators_to_the_generated_statements()
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_quad_asm.py")], capture_output=True, text=True)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
     assert "0 problem(s)" in res.stdout
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import check_quad_asm as cq
+    finally:
+        sys.path.pop(0)
+    good = """
+\t.globl\t_Z22gemm_bt_quad_kernel_demo
+_Z22gemm_bt_quad_kernel_demo:
+\t;;#ASMSTART
+\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], 0
+\t;;#ASMEND
+\t;;#ASMSTART
+\tv_mfma_f32_16x16x32_bf16 a[0:3], v[0:3], v[4:7], a[0:3]
+\t;;#ASMEND
+%s\t;;#ASMSTART
+\tv_accvgpr_read_b32 v8, a0
+\tv_accvgpr_read_b32 v9, a1
+\tv_accvgpr_read_b32 v10, a2
+\tv_accvgpr_read_b32 v11, a3
+\t;;#ASMEND
+%s\ts_endpgm
+\t.amdhsa_accum_offset 256
+\t.amdhsa_next_free_vgpr 512
+"""
+    def problems(text):
+        return [e for e in cq.check(text)[1] if "v_accvgpr_read_b32 (expected 256" not in e]
+    assert problems(good % ("", "")) == []
+    assert problems(good % ("", "\tv_accvgpr_write_b32 a2, v20\n\tv_accvgpr_read_b32 v21, a2\n")) == []      # parked behind the read-back: fine
+    bad = problems(good % ("\tv_accvgpr_write_b32 a2, v20\n", ""))
+    assert bad and "live accumulator a2" in bad[0]
