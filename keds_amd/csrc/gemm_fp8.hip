@@ -117,6 +117,8 @@ __global__ __launch_bounds__(256) void fold_quantize_mxfp8_kernel(const float* _
 // timing-only ablations of the 4-wave kernel (tools/fp8_ablate.sh rebuilds with -DKEDS_FQ_ABL=n; results are wrong), bits:
 // 1: no epilogue (read-back only)   2: the K-loop runs its first two and last two K-tiles only
 // residual epilogues:  4: no statistics atomics   8: no MXFP8 copy / scale stores   16: no residual store   32: no residual load
+// K-loop (tools/fp8_kloop_ab.sh, with -DKEDS_FQ_STAMP):  64: no DMA pieces   128: no fragment / scale reads   256: no wait +
+//          barrier per K-tile   512: the wait without the barrier   1024: the barrier without the vmcnt wait   2048: the barrier alone
 #ifndef KEDS_FQ_ABL
 #define KEDS_FQ_ABL 0
 #endif
@@ -559,6 +561,14 @@ constexpr int LDS_BYTES = RAW + 6144;            // 146 KiB
                          : "v"(sct[(k) == 15 ? 2 : ((k) & 1)]), "v"(psel[(k) & 3]));                             \
     }
 // gap n (0..63) behind MFMA n of a step
+// (Round 4, measured and not kept.  Stamped ablations, cycles of one tile's K-loop of 8 K-tiles (profiles/r04_fp8_kloop_ablation.txt):
+// MFMAs alone 16.65 k; + fragment reads + DMA pieces 16.95 k; + the barrier 17.3 k; + `s_waitcnt vmcnt(0)` 20.7 k -- 400 cycles per
+// K-tile waiting for pieces requested less than a K-step earlier.  (a) All 17 pieces in the step's first half: 20.6 k, and 3 %
+// fewer img/s (r04_fp8_sched_ab.txt): a piece takes longer than a K-step to land.  (b) The A operand one K-tile further ahead in
+// the same two LDS buffers -- X-fragment reads in the first half of the step, a mid-step barrier, the X pieces of K-tile p + 3 in
+// the second half, a counted vmcnt(8) in front of step p + 1; bit-identical: 20.1 k cycles, the tile 37.1 k instead of 38.8 k -- and
+// on the same box qkv +2 %, c_fc +7 %, the bench -1.6 % in TIME (r04_fp8_deep_prefetch_ab.txt).  The cycles it saves are stall
+// cycles; at the power cap they are not what the time is made of.)
 #define KEDS_FQ_GAP(n_, xn, sxn, swn, nb, ISSUE, ip, PF)                                                         \
     {                                                                                                            \
         constexpr int gn_ = (n_);                                                                                \
@@ -602,10 +612,15 @@ constexpr int LDS_BYTES = RAW + 6144;            // 146 KiB
 // One K-tile: 64 MFMAs from (w, xc) with the scales (swc, sxc); the next K-tile's fragments / scales go to (w in place, xn,
 // swn, sxn) from buffer `nb`; ISSUE: the DMA pieces of K-tile `ip`; SYNC: the next K-tile has landed and its predecessor's
 // buffer is free (wait + barrier)
-#define KEDS_FQ_STEP(FIRST, xc, sxc, swc, xn, sxn, swn, nb, SYNC, ISSUE, ip, PF)                                 \
+#define KEDS_FQ_STEP(FIRST, xc, sxc, swc, xn, sxn, swn, nb, SYNC_, ISSUE_, ip, PF_)                              \
     {                                                                                                            \
+        constexpr bool SYNC = (SYNC_) && !(KEDS_FQ_ABL & 256), ISSUE = (ISSUE_) && !(KEDS_FQ_ABL & 64),          \
+                       PF = (PF_) && !(KEDS_FQ_ABL & 128);                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
-        if constexpr (SYNC) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");             \
+        if constexpr (SYNC && (KEDS_FQ_ABL & 512)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
+        else if constexpr (SYNC && (KEDS_FQ_ABL & 1024)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else if constexpr (SYNC && (KEDS_FQ_ABL & 2048)) asm volatile("s_barrier" ::: "memory");                  \
+        else if constexpr (SYNC) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         KEDS_FQ_ROW(FIRST, 0, xc, sxc, swc, xn, sxn, swn, nb, ISSUE, ip, PF)                                     \
         KEDS_FQ_ROW(FIRST, 1, xc, sxc, swc, xn, sxn, swn, nb, ISSUE, ip, PF)                                     \
