@@ -1336,7 +1336,20 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
     // 1/64 +45 us, 1/128 +75 us at 0.5 M rows: at a 0.2 % accept rate one compare in eight still takes the 16-slot insert for
     // its whole wave, which is what a larger sample buys back.)
     const bool two_phase = g_scan_phases != 1 && total_stages >= 16 * 64;
-    const int stagesA = total_stages / 16;                         // threshold pass: first 1/16 of the rows
+    // The sample: 1/16 of the rows, but at least 16 k rows (512 stages) where a quarter of the database allows it.  Round 4: at the
+    // 8-GPU shard shape (1,024 queries x 62.5 k rows) a 1/16 sample is 3.9 k rows, the accept rate 64 / 3.9 k = 1.6 % instead of
+    // the 0.2 % of the 0.5 M-row search, and with eight query blocks per launch set nothing hides the inserts: the candidate
+    // pass took 236 us of which 125 were list updates (keds_scan_debug ablations under rocprofv3).  Whole search at that shape with
+    // 1/16, 1/8, 1/6, 1/4, 1/3 of the rows sampled: 342, 301, 294, 292, 299 us; the 0.5 M-row search is unchanged (its 1/16 is 31 k
+    // rows).  KEDS_SCAN_SAMPLE_DIV=<d> forces 1/d (A/B).
+    static int sample_div = -1;
+    if (sample_div < 0) {
+        const char* e = getenv("KEDS_SCAN_SAMPLE_DIV");
+        sample_div = e && atoi(e) >= 2 ? atoi(e) : 0;
+    }
+    int stagesA = total_stages / 16;
+    if (sample_div) stagesA = total_stages / sample_div;
+    else if (stagesA < 512) stagesA = total_stages / 4 < 512 ? total_stages / 4 : 512;
     int rc;
     // Up to MAXQB query blocks (1024 queries) share one set of launches: grid.y = query block, and the `cus`
     // workgroups are divided between the blocks, each block's workgroups splitting the stage range.  A row-sharded
