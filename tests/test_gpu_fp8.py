@@ -309,7 +309,7 @@ def test_text_tower_and_session_handles_in_fp8():
 
 @pytest.mark.parametrize("epi,M,N,K", [("bias", 8448, 1024, 1024), ("ln", 8448, 3072, 1024), ("ln_gelu", 8192, 4096, 1024),
                                        ("resid_h", 8448, 1024, 4096), ("resid_h", 8448, 1024, 1024), ("resid", 4352, 1024, 512),
-                                       ("ln", 512, 768, 768)])
+                                       ("ln", 512, 768, 768), ("resid_h", 1280, 1024, 512), ("ln_gelu", 768, 512, 512), ("bias", 65792, 256, 3072)])
 def test_mxfp8_four_wave_kernel_is_bit_identical_to_the_eight_wave_kernel(epi, M, N, K):
     """The 4-wave persistent kernel (gemm_mxfp8_quad_kernel: 128 x 128 wave tiles, accumulators in fixed AGPRs, W fragments refilled
     in place, the next tile's K-tiles requested before the epilogue) against the 8-wave kernel (keds_mxfp8_debug(16)) on the same
