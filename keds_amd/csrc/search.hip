@@ -127,18 +127,29 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
     // make sure the query loads are consumed before any LDS-DMA is counted on vmcnt
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
+    // LDS-DMA in its BUFFER form (round 4).  As `__builtin_amdgcn_global_load_lds` (FLAT encoding) the requests inside the stage
+    // loop made the compiler's wait-count pass treat every LDS wait of the loop as possibly out of order: all 31 waits between the
+    // fragment reads and their MFMAs were `s_waitcnt lgkmcnt(0)` -- each MFMA waited for every read in flight, also those of the
+    // MFMAs behind it.  With buffer instructions the waits are counted.  The descriptor's base is this workgroup's first stage
+    // (uniform), offsets are 32-bit: a workgroup's stage range stays far below 4 GiB.
+    // (KEYB_ / STAGEB_ as LOCAL constants: with the class template's static member `C::KEYB` written inside the builtin's argument
+    // list hipcc 7.2 drops this kernel's host-side stub without a diagnostic -- every instantiation links as an undefined symbol.)
+    constexpr int KEYB_ = C::KEYB, STAGEB_ = C::STAGEB, LDS_STAGE_ = C::LDS_STAGE;
+    auto krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(packed + (size_t)s0 * STAGEB_)), 0, 0x7FFFFFFF,
+                                                 0x00020000);
+    const int voff = lane * 16;
     auto issue = [&](int stage, int slot) {
-        const char* src = packed + (size_t)stage * C::STAGEB + lane * 16;
-        char* dst = smem + slot * C::LDS_STAGE;
+        const int so = (stage - s0) * STAGEB_;
+        char* dst = smem + slot * LDS_STAGE_;
 #pragma unroll
         for (int i = 0; i < C::PPW; ++i) {
             const int piece = wave + 8 * i;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + piece * 1024),
-                                             (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, voff,
+                                                     so + piece * 1024, 0, NT ? 2 : 0);
         }
         if (lane < 8) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + C::KEYB),
-                                             (__attribute__((address_space(3))) void*)(dst + C::KEYB + wave * 128), 16, 0, NT ? 2 : 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, (__attribute__((address_space(3))) void*)(dst + KEYB_ + wave * 128), 16, voff,
+                                                     so + KEYB_, 0, NT ? 2 : 0);
         }
     };
 
