@@ -532,16 +532,20 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     const int g = lane >> 4, c = lane & 15;
 
     // ---- staging addresses: wave w stages LDS rows [32w, 32w+32) of both tiles, 8 rows per DMA
+    // (LDS-DMA in its buffer form, round 4: uniform tile bases in descriptors + 32-bit lane offsets.  With the FLAT-encoded
+    // global_load_lds inside the K-loop the compiler's wait-count pass treated every LDS wait of the loop as out of order -- all of
+    // them `lgkmcnt(0)`, each MFMA group waiting for every fragment read in flight; cf. search.hip / gemm_fp8.hip.)
     const int srow = lane >> 3, sslot = lane & 7;
-    const char* xsrc[4];
-    const char* wsrc[4];
+    auto xrs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(X + (size_t)m0 * lda)), 0, 0x7FFFFFFF, 0x00020000);
+    auto wrs_ = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(W + (size_t)n0 * K)), 0, 0x7FFFFFFF, 0x00020000);
+    int xsrc[4], wsrc[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int R = 32 * wave + 8 * i + srow;
         const int ch = sslot ^ swz_f(R);
-        const int xr = m0 + R < M ? m0 + R : M - 1;     // rows past M re-read row M-1 (results discarded): A needs no padding
-        xsrc[i] = reinterpret_cast<const char*>(X + (size_t)xr * lda) + ch * 16;
-        wsrc[i] = reinterpret_cast<const char*>(W + (size_t)(n0 + perm_w(R)) * K) + ch * 16;
+        const int xr = m0 + R < M ? R : M - 1 - m0;      // rows past M re-read row M-1 (results discarded): A needs no padding
+        xsrc[i] = (int)((long long)xr * lda * 2) + ch * 16;
+        wsrc[i] = perm_w(R) * K * 2 + ch * 16;
     }
     auto stage = [&](int buf, int kt) {
         char* xb = smem + buf * BUF_BYTES + (32 * wave) * 128;
@@ -549,10 +553,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
         const int koff = (k_begin + kt * BK) * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[i] + koff),
-                                             (__attribute__((address_space(3))) void*)(wb + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs_, (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, xsrc[i], koff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs_, (__attribute__((address_space(3))) void*)(wb + i * 1024), 16, wsrc[i], koff, 0, 0);
         }
     };
 
