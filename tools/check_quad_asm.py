@@ -22,9 +22,6 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-# <EPI, STAMP, PERSIST> instantiations that are A/B or stamped diagnostic variants, never chosen by quad_by_shape: they may spill
-ALLOW_SCRATCH = (re.compile(r"gemm_bt_quad_kernelILi9ELi0ELi1E"),)     # persistent residual form (measured, not dispatched)
-
 
 def kernels(asm: str):
     for chunk in re.split(r"\n\s*\.globl\s+", asm)[1:]:
