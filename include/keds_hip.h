@@ -30,9 +30,12 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 6
+#define KEDS_ABI_VERSION 7
 
 int keds_abi_version(void);
+/* compiler flags of this build beyond the Makefile's defaults ("" for the product build; `make EXTRA="-D..."` variants of the
+ * A/B and timing-only scripts record theirs here, and the evidence digest of keds_amd/_lib.py includes it) */
+const char* keds_build_flags(void);
 const char* keds_last_error(void);
 
 /* ---- numerics guard of the fast tower flow ---------------------------------------------------------------------
@@ -258,6 +261,10 @@ int keds_gemm_set_workspace(void* ptr, size_t bytes);
  * value, bits 11-12 kernel form (1 = 4 waves, 2 = 4 waves persistent, 3 = 8 waves; 0 = by shape), bits 13-15 stamped
  * diagnostic build, bit 16 no three-deep A ring, bit 17 no deferred epilogue stores in the persistent kernel */
 int keds_gemm_force_small(int on);
+/* The 256 x 256 GEMMs with LayerNorm-folded fp16-operand epilogues (in_proj, c_fc) on the two-accumulator-set kernel (round 5,
+ * csrc/gemm_duo.hip: the epilogue of one 128 x 256 unit runs in the gaps between the next unit's MFMAs): 1 on, 0 off (the
+ * round-4 kernels), -1 = the KEDS_GEMM_DUO environment variable decides (default on).  Same bits either way. */
+int keds_gemm_duo_enable(int on);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (fp32 statistics, eps 1e-5).
  * x fp32 [rows, dim] with row stride x_stride (elements); out bf16 (out_f32 == 0) or fp32,
@@ -406,6 +413,19 @@ size_t keds_text_workspace_bytes(const keds_text_params* p, int B);
 int keds_text_run(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
                       const float* img_tokens, int n_tok, int insert_col, int B, float* out, int normalize,
                       void* workspace, size_t workspace_bytes, void* stream);
+/* The same with the host's knowledge of the read-out columns (ABI 7).  The mask is causal (model.py:543-549) and only the
+ * read-out row of every sample is read (model.py:587-589, 847-849), so columns >= seq_used = max(readout_row) + 1 cannot
+ * change the result: they are neither embedded nor run through the blocks (the sequence is cut there), and the last block's
+ * out-proj / ln_2 / MLP run on the B read-out rows only.  seq_used = 0: unknown (all L columns; keds_text_run).  CONTRACT: every readout_row[b] < seq_used -- the rows live on
+ * the device and are not checked.  keds_text_trim_enable(0) restores the all-columns / all-rows flow (A/B, bisecting), 2 =
+ * the column cut only, 3 = the read-out-row tail only; -1 = the KEDS_TEXT_TRIM environment variable decides (default: on).
+ * Numerics: the column cut changes no arithmetic (rows only land in other tiles); the tail runs the last block's out-proj /
+ * ln_2 / MLP in the fp32-stream form (stand-alone LayerNorm, fp32 residual, as the ViT's CLS tail does) where the all-rows
+ * flow uses the folded form on the fp16 stream: both are roundings of the same fp32 reference, 2-3e-3 apart. */
+int keds_text_run_ex(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
+                     const float* img_tokens, int n_tok, int insert_col, int B, int seq_used, float* out, int normalize,
+                     void* workspace, size_t workspace_bytes, void* stream);
+int keds_text_trim_enable(int on);
 
 /* =====================================================================================
  * 4. Knowledge injection (IM2TEXT + 2 x CrossFormer, model.py:37-123, eval_utils.py:661-672)

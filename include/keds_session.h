@@ -70,6 +70,11 @@ int keds_text_info(const keds_text* txt, int* width, int* layers, int* context, 
  * row that is projected (EOT column, + n_img_tok - 1 after a splice, model.py:847-850). */
 int keds_text_forward(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
                       int insert_idx, const int32_t* readout_idx, int B, void* out, void* stream);
+/* the same when the HOST knows the read-out rows (it usually does: they come from the token ids): seq_used = max(readout_idx) + 1
+ * lets the tower skip the columns behind it (causal mask: they cannot reach a read-out; keds_text_run_ex, keds_hip.h);
+ * 0 = unknown.  Every readout_idx[b] must be < seq_used. */
+int keds_text_forward_used(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
+                           int insert_idx, const int32_t* readout_idx, int seq_used, int B, void* out, void* stream);
 
 /* ---- knowledge injection of ONE stream: IM2TEXT keys (layers.{i}.0.{weight,bias}, fc_out.*) and two
  *      CrossFormers (cross_layers.{i}.to_{q,k,v}.*, to_out.0.*): retrieval_fuse, text_condition ---- */

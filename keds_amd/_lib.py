@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 
 # ---- constants mirrored from keds_hip.h ------------------------------------------------------
-ABI_VERSION = 6
+ABI_VERSION = 7
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
@@ -99,6 +99,7 @@ SIGNATURES = {
     "keds_text_destroy": (i32, [vp]),
     "keds_text_info": (i32, [vp] + [C.POINTER(i32)] * 5),
     "keds_text_forward": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, vp]),
+    "keds_text_forward_used": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
     "keds_knowledge_create": (i32, [vp, C.POINTER(Tensor), i32, C.POINTER(Tensor), i32, C.POINTER(Tensor), i32, pp]),
     "keds_knowledge_destroy": (i32, [vp]),
     "keds_knowledge_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),
@@ -114,6 +115,7 @@ SIGNATURES = {
     "keds_index_search_sharded": (i32, [vp, vp, i32, i32, vp, vp, vp, vp]),
     # ---- keds_hip.h (stateless) -----------------------------------------------------------------
     "keds_abi_version": (i32, []),
+    "keds_build_flags": (C.c_char_p, []),
     "keds_last_error": (C.c_char_p, []),
     "keds_numerics_guard_set": (i32, [vp]),
     # ---- training building blocks (keds_hip.h section 9) ------------------------------------------
@@ -159,6 +161,7 @@ SIGNATURES = {
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "keds_gemm_set_workspace": (i32, [vp, sz]),
     "keds_gemm_force_small": (i32, [i32]),
+    "keds_gemm_duo_enable": (i32, [i32]),
     "keds_gemm_bt_ex2": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp]),
     "keds_fold_layernorm": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "keds_rowstats_cast": (i32, [vp, vp, vp, i32, i32, vp]),
@@ -206,6 +209,8 @@ SIGNATURES = {
     "keds_vit_run": (i32, [C.POINTER(VitParams), vp, i32, vp, i32, vp, sz, vp]),
     "keds_text_workspace_bytes": (sz, [C.POINTER(TextParams), i32]),
     "keds_text_run": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "keds_text_run_ex": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "keds_text_trim_enable": (i32, [i32]),
     "keds_im2text_workspace_bytes": (sz, [C.POINTER(Im2TextParams), i32]),
     "keds_im2text_forward": (i32, [C.POINTER(Im2TextParams), vp, i32, vp, vp, sz, vp]),
     "keds_crossformer_workspace_bytes": (sz, [C.POINTER(CrossFormerParams), i32, i32]),
@@ -265,6 +270,13 @@ def source_digest() -> str:
         h.update(os.path.relpath(f, os.path.dirname(_HERE)).encode())
         with open(f, "rb") as fh:
             h.update(fh.read())
+    # a variant build (make EXTRA="-D...": A/B and timing-only scripts) is a different build of the same sources
+    try:
+        extra = (load().keds_build_flags() or b"").decode().strip()
+    except Exception:                                                 # noqa: BLE001  (no library: the sources alone)
+        extra = ""
+    if extra:
+        h.update(b"EXTRA " + extra.encode())
     return h.hexdigest()[:16]
 
 

@@ -145,6 +145,33 @@ __global__ __launch_bounds__(256) void cast_rows_f16_f32_kernel(const f16_t* __r
     *reinterpret_cast<f32x4*>(o + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
 }
 
+// one row per sample out of a [B, S, dim] stream into a compact [B, dim] buffer: dst[b] = src[b * S + row[b]]
+// (the read-out rows of the text tower, model.py:587-589, 847-849: the last block runs on them only).
+// MODE 0: 16-bit elements copied; 1: fp16 -> fp32; 2: fp32 copied.  One thread per 8 elements.
+template <int MODE>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const void* __restrict__ src, void* __restrict__ dst,
+                                                          const int* __restrict__ row, int S, int B, int dim) {
+    const int per_row = dim >> 3;
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= B * per_row) return;
+    const int b = id / per_row, i = (id - b * per_row) << 3;
+    const size_t so = ((size_t)b * S + row[b]) * dim + i, d_o = (size_t)b * dim + i;
+    if constexpr (MODE == 0) {
+        *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(dst) + d_o) =
+            *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(src) + so);
+    } else if constexpr (MODE == 1) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16_t*>(src) + so);
+        float* o = reinterpret_cast<float*>(dst) + d_o;
+        *reinterpret_cast<f32x4*>(o) = f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        *reinterpret_cast<f32x4*>(o + 4) = f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+    } else {
+        const float* q = reinterpret_cast<const float*>(src) + so;
+        float* o = reinterpret_cast<float*>(dst) + d_o;
+        *reinterpret_cast<f32x4*>(o) = *reinterpret_cast<const f32x4*>(q);
+        *reinterpret_cast<f32x4*>(o + 4) = *reinterpret_cast<const f32x4*>(q + 4);
+    }
+}
+
 // ---- image preprocessing (src/model/clip.py:107-123 `_transform`, eval branch) on raw uint8 images ------------------
 // Resize(n_px, bicubic) on the shorter side + CenterCrop(n_px) + ToTensor + Normalize, as PIL / torchvision do them:
 // PIL resamples uint8 images in two separable passes (horizontal, then vertical), each with antialiasing support
@@ -314,8 +341,10 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict
                                                            const float* __restrict__ table,
                                                            const float* __restrict__ pos,
                                                            const float* __restrict__ img_tokens, int n_tok,
-                                                           int insert_col, float* __restrict__ x, int L, int d) {
-    const int b = blockIdx.x / L, t = blockIdx.x % L;
+                                                           int insert_col, float* __restrict__ x, int L, int Lx, int d) {
+    // Lx <= L: only the first Lx columns of every sequence are written, x is [B, Lx, d] (keds_text_run_ex: columns that
+    // cannot reach the read-out under the causal mask are never embedded)
+    const int b = blockIdx.x / Lx, t = blockIdx.x % Lx;
     const float* src;
     if (img_tokens && t >= insert_col && t < insert_col + n_tok) {
         src = img_tokens + ((size_t)b * n_tok + (t - insert_col)) * d;
@@ -324,7 +353,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict
         src = table + (size_t)tokens[(size_t)b * L + col] * d;
     }
     const float* pe = pos + (size_t)t * d;
-    float* o = x + ((size_t)b * L + t) * d;
+    float* o = x + ((size_t)b * Lx + t) * d;
     for (int i = threadIdx.x * 4; i < d; i += 1024)
         *reinterpret_cast<f32x4*>(o + i) =
             *reinterpret_cast<const f32x4*>(src + i) + *reinterpret_cast<const f32x4*>(pe + i);
@@ -430,17 +459,26 @@ int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int 
     return keds_check_launch("cls_rows_kernel");
 }
 
+int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
+                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream);
+
 extern "C" int keds_embed_tokens(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
                                  int n_tok, int insert_col, float* x, int B, int L, int d, void* stream) {
-    KEDS_REQUIRE(tokens && table && pos && x && B > 0 && L > 0, "keds_embed_tokens: bad argument");
+    return keds_embed_tokens_impl(tokens, table, pos, img_tokens, n_tok, insert_col, x, B, L, L, d, stream);
+}
+
+// the first Lx columns only (x: [B, Lx, d]); a splice that reaches beyond Lx is cut there, like the context cut at L
+int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
+                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream) {
+    KEDS_REQUIRE(tokens && table && pos && x && B > 0 && L > 0 && Lx > 0 && Lx <= L, "keds_embed_tokens: bad argument");
     KEDS_REQUIRE(d % 4 == 0, "keds_embed_tokens: d must be a multiple of 4");
     if (img_tokens) {
         KEDS_REQUIRE(n_tok >= 1 && insert_col >= 0 && insert_col + n_tok <= L,
                      "keds_embed_tokens: splice [%d,%d) outside the context of %d", insert_col, insert_col + n_tok, L);
     }
     KedsProfScope prof(KEDS_PROF_OTHER, (hipStream_t)stream);
-    embed_tokens_kernel<<<B * L, 256, 0, (hipStream_t)stream>>>(tokens, table, pos, img_tokens, n_tok, insert_col, x, L,
-                                                                 d);
+    embed_tokens_kernel<<<B * Lx, 256, 0, (hipStream_t)stream>>>(tokens, table, pos, img_tokens, n_tok, insert_col, x, L,
+                                                                  Lx, d);
     return keds_check_launch("embed_tokens_kernel");
 }
 
@@ -513,6 +551,16 @@ int keds_cast_rows_f16_f32_impl(const void* x16, float* x32, int rows, int dim, 
     const long long threads = (long long)rows * (dim / 8);
     cast_rows_f16_f32_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>((const f16_t*)x16, x32, rows, dim, stride);
     return keds_check_launch("cast_rows_f16_f32_kernel");
+}
+
+int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st) {
+    KEDS_REQUIRE(src && dst && row && S > 0 && B > 0 && dim % 8 == 0 && mode >= 0 && mode <= 2, "gather_rows: bad argument");
+    KedsProfScope prof(KEDS_PROF_OTHER, st);
+    const unsigned grid = (unsigned)((B * (dim / 8) + 255) / 256);
+    if (mode == 0) gather_rows_kernel<0><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim);
+    else if (mode == 1) gather_rows_kernel<1><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim);
+    else gather_rows_kernel<2><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim);
+    return keds_check_launch("gather_rows_kernel");
 }
 
 extern "C" int keds_fold_layernorm_ex(const float* W, const float* bias, const float* gamma, const float* beta, int N, int K,

@@ -326,7 +326,10 @@ size_t keds_tower_f32_workspace_bytes(int width, int seq, int B) {
            keds_align_up(M * (size_t)width * 4 * 4, 256);
 }
 
-int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st) {
+int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st);
+
+// last_rows (device int32 [B], nullable): towers.hip, rows_tail -- the text tower's read-out rows; on return x[b] = that row
+int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows) {
     const int w = p->width, S = p->seq, M = B * S;
     const size_t Mp = keds_align_up((size_t)M, 256);
     char* base = (char*)ws;
@@ -342,6 +345,24 @@ int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws
                     *proj_w = (const float*)k.proj_w;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, ln, 1, M, w, st))) return rc;
         if ((rc = keds_gemm_f32(ln, w, qkv_w, k.qkv_b, qkv, 3 * w, M, 3 * w, w, F32_EPI_BIAS, nullptr, 0, st))) return rc;
+        if (last && last_rows) {
+            // after the last block only the read-out row of every sample is read (model.py:587-589, 847-849): attention on all
+            // rows, then out-proj, ln_2 and the MLP on the B gathered rows (compact [B, w] buffers in the qkv buffer)
+            if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
+            float* att_c = qkv;
+            float* x_c = qkv + (size_t)B * w;
+            if ((rc = keds_gather_rows_impl(att, att_c, last_rows, S, B, w, 2, st))) return rc;
+            if ((rc = keds_gather_rows_impl(x, x_c, last_rows, S, B, w, 2, st))) return rc;
+            if ((rc = keds_gemm_f32(att_c, w, out_w, k.out_b, x_c, w, B, w, w, F32_EPI_RESID, nullptr, 0, st))) return rc;
+            if ((rc = keds_layernorm_impl(x_c, w, nullptr, 1, k.ln2_g, k.ln2_b, ln, 1, B, w, st))) return rc;
+            if ((rc = keds_gemm_f32(ln, w, fc_w, k.fc_b, hid, 4 * w, B, 4 * w, w, F32_EPI_QGELU, nullptr, 0, st))) return rc;
+            if ((rc = keds_gemm_f32(hid, 4 * w, proj_w, k.proj_b, x_c, w, B, w, 4 * w, F32_EPI_RESID, nullptr, 0, st))) return rc;
+            if (hipMemcpyAsync(x, x_c, (size_t)B * w * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                keds_set_error("keds_tower_forward_f32: read-out rows: %s", hipGetErrorString(hipGetLastError()));
+                return KEDS_E_LAUNCH;
+            }
+            return KEDS_OK;
+        }
         if (last && p->last_cls_only) {
             // after the last block only token 0 of every sample is read (model.py:412): its attention query, out-proj, ln_2
             // and MLP run on those B rows (row stride S*w in x / att)

@@ -12,25 +12,23 @@
 #include "keds_common.h"
 #include <math.h>
 #include <cstdlib>
+#include "gemm_shared.h"
 #include "gemm_quad_gen.h"
+// gemm_duo.hip: the two-accumulator-set kernel (LayerNorm-folded epilogues under the next unit's MFMAs)
+bool keds_gemm_duo_ok(int epi, int M, int N, int K);
+int keds_gemm_duo_launch(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
+                         void* aux2, hipStream_t st);
+
+#ifndef KEDS_QUAD_NOEPI
+#define KEDS_QUAD_NOEPI 0
+#endif
 
 namespace {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;        // 16 KiB per operand tile
 constexpr int BUF_BYTES = 2 * TILE_BYTES;       // X tile + W tile
 
-// LDS row r (128 bytes = 8 chunks of 16 B): chunk c is stored at slot c ^ f(r)
-__device__ __forceinline__ int swz_f(int row) { return (row >> 1) & 7; }
-
-// LDS row R (0..127) of the W tile holds W row n0 + perm_w(R): with i = R&15 (MFMA row), g = i>>2,
-// r = i&3, tile t = R>>4: n = 64*(t>>2) + 32*((t>>1)&1) + 8*g + 4*(t&1) + r, so the accumulator
-// registers of tiles (2p, 2p+1) of one lane are 8 consecutive output columns.
-__device__ __forceinline__ int perm_w(int R) {
-    const int t = R >> 4, i = R & 15;
-    return 64 * (t >> 2) + 32 * ((t >> 1) & 1) + 8 * (i >> 2) + 4 * (t & 1) + (i & 3);
-}
 
 // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702*log2(e)*x)); v_exp_f32 + v_rcp_f32 (1 ulp-level, then rounded to bf16)
 __device__ __forceinline__ float qgelu(float x) {
@@ -87,14 +85,6 @@ __device__ __forceinline__ void epilogue_store(f32x4 v0, f32x4 v1, void* __restr
     }
 }
 
-// KEDS_EPI_LN_*_H: the same epilogues with fp16 operands (A = the fp16 residual stream, W' folded to fp16)
-constexpr bool epi_f16(int e) { return e == KEDS_EPI_LN_BIAS_BF16_H || e == KEDS_EPI_LN_QGELU_BF16_H; }
-constexpr bool epi_is_ln(int e) { return e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_QGELU_BF16 || epi_f16(e); }
-constexpr int epi_base(int e) {
-    return (e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_BIAS_BF16_H)     ? KEDS_EPI_BIAS_BF16
-           : (e == KEDS_EPI_LN_QGELU_BF16 || e == KEDS_EPI_LN_QGELU_BF16_H) ? KEDS_EPI_BIAS_QGELU_BF16
-                                                                            : e;
-}
 // one 16x16x32 MFMA on fragments staged as raw 16-byte chunks: bf16 or fp16 operands, fp32 accumulate (same rate)
 template <bool F16>
 __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
@@ -103,17 +93,8 @@ __device__ __forceinline__ f32x4 mma(bf16x8 a, bf16x8 b, f32x4 c) {
     else
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 }
-constexpr float LN_EPS = 1e-5f;
 
 // LayerNorm statistics of row m from {sum, sum of squares}: returns (rstd, -mean * rstd)
-// Numerics guard of the folded-LayerNorm flow (keds_hip.h, keds_numerics_guard): the GEMM multiplies UN-centred rows, so
-// operand rounding is amplified by |row mean| / row std = |nmr| (rel-L2 4.8e-3 at 20, 1.8e-2 at 100),
-// and an fp16 residual stream that overflowed shows up as non-finite statistics.  Either raises the caller's flag; the
-// host then re-runs the pass on the fp32-stream flow with stand-alone LayerNorm.
-constexpr float GUARD_MAX_MEAN_OVER_STD = 32.0f;
-__device__ __forceinline__ void guard_check(int* __restrict__ guard, float nmr) {
-    if (guard && !(fabsf(nmr) <= GUARD_MAX_MEAN_OVER_STD)) *guard = 1;       // NaN / inf fail the comparison too
-}
 
 __device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats_, int m, float invk, float& rstd, float& nmr,
                                              int* __restrict__ guard = nullptr) {
@@ -126,14 +107,6 @@ __device__ __forceinline__ void ln_row_coeff(const float* __restrict__ stats_, i
     guard_check(guard, nmr);
 }
 
-__device__ __forceinline__ void ln_coeff_from(keds_stat_t s_fixed, keds_stat_t ss_fixed, float invk, float& rstd, float& nmr,
-                                              int* __restrict__ guard = nullptr) {
-    const float mean = keds_stat_value(s_fixed) * invk;
-    const float var = fmaxf(keds_stat_value(ss_fixed) * invk - mean * mean, 0.f);
-    rstd = rsqrtf(var + LN_EPS);
-    nmr = -mean * rstd;
-    guard_check(guard, nmr);
-}
 
 __device__ __forceinline__ float sum8(f32x4 a, f32x4 b) { return ((a[0] + a[1]) + (a[2] + a[3])) + ((b[0] + b[1]) + (b[2] + b[3])); }
 
@@ -1151,6 +1124,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 #ifndef KEDS_QUAD_ORDER
 #define KEDS_QUAD_ORDER 1
 #endif
+// TIMING ONLY (tools/r05_noepi_bound.sh): KEDS_QUAD_FILL plain + KEDS_QUAD_FILLX transcendental vector instructions in EVERY gap
+// of the K-loop -- how much epilogue arithmetic the gaps between the MFMA pairs can carry before the K-tile grows
+#ifndef KEDS_QUAD_FILL
+#define KEDS_QUAD_FILL 0
+#endif
+#ifndef KEDS_QUAD_FILLX
+#define KEDS_QUAD_FILLX 0
+#endif
+#if KEDS_QUAD_FILL || KEDS_QUAD_FILLX
+#define KEDS_QUAD_FILLER                                                                                       \
+    _Pragma("unroll") for (int f_ = 0; f_ < KEDS_QUAD_FILL; ++f_) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(fill_v[f_ & 3])); \
+    _Pragma("unroll") for (int f_ = 0; f_ < KEDS_QUAD_FILLX; ++f_) asm volatile("v_exp_f32 %0, %0" : "+v"(fill_v[4 + (f_ & 1)]));
+#else
+#define KEDS_QUAD_FILLER
+#endif
 #define KEDS_QMFMA(FIRST, j, mi, wc, xc)                                                                       \
     if constexpr (FIRST) {                                                                                     \
         if constexpr (epi_f16(EPI)) { KEDS_QUAD_MFMAZ_##j##_##mi("v_mfma_f32_16x16x32_f16", wc[j], xc[mi]) }   \
@@ -1180,6 +1168,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     } else if constexpr (PREFETCH && (n_) < 16 && !(DBG & 2)) {                                                \
         KEDS_QRD(n_, xn, wn_, nb, nslot)                                                                       \
     }                                                                                                          \
+    KEDS_QUAD_FILLER                                                                                           \
     __builtin_amdgcn_sched_barrier(0);
 #define KEDS_QUAD_GROUP(FIRST, mi, xc, wc, xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)                            \
     KEDS_QG2(FIRST, mi, 0, 1, wc, xc) KEDS_QGAP(4 * (mi), xn, wn_, nb, nslot, ISSUE, ip, PREFETCH)             \
@@ -1286,6 +1275,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     const int wrow = OP_BYTES + (128 * wn2 + c) * 128;             // + j * 2048, j = 4 h + ni
     const int np = K / TK;                                         // >= 2
     const int step = PERSIST ? (int)gridDim.x : ntiles;            // (not persistent: one tile per workgroup)
+    [[maybe_unused]] float fill_v[6] = {1.f + K, 2.f, 3.f, 4.f, 0.5f, 0.25f};   // (KEDS_QUAD_FILLER)
 
     // side data of a tile: row t's LayerNorm statistics and column t's bias' / column sum (LN epilogues), column t's bias
     // (residual epilogue), one element per thread, requested with inline-asm loads (the compiler would wait vmcnt(0) for a
@@ -1430,6 +1420,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         [[maybe_unused]] const bool defer_now = more && aux_i != 0 && np >= 8;
         [[maybe_unused]] void* stamp_out = aux2;
         void* aux2e = STAMP ? nullptr : aux2;                             // (stamped build: aux2 carries the stamp buffer)
+#if KEDS_QUAD_NOEPI   // TIMING ONLY (-DKEDS_QUAD_NOEPI=1, tools/r05_noepi_bound.sh): no read-back, no epilogue arithmetic, no stores
+        if (more) { id = nid; m0 = nm0; n0 = nn0; side_write(smem + qd::SIDE0 + ((it + 1) & 1) * 4096, n0);
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); continue; }
+        break;
+#endif
         KEDS_QUAD_DRAIN
         f32x4 av[4][8];
         [[maybe_unused]] keds_stat_t* stats = reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux));
@@ -1557,6 +1552,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __r
     const int xrow = (128 * wm + c) * 128;                              // relative to an A buffer
     const int wrow0 = (128 * wn2 + c) * 128;                            // relative to a W buffer
     const int np = K / TK;                                              // >= 4 (the launcher checks)
+    [[maybe_unused]] float fill_v[6] = {1.f + K, 2.f, 3.f, 4.f, 0.5f, 0.25f};   // (KEDS_QUAD_FILLER)
     float pb = 0.f;
     if (bias) {
         const float* bp = bias + n0 + tid;
@@ -1624,6 +1620,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __r
     }
     // every wave has read its last fragments: the W ring becomes bias slice (side + 2048) and statistics scratch
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#if KEDS_QUAD_NOEPI   // TIMING ONLY: see gemm_bt_quad_kernel
+    if (np > 0) return;
+#endif
     char* side = smem + WRING;
     char* red = smem + WRING + 8192;
     *reinterpret_cast<float*>(side + 2048 + tid * 4) = pb;
@@ -1651,6 +1650,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad3_kernel(const bf16_t* __r
 #undef KEDS_QGAP
 #undef KEDS_QRD
 #undef KEDS_QMFMA
+#undef KEDS_QUAD_FILLER
 
 // NOTE (measured twice in round 1): a PERSISTENT form of this kernel does not pay.  Second attempt, with the fp16 residual
 // stream and the LDS-staged LN epilogue in place: one workgroup per CU walks its tiles; before the LAST K-step of a tile
@@ -1754,6 +1754,11 @@ int g_pair_stamp = 0;     // diagnostic: stamped build of the qkv instantiation 
 template <int EPI>
 int launch_big(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                int aux_i, void* aux2, hipStream_t st) {
+    if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_LN_QGELU_BF16_H) {
+        // (a forced kernel form -- keds_gemm_force_small bits 11-15, KEDS_GEMM_QUAD -- keeps the round-4 kernels: A/B tools)
+        if (g_quad < 0 && quad_env() < 0 && !g_pair_stamp && keds_gemm_duo_ok(EPI, M, N, K))
+            return keds_gemm_duo_launch(EPI, A, W, bias, out, M, N, K, aux, aux2, st);
+    }
     if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
     if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_RESID_STATS_F16) {
         if (g_pair_stamp && g_quad > 0) {                            // stamped build of the 4-wave kernel

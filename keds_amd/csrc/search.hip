@@ -131,7 +131,8 @@ __global__ __launch_bounds__(SCAN_THREADS, 2) void scan_topk_kernel(
     // loop made the compiler's wait-count pass treat every LDS wait of the loop as possibly out of order: all 31 waits between the
     // fragment reads and their MFMAs were `s_waitcnt lgkmcnt(0)` -- each MFMA waited for every read in flight, also those of the
     // MFMAs behind it.  With buffer instructions the waits are counted.  The descriptor's base is this workgroup's first stage
-    // (uniform), offsets are 32-bit: a workgroup's stage range stays far below 4 GiB.
+    // (uniform), offsets are SIGNED 32-bit and the descriptor covers 2 GiB: launch_scan refuses a launch whose per-workgroup stage
+    // span reaches that (a 768-wide index above ~40 M rows scanned by ~32 workgroups per query block).
     // (KEYB_ / STAGEB_ as LOCAL constants: with the class template's static member `C::KEYB` written inside the builtin's argument
     // list hipcc 7.2 drops this kernel's host-side stub without a diagnostic -- every instantiation links as an undefined symbol.)
     constexpr int KEYB_ = C::KEYB, STAGEB_ = C::STAGEB, LDS_STAGE_ = C::LDS_STAGE;
@@ -1182,7 +1183,7 @@ int g_scan_phases = 0;  // test hook: 1 forces the single-phase scan (no thresho
 int g_force_exact = 0;  // test hook: 1 sends every query through the exact fallback
 int g_scan_nt = 1;      // non-temporal LDS-DMA for the D = 768 candidate pass (A/B hook: keds_scan_debug bit 6 turns it off)
 int g_thr_depth = 0;    // threshold-pass list depth: 0 = by launch shape, 1 / 4 forced (A/B hook: keds_scan_debug bits 7-9)
-int g_tail_unfused = 0; // keds_scan_debug bit 10: merge + re-rank + certificate in ONE launch (A/B, tests; see search_tail_fused)
+int g_tail_fused = 0; // keds_scan_debug bit 10: merge + re-rank + certificate in ONE launch (A/B, tests; see search_tail_fused)
 // (Measured, round 4, same box, tools/search_profile.py: fused 234-242 us per search, three launches 237 -- one block per
 // query re-ranks its 64 candidates on four waves where rerank_kernel spreads 8,192 waves over the chip; the two kernel
 // boundaries it saves cost less than that.  OFF by default; KEDS_SEARCH_FUSED=1 / keds_scan_debug bit 10 select it.)
@@ -1192,7 +1193,7 @@ bool search_tail_fused() {
         const char* e = getenv("KEDS_SEARCH_FUSED");
         env = e && e[0] == '1';
     }
-    return env || g_tail_unfused;
+    return env || g_tail_fused;
 }
 
 template <int D, int L>
@@ -1200,6 +1201,11 @@ int launch_scan(const void* packed, int stage_begin, int total_stages, const bf1
                 unsigned long long* lval, uint2* lidx, int nwg, int nqb, hipStream_t st) {
     using C = ScanCfg<D>;
     const size_t lds = (size_t)C::NST * C::LDS_STAGE;
+    // the key stream's buffer descriptor starts at the workgroup's first stage and takes signed 32-bit offsets (2 GiB): an
+    // out-of-range buffer load returns zeros SILENTLY -- wrong neighbours, no fault -- so the span is checked here
+    KEDS_REQUIRE(nwg > 0 && ((long long)(total_stages + nwg - 1) / nwg + 1) * (long long)C::STAGEB < (1LL << 31),
+                 "keds_index_search: %d stages over %d workgroups: a workgroup's key stream would span 2 GiB or more "
+                 "(search the index in row ranges)", total_stages, nwg);
     if (int rc = keds_func_lds_once((const void*)scan_topk_kernel<D, L>, (int)lds, "scan_topk_kernel")) return rc;
     KedsProfScope prof(KEDS_PROF_SCAN, st);
     if constexpr (D == 768 && L == LISTK) {
@@ -1272,7 +1278,7 @@ extern "C" int keds_scan_debug(int variant) {
     g_scan_nt = (variant >> 6) & 1 ? 0 : 1;   // bit 6: default-policy key stream instead of non-temporal (A/B)
     g_thr_depth = (variant >> 7) & 7;         // bits 7-9: threshold-pass list depth 1 or 4 forced (0: by launch shape)
     if (g_thr_depth != 1 && g_thr_depth != 4) g_thr_depth = 0;
-    g_tail_unfused = (variant >> 10) & 1;     // bit 10: merge + re-rank + certificate in one launch (A/B, tests)
+    g_tail_fused = (variant >> 10) & 1;     // bit 10: merge + re-rank + certificate in one launch (A/B, tests)
     return KEDS_OK;
 }
 

@@ -588,6 +588,11 @@ extern "C" int keds_text_info(const keds_text* txt, int* width, int* layers, int
 
 extern "C" int keds_text_forward(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
                                  int insert_idx, const int32_t* readout_idx, int B, void* out, void* stream) {
+    return keds_text_forward_used(txt, tokens, img_tokens, n_img_tok, insert_idx, readout_idx, 0, B, out, stream);
+}
+
+extern "C" int keds_text_forward_used(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
+                                      int insert_idx, const int32_t* readout_idx, int seq_used, int B, void* out, void* stream) {
     const char* what = "keds_text_forward";
     KEDS_REQUIRE(txt && tokens && readout_idx && out && B > 0, "%s: bad argument", what);
     KEDS_REQUIRE((img_tokens == nullptr) == (n_img_tok == 0), "%s: img_tokens and n_img_tok disagree", what);
@@ -597,8 +602,8 @@ extern "C" int keds_text_forward(keds_text* txt, const int32_t* tokens, const vo
     int rc;
     const size_t need = keds_text_workspace_bytes(&txt->p, B);
     if ((rc = txt->ws.reserve(need, (hipStream_t)stream, what))) return rc;
-    return keds_text_run(&txt->p, tokens, readout_idx, (const float*)img_tokens, n_img_tok, insert_idx, B, (float*)out, 0,
-                         txt->ws.p, txt->ws.bytes, stream);
+    return keds_text_run_ex(&txt->p, tokens, readout_idx, (const float*)img_tokens, n_img_tok, insert_idx, B, seq_used, (float*)out,
+                            0, txt->ws.p, txt->ws.bytes, stream);
 }
 
 // ---- knowledge injection ------------------------------------------------------------------------------

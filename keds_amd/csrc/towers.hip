@@ -11,12 +11,15 @@ int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, 
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
 int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int S, int d, hipStream_t st);
 int keds_cast_rows_f16_f32_impl(const void* x16, float* x32, int rows, int dim, long long stride, hipStream_t st);
+int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st);
+int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
+                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream);
 
 bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
 
 // f32path.hip: the fp32-accurate flow (keds_tower_params.f32)
 size_t keds_tower_f32_workspace_bytes(int width, int seq, int B);
-int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st);
+int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows = nullptr);
 size_t keds_readout_f32_workspace_bytes(int B, int d);
 int keds_readout_f32(const float* x, int S, const int32_t* row, const float* gamma, const float* beta, const float* proj_t,
                      float* out, int B, int d, int E, int normalize, void* workspace, hipStream_t st);
@@ -139,6 +142,32 @@ int cls_rows_tail(const keds_tower_params* p, const keds_block_params& k, const 
     return keds_gemm_bt_ex(t.hid, 4 * w, k.proj_w, k.proj_b, x, ld, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st);
 }
 
+// The text tower's form of the same cut: after the last block only ONE row of every sample is read -- the EOT column
+// (+ n_tok - 1 with spliced pseudo tokens; model.py:587-589, 847-849) -- a different row per sample, known on the device only
+// (`rows`, int32 [B]).  The block's in_proj and attention run on all rows (every key is needed; the attention is 1.6 % of a
+// block), then the B read-out rows of the attention output and of the residual stream are gathered into compact [B, w]
+// buffers (in the qkv buffer, which nobody reads any more) and out-proj, ln_2 and the MLP run on those.  On return the first
+// B rows of x hold the block's output for sample b in row b: the caller reads out with S = 1, row 0.
+int rows_tail(const keds_tower_params* p, const keds_block_params& k, const TowerWs& t, float* x, const void* x16, int B,
+              const int32_t* rows, hipStream_t st) {
+    const int w = p->width, S = p->seq;
+    int rc;
+    if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
+    bf16_t* att_c = t.qkv;                                               // [B, w] bf16 (2 w bytes per row: a multiple of 256)
+    float* x_c = (float*)((char*)t.qkv + (size_t)B * w * 2);             // [B, w] fp32; 6 B w <= the buffer's 6 w pad256(B S)
+    if ((rc = keds_gather_rows_impl(t.att, att_c, rows, S, B, w, 0, st))) return rc;
+    if ((rc = keds_gather_rows_impl(x16 ? x16 : (const void*)x, x_c, rows, S, B, w, x16 ? 1 : 2, st))) return rc;
+    if ((rc = keds_gemm_bt_ex(att_c, w, k.out_w, k.out_b, x_c, w, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
+    if ((rc = keds_layernorm_impl(x_c, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, B, w, st))) return rc;
+    if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, t.hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
+    if ((rc = keds_gemm_bt_ex(t.hid, 4 * w, k.proj_w, k.proj_b, x_c, w, B, w, 4 * w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
+    if (hipMemcpyAsync(x, x_c, (size_t)B * w * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        keds_set_error("keds_tower_forward: read-out rows: %s", hipGetErrorString(hipGetLastError()));
+        return KEDS_E_LAUNCH;
+    }
+    return KEDS_OK;
+}
+
 // KEDS_TAIL_ATTN=1 in the environment: the tail samples' attention on the side lane (round-4 experiment, OFF by default:
 // bit-identical and neutral -- 6,759-6,770 vs 6,770-6,776 img/s in four same-box pairs, profiles/r04_tail_attention_ab.txt)
 bool tail_attention_on_side() {
@@ -177,7 +206,8 @@ int tower_fill_rows(int M, int w) {
 // its MXFP8 copy (xq, xs), the attention output (aq) and the MLP hidden (hq) are e4m3 + one e8m0 scale per 32 columns,
 // produced by the GEMM epilogues themselves (the attention output by the attention kernel).  Rows beyond the last full
 // 256-row tile (128 of 32,896 at B = 128) keep the bf16 path, on the side lane: every producer has a bf16 twin for them.
-int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs& t, int Mm, hipStream_t st) {
+int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs& t, int Mm, hipStream_t st,
+                      const int32_t* last_rows) {
     const int w = p->width, S = p->seq;
     const int M = B * S, Mt = M - Mm;
     RowLanes lanes;
@@ -195,6 +225,7 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
             return rc;
         if (Mt && (rc = qkv_rows(t, k, w, rem))) return rc;
         if ((rc = lanes.to_main())) return rc;
+        if (last && last_rows) return rows_tail(p, k, t, x, t.h, B, last_rows, st);
         if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, t.h, B, st);
         // attention writes its output as MXFP8 for the full-tile rows and as bf16 for the remainder rows
         if ((rc = keds_attention_mx(t.qkv, t.att, B, S, p->heads, p->causal, S, t.aq, t.as, Mm, st))) return rc;
@@ -218,7 +249,10 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
 
 // allow_fill: the caller's x holds pad_rows(B * seq) rows (keds_vit_run / keds_text_run carve it so); the public
 // keds_tower_forward promises only a multiple of 128 and keeps the two-lane scheme
-int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, bool allow_fill) {
+// last_rows (device int32 [B], nullable): the one row of every sample that is read after the last block (rows_tail): on
+// return x[b] (row b of the first B rows) holds that row of sample b; without it x holds every row as before
+int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, bool allow_fill,
+                  const int32_t* last_rows = nullptr) {
     const int w = p->width, S = p->seq;
     const int M = B * S;
     TowerWs t = carve_tower(ws, w, S, B);
@@ -240,7 +274,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         return KEDS_E_ARG;
     }
     const bool fp8 = p->fp8 && Mm > 0;             // fewer than 256 rows: everything is "remainder rows" (bf16 kernels)
-    if (fp8) return tower_forward_fp8(p, x, B, t, Mm, st);
+    if (fp8) return tower_forward_fp8(p, x, B, t, Mm, st, last_rows);
     if (folded) {
         // When every GEMM of the block would split into full 256-row tiles + a remainder launch anyway, the remainder
         // rows become their own chain on the side lane; otherwise one span covers all rows.
@@ -274,9 +308,9 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
             const bool last = l == p->layers - 1;
             if ((rc = qkv_rows(t, k, w, body))) return rc;
             if (rem.n && (rc = qkv_rows(t, k, w, rem))) return rc;
-            if (last && p->last_cls_only) {
+            if (last && (p->last_cls_only || last_rows)) {
                 if ((rc = lanes.to_main())) return rc;
-                return cls_rows_tail(p, k, t, x, t.h, B, st);
+                return last_rows ? rows_tail(p, k, t, x, t.h, B, last_rows, st) : cls_rows_tail(p, k, t, x, t.h, B, st);
             }
             if (tail_side) {
                 if ((rc = lanes.to_side())) return rc;               // side: behind the main in_proj
@@ -306,6 +340,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         const bool last = l == p->layers - 1;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
         if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, t.qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
+        if (last && last_rows) return rows_tail(p, k, t, x, nullptr, B, last_rows, st);
         if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, nullptr, B, st);
         if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
         if ((rc = keds_gemm_bt(t.att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
@@ -448,13 +483,15 @@ struct TextWs {
     char* ro;
     size_t bytes;
 };
-TextWs carve_text(const keds_text_params* p, int B, void* ws) {
+TextWs carve_text_cols(const keds_text_params* p, int B, int S, void* ws) {        // the layout for S columns per sequence
     TextWs v;
     char* base = (char*)ws;
-    const int w = p->tower.width, S = p->tower.seq;
+    const int w = p->tower.width;
     const size_t Mp = pad_rows((size_t)B * S);
     const size_t xb = keds_align_up(Mp * w * sizeof(float), 256);
-    const size_t tb = keds_tower_workspace_bytes_ex(&p->tower, B);
+    keds_tower_params tp = p->tower;
+    tp.seq = S;
+    const size_t tb = keds_tower_workspace_bytes_ex(&tp, B);
     const size_t rb = keds_align_up(p->tower.f32 ? keds_readout_f32_workspace_bytes(B, w) : keds_readout_workspace_bytes(B, w), 256);
     v.x = (float*)base;
     v.tower = base ? base + xb : nullptr;
@@ -462,6 +499,7 @@ TextWs carve_text(const keds_text_params* p, int B, void* ws) {
     v.bytes = xb + tb + rb;
     return v;
 }
+TextWs carve_text(const keds_text_params* p, int B, void* ws) { return carve_text_cols(p, B, p->tower.seq, ws); }
 }  // namespace
 
 extern "C" size_t keds_text_workspace_bytes(const keds_text_params* p, int B) {
@@ -469,27 +507,66 @@ extern "C" size_t keds_text_workspace_bytes(const keds_text_params* p, int B) {
     return carve_text(p, B, nullptr).bytes;
 }
 
-extern "C" int keds_text_run(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
-                                 const float* img_tokens, int n_tok, int insert_col, int B, float* out, int normalize,
-                                 void* workspace, size_t workspace_bytes, void* stream) {
+// KEDS_TEXT_TRIM=0 in the environment: the round-4 flow (all L columns through all blocks) for an A/B or a bisect
+static bool text_trim_on() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_TEXT_TRIM");
+        v = !(e && e[0] == '0');
+    }
+    return v != 0;
+}
+static int g_text_trim = -1;                     // run-time override (keds_text_trim_enable: tests, A/B); -1: the environment
+extern "C" int keds_text_trim_enable(int on) {   // 0 off, 1 on, 2 the column cut only, 3 the read-out-row tail only
+    g_text_trim = on < 0 || on > 3 ? -1 : on;
+    return KEDS_OK;
+}
+
+// Work that cannot reach the read-out is not done (round 5):
+//  * the mask is causal (model.py:543-549), so columns to the right of the last read-out column change no row that is read:
+//    `seq_used` (host-known: max(readout_row) + 1; 0 = unknown, all L columns) cuts the sequence there for the embedding, all
+//    blocks and the workspace layout ([B, columns, w]);
+//  * the last block's out-proj, ln_2 and MLP run on the B read-out rows only (rows_tail), as the ViT's do on the CLS rows.
+extern "C" int keds_text_run_ex(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
+                                const float* img_tokens, int n_tok, int insert_col, int B, int seq_used, float* out,
+                                int normalize, void* workspace, size_t workspace_bytes, void* stream) {
     KEDS_REQUIRE(p && tokens && readout_row && out && workspace && B > 0, "keds_text_run: bad argument");
     int rc = check_tower(&p->tower, "keds_text_run");
     if (rc) return rc;
     KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_text_run: embed_dim must be a multiple of 128");
+    KEDS_REQUIRE(seq_used >= 0 && seq_used <= p->tower.seq, "keds_text_run: seq_used %d outside [0, %d]", seq_used, p->tower.seq);
     TextWs v = carve_text(p, B, workspace);
     if (workspace_bytes < v.bytes) {
         keds_set_error("keds_text_run: workspace %zu < %zu", workspace_bytes, v.bytes);
         return KEDS_E_WORKSPACE;
     }
     const int w = p->tower.width, L = p->tower.seq;
-    if ((rc = keds_embed_tokens(tokens, p->token_emb, p->pos_emb, img_tokens, n_tok, insert_col, v.x, B, L, w, stream)))
+    const int mode = g_text_trim < 0 ? (text_trim_on() ? 1 : 0) : g_text_trim;
+    const bool cut = mode == 1 || mode == 2, trim = mode == 1 || mode == 3;
+    int Lx = L;
+    // (no rounding of the cut to whole row tiles: measured at B = 128 -- tools/text_shapes.py, profiles/r05_text_shapes.txt --
+    // the four GEMMs of a block take 161 us at 43 columns, 170 at 44, 172-174 at 46-48: at these sizes the 128 x 128 kernel's
+    // rounds of 512 workgroups decide, and fewer rows are never slower)
+    if (cut && seq_used > 0 && seq_used < L && p->tower.causal) Lx = seq_used;
+    keds_tower_params tp = p->tower;              // the tower on the columns that are computed
+    tp.seq = Lx;
+    v = carve_text_cols(p, B, Lx, workspace);     // (never larger than the full layout the size check above covers)
+    if ((rc = keds_embed_tokens_impl(tokens, p->token_emb, p->pos_emb, img_tokens, n_tok, insert_col, v.x, B, L, Lx, w, stream)))
         return rc;
-    if (p->tower.f32) {
-        if ((rc = keds_tower_forward_f32(&p->tower, v.x, B, v.tower, (hipStream_t)stream))) return rc;
-        return keds_readout_f32(v.x, L, readout_row, p->ln_final_g, p->ln_final_b, (const float*)p->proj_t, out, B, w,
-                                p->embed_dim, normalize, v.ro, (hipStream_t)stream);
+    const int32_t* last_rows = trim ? readout_row : nullptr;
+    if (tp.f32) {
+        if ((rc = keds_tower_forward_f32(&tp, v.x, B, v.tower, (hipStream_t)stream, last_rows))) return rc;
+        return keds_readout_f32(v.x, last_rows ? 1 : Lx, last_rows ? nullptr : readout_row, p->ln_final_g, p->ln_final_b,
+                                (const float*)p->proj_t, out, B, w, p->embed_dim, normalize, v.ro, (hipStream_t)stream);
     }
-    if ((rc = tower_forward(&p->tower, v.x, B, v.tower, (hipStream_t)stream, true))) return rc;
-    return keds_readout(v.x, L, readout_row, p->ln_final_g, p->ln_final_b, p->proj_t, out, B, w, p->embed_dim, normalize,
-                        v.ro, keds_readout_workspace_bytes(B, w), stream);
+    if ((rc = tower_forward(&tp, v.x, B, v.tower, (hipStream_t)stream, true, last_rows))) return rc;
+    return keds_readout(v.x, last_rows ? 1 : Lx, last_rows ? nullptr : readout_row, p->ln_final_g, p->ln_final_b, p->proj_t, out,
+                        B, w, p->embed_dim, normalize, v.ro, keds_readout_workspace_bytes(B, w), stream);
+}
+
+extern "C" int keds_text_run(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,
+                                 const float* img_tokens, int n_tok, int insert_col, int B, float* out, int normalize,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    return keds_text_run_ex(p, tokens, readout_row, img_tokens, n_tok, insert_col, B, 0, out, normalize, workspace,
+                            workspace_bytes, stream);
 }

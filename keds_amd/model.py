@@ -422,13 +422,17 @@ class CLIP(nn.Module):
         ro = readout.to(torch.int32).to(eng.device, non_blocking=True).contiguous()
         it = None if img_tokens is None else img_tokens.to(eng.device, dtype=torch.float32).contiguous()
         n_tok = 0 if it is None else it.shape[1]
+        # columns to the right of the last read-out column cannot reach any read-out under the causal mask
+        # (model.py:543-549): the host knows the read-out columns (they were derived from the host copy of the tokens), so
+        # the library cuts the sequence there (keds_text_run_ex)
+        seq_used = int(readout.max()) + 1
 
         def run(eng):
             nbytes = lib.keds_text_workspace_bytes(C.byref(eng.text), B)
             ws = self._ws.get(nbytes, eng.device)
             out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
-            check(lib.keds_text_run(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, ptr(out),
-                                    1 if normalize else 0, ptr(ws), ws.numel(), stream()), "keds_text_run")
+            check(lib.keds_text_run_ex(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, seq_used,
+                                       ptr(out), 1 if normalize else 0, ptr(ws), ws.numel(), stream()), "keds_text_run")
             return out
         return self._guarded(run).to(self.dtype)
 

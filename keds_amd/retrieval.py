@@ -39,14 +39,25 @@ def extract_feature_database(model: CLIP, image_batches, text_batches, out_dir: 
     (image_bases, text_bases) as float32 [N, D] device tensors -- what `build_database` takes.  With `out_dir` the two
     matrices are also written as `cc_image_databases.pt` / `cc_text_databases.pt` (plain float32 tensors: the reference's
     own on-disk format) and the ready-to-search indices as `cc_image_index.pt` / `cc_text_index.pt` (FlatIndex.save)."""
-    image_batches, text_batches = list(image_batches), list(text_batches)      # (a second pass must see the same batches)
+    # Streaming: `image_batches` / `text_batches` may be DataLoaders or generators over the whole dataset (0.5 M images are
+    # 300 GB of fp32 pixels) -- only VERIFY_CHUNK input batches are held at a time.  No row enters the database from an
+    # unverified pass of the numerics guard: the guard is synchronised behind every chunk (CLIP.numerics_checked) and a chunk
+    # during which it tripped late is encoded again -- on the safe flow by then -- from the inputs still held.
+    import itertools
 
-    def encode_all():
-        imgs = [model.encode_image(b.to(device) if device is not None else b, normalize=True).float() for b in image_batches]
-        txts = [model.encode_text(b.to(device) if device is not None else b, normalize=True).float() for b in text_batches]
-        return torch.cat(imgs), torch.cat(txts)
-    # no row enters the database from an unverified pass of the numerics guard (CLIP.numerics_checked)
-    image_bases, text_bases = model.numerics_checked(encode_all)
+    def encode_stream(batches, enc):
+        feats, it = [], iter(batches)
+        while True:
+            held = list(itertools.islice(it, VERIFY_CHUNK))
+            if not held:
+                break
+            feats += model.numerics_checked(lambda: [enc(b.to(device) if device is not None else b, normalize=True).float() for b in held])
+            held = None                                           # released before the next chunk is drawn
+        if not feats:
+            raise RuntimeError("extract_feature_database: no batches")
+        return torch.cat(feats)
+    image_bases = encode_stream(image_batches, model.encode_image)
+    text_bases = encode_stream(text_batches, model.encode_text)
     if image_bases.shape != text_bases.shape:
         raise RuntimeError(f"image / text databases differ in shape: {tuple(image_bases.shape)} vs {tuple(text_bases.shape)}")
     if out_dir is not None:
@@ -60,6 +71,7 @@ def extract_feature_database(model: CLIP, image_batches, text_batches, out_dir: 
     return image_bases, text_bases
 
 
+VERIFY_CHUNK = 8          # input batches held (and re-encoded after a late trip of the numerics guard) at a time
 SHARD_MANIFEST = "cc_database_shards.json"
 
 

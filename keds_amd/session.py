@@ -121,13 +121,17 @@ class Text(_Handle):
         self.width, self.layers, self.context, self.vocab, self.embed_dim = [i.value for i in info]
 
     def forward(self, tokens: torch.Tensor, readout: torch.Tensor, img_tokens: Optional[torch.Tensor] = None,
-                insert_idx: int = 0) -> torch.Tensor:
+                insert_idx: int = 0, seq_used: Optional[int] = None) -> torch.Tensor:
+        """seq_used: max(readout) + 1 when the caller knows it on the host (None: taken from `readout`, one device-to-host
+        copy when that lives on the device; 0: unknown -- every column runs)."""
         tok = tokens.to(torch.int32).contiguous()
         ro = readout.to(torch.int32).contiguous()
         it = None if img_tokens is None else img_tokens.float().contiguous()
+        if seq_used is None:
+            seq_used = int(ro.max()) + 1 if ro.numel() else 0
         out = torch.empty((tok.shape[0], self.embed_dim), dtype=torch.float32, device=tok.device)
-        check(load().keds_text_forward(self.h, ptr(tok), ptr(it), 0 if it is None else it.shape[1], insert_idx, ptr(ro),
-                                       tok.shape[0], ptr(out), stream()), "keds_text_forward")
+        check(load().keds_text_forward_used(self.h, ptr(tok), ptr(it), 0 if it is None else it.shape[1], insert_idx, ptr(ro),
+                                            int(seq_used), tok.shape[0], ptr(out), stream()), "keds_text_forward")
         return out
 
 

@@ -25,28 +25,51 @@ def _start_exchange2(config):
     args = [str(a) for a in config.args]
     if any(a.endswith(".py") or "::" in a for a in args) and not any("test_gpu_exchange2" in a for a in args):
         return                                                   # a run of other test files only
+    kexpr = getattr(config.option, "keyword", "") or ""
+    if kexpr and "exchange" not in kexpr:
+        return                                                   # -k selects by name and does not name this test
     try:
         import torch
         if torch.cuda.device_count() < 1:
             return
     except Exception:                                            # noqa: BLE001
         return
-    import socket
     import subprocess
     import tempfile
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     d = tempfile.mkdtemp(prefix="keds_exchange2_")
+    port = "file://" + os.path.join(d, "rendezvous")             # a file in the job's own directory: no pre-probed TCP port to race for
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["OMP_NUM_THREADS"] = "4"
+    env.setdefault("GLOO_SOCKET_IFNAME", "lo")                   # the container's hostname may not resolve: pair up over loopback
     procs = []
     for r in range(2):
         log = open(os.path.join(d, f"rank{r}.log"), "w")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exchange2_worker.py"), str(r), "2", str(port), d],
                                       env=env, stdout=log, stderr=subprocess.STDOUT, cwd=ROOT))
     EXCHANGE2 = {"procs": procs, "dir": d}
+
+
+def _stop_exchange2():
+    """Reap the two ranks and remove their directory whatever happened to the test that reads their verdicts (deselected, -x
+    stopped earlier, interrupted): nothing of this session outlives it."""
+    global EXCHANGE2
+    job, EXCHANGE2 = EXCHANGE2, None
+    if job is None:
+        return
+    import shutil
+    for p in job["procs"]:
+        if p.poll() is None:
+            p.kill()                                             # (the exact children this session started)
+        try:
+            p.wait(timeout=30)
+        except Exception:                                        # noqa: BLE001
+            pass
+    shutil.rmtree(job["dir"], ignore_errors=True)
+
+
+def pytest_unconfigure(config):
+    _stop_exchange2()
 
 
 def pytest_configure(config):

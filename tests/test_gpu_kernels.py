@@ -540,7 +540,7 @@ def test_large_gallery_ranking_and_imgnet_metric(nq, ng):
         assert abs(v - mg[k]) <= 1.0 / nq + 1e-6, (k, v, mg[k])
 
 
-@pytest.mark.parametrize("M,K", [(4096, 256), (4096, 1024), (8192 + 1024, 256), (12288, 512), (11008, 1024), (11008, 256)])
+@pytest.mark.parametrize("M,K", [(4096, 256), (4096, 1024), (8192 + 1024, 256), (12288, 512), (11008, 1024), (11008, 256), (4096, 2048)])
 def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(M, K):
     """The 4-wave 256 x 256 kernel (round 3: one wave per SIMD, 128 x 128 outputs per wave, accumulators in fixed AGPRs) runs
     the same MFMA chains in the same k order and the same epilogues as the 8-wave kernel: every epilogue the towers use must
@@ -548,7 +548,11 @@ def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(M, K):
     Its persistent form (one workgroup per CU walks the tiles; M = 12288 / 11008 here: 768 / 688 tiles = three rounds, the last
     one ragged -- fewer tiles than 85 % of whole rounds go to the 128 x 128 kernel and would not test it)
     must as well -- including the LayerNorm epilogue's deferred stores (K >= 512: 18 of a lane's 32 stores of a tile are issued
-    from inside the next tile's K-loop; K = 256 is too short for the trickle and stores everything in the epilogue)."""
+    from inside the next tile's K-loop; K = 256 is too short for the trickle and stores everything in the epilogue).
+    Round 5: what the dispatcher picks (`default`) is, for the LayerNorm-folded epilogues at K >= 1024, the two-accumulator-set
+    kernel (gemm_duo.hip: 128 x 256 units, the previous unit's epilogue in the gaps between this unit's MFMAs; K = 2048 also
+    runs its plain K-tile loop behind the 16 K-tiles that carry the sub-slices): the same chains, the same bits, and the other
+    statistics buffer cleared for exactly the rows of the launch."""
     lib = _lib.load()
     N = 4096                                                     # >= 256 tiles of 256 x 256: the big-tile path
     g = torch.Generator(device="cuda").manual_seed(K)

@@ -441,3 +441,82 @@ def test_default_fp16_checkpoint_model_and_empty_batches():
     _assert_close("tiny.fp16_model.encode_text", txt, g["encode_text"], cos_min=0.9995, rel_max=4e-2)
     assert tuple(m.encode_image(img[:0]).shape) == (0, 128)
     assert tuple(m.encode_text(torch.from_numpy(g["text"][:0]).cuda()).shape) == (0, 128)
+
+
+def _ragged_tokens(B, L, eots, end_id, star, vocab, seed=11):
+    """[B, L] token rows: start token, random ids, the split token `star` at column 3, ONE EOT at column eots[b], zeros behind."""
+    rs = np.random.RandomState(seed)
+    t = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        e = int(eots[b % len(eots)])
+        t[b, :e] = rs.randint(1, min(vocab, 40000) - 2, size=e)
+        t[b, t[b] == star] = star + 1
+        t[b, 0] = end_id - 1
+        if e > 3:
+            t[b, 3] = star
+        t[b, e] = end_id
+    return torch.from_numpy(t)
+
+
+@pytest.mark.parametrize("size", ["tiny", "vitl"])
+def test_text_tower_does_only_the_work_that_reaches_the_readout(size, tiny_model):
+    """Round 5: keds_text_run_ex cuts the sequence behind the last read-out column (causal mask, model.py:543-549) and runs
+    the last block's out-proj / ln_2 / MLP on the B read-out rows only (model.py:587-589, 847-849).  Against the all-columns /
+    all-rows flow (keds_text_trim_enable(0) = the round-4 flow):
+      * the COLUMN CUT alone (mode 2) changes no arithmetic -- the same MFMA chains on the same rows, which only land in other
+        tiles / other kernels (256 x 256 vs 128 x 128 vs split-K): equal bits are reported, closeness far inside the operand
+        rounding is asserted;
+      * the read-out-row TAIL (mode 1 = cut + tail) runs the last block's second half in the fp32-stream form (stand-alone
+        LayerNorm, fp32 residual: what the ViT's CLS tail does) where the all-rows flow uses the folded form on the fp16
+        stream: two roundings of the same fp32 function, asserted inside the operand-rounding class;
+      * in fp32 mode (no operand rounding) all flows agree to 2e-6.
+    Ragged EOT sweep: EOT at column 6 (with the splice: read-out at 8), 40, 73 (the last column a 3-token splice allows), mixed."""
+    from keds_amd import _lib
+    lib = _lib.load()
+    if size == "tiny":
+        _, sd, m = tiny_model
+        d = 128
+    else:
+        sd = O.synth_clip_state_dict(**VITL, seed=7)
+        m = keds_amd.build_model(sd, fp16=False).cuda()
+        del sd
+        d = 768
+    L, star = 77, 7
+    rs = np.random.RandomState(3)
+    try:
+        for precision in ("bf16", "fp32", "fp8") if size == "vitl" else ("bf16",):
+            m.set_precision(precision)
+            for tag, B, eots in (("eot6", 5, [6]), ("eot40", 128, [40]), ("eot73", 33, [73]), ("mixed", 128, [9, 40, 12, 30, 41, 8])):
+                if size == "vitl" and precision == "fp32" and B > 33:
+                    B = 33
+                text = _ragged_tokens(B, L, eots, m.end_id, star, m.vocab_size)
+                tok3 = torch.from_numpy(rs.standard_normal((B, 3, d)).astype(np.float32) * 0.05).cuda()
+                tok2 = tok3[:, :2].contiguous()
+                calls = {
+                    "encode_text": lambda: m.encode_text(text.cuda()),
+                    "eti3": lambda: m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False),
+                    "eti2": lambda: m.encode_text_img_retrieval(text, tok2, split_ind=star, repeat=False),
+                    "eti3_repeat": lambda: m.encode_text_img_retrieval(text[:1], tok3, split_ind=star, repeat=True),
+                    "eti_train3": lambda: m.encode_text_img_train(text.cuda(), tok3, split_ind=star),
+                }
+                for name, fn in calls.items():
+                    out = {}
+                    for mode in (1, 2, 0):
+                        lib.keds_text_trim_enable(mode)
+                        out[mode] = fn().clone()
+                        assert torch.equal(out[mode], fn()) and torch.isfinite(out[mode]).all(), (size, precision, tag, name, mode)
+                    for mode, what in ((2, "cut"), (1, "cut+tail")):
+                        c, r = min_cosine(out[mode], out[0]), rel_l2(out[mode], out[0])
+                        report("text_trim_vs_full", size=size, precision=precision, case=tag, call=name, B=B, flow=what,
+                               bit_equal=bool(torch.equal(out[mode], out[0])), min_cosine=c, rel_l2=r)
+                        if precision == "fp32":
+                            assert r <= 2e-6, (size, tag, name, what, r)
+                        elif precision == "fp8":
+                            assert c >= 0.999 and r <= 4e-2, (size, precision, tag, name, what, c, r)
+                        elif mode == 2 and size == "tiny":
+                            assert torch.equal(out[mode], out[0]), (size, precision, tag, name, what, c, r)     # measured: equal bits
+                        else:               # (ViT-L/14 width: small-M launches split K, another summation order -- the batch-size sweep's class)
+                            assert c >= 0.99998 and r <= 6e-3, (size, precision, tag, name, what, c, r)
+    finally:
+        lib.keds_text_trim_enable(-1)
+        m.set_precision("bf16")

@@ -413,3 +413,102 @@ _Z22gemm_bt_quad_kernel_demo:
     assert problems(good % ("", "\tv_accvgpr_write_b32 a2, v20\n\tv_accvgpr_read_b32 v21, a2\n")) == []      # parked behind the read-back: fine
     bad = problems(good % ("\tv_accvgpr_write_b32 a2, v20\n", ""))
     assert bad and "live accumulator a2" in bad[0]
+
+
+def test_extract_feature_database_streams_its_inputs_and_reencodes_a_late_tripped_chunk():
+    """retrieval.extract_feature_database over a GENERATOR of batches (a DataLoader over 0.5 M images is 300 GB of pixels): at
+    most VERIFY_CHUNK input batches are ever held, the numerics guard is synchronised behind every chunk, and a chunk during
+    which it tripped late is encoded again from the inputs still held (advisor finding of round 4: the inputs used to be
+    materialised with list()).  Host logic only: a stand-in model counts what it is asked to do."""
+    import torch
+    from keds_amd import retrieval
+
+    alive = {"now": 0, "max": 0, "made": 0}
+
+    class Batch(torch.Tensor):
+        pass
+
+    def gen(n):
+        import weakref
+        for i in range(n):
+            t = torch.full((2, 4), float(i))
+            alive["now"] += 1
+            alive["made"] += 1
+            alive["max"] = max(alive["max"], alive["now"])
+            weakref.finalize(t, lambda: alive.__setitem__("now", alive["now"] - 1))
+            yield t
+            del t
+
+    class Model:
+        def __init__(self):
+            self.calls, self.chunks, self.safe = 0, 0, False
+
+        def encode_image(self, x, normalize=False):
+            self.calls += 1
+            return x[:, :3] + (0.0 if self.safe else 0.5 * (self.chunks == 1))      # the fast flow of chunk 1 is "wrong"
+
+        encode_text = encode_image
+
+        def numerics_checked(self, fn):
+            out = fn()
+            if self.chunks == 1 and not self.safe:      # the guard trips late during the second chunk: run it again, safely
+                self.safe = True
+                out = fn()
+            self.chunks += 1
+            return out
+
+    m = Model()
+    n = 3 * retrieval.VERIFY_CHUNK + 2
+    ib, tb = retrieval.extract_feature_database(m, gen(n), gen(n))
+    want = torch.cat([torch.full((2, 3), float(i)) for i in range(n)])
+    assert torch.equal(ib, want) and torch.equal(tb, want)
+    assert alive["made"] == 2 * n and alive["max"] <= retrieval.VERIFY_CHUNK + 1, alive
+    assert m.calls == 2 * n + retrieval.VERIFY_CHUNK                     # one chunk encoded twice
+
+
+def _run_bench_dry(gpus, extra_env=None, timeout=600):
+    import subprocess
+    env = dict(os.environ)
+    env.update({"KEDS_BENCH_CPU_DRYRUN": "1", "OMP_NUM_THREADS": "1"})
+    env.update(extra_env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "3", "--warmup", "1",
+                           "--db-rows", "4096", "--batch", "4"], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_eight_rank_flow_on_cpu():
+    """`python bench.py --gpus 8` cold, the way the driver will start it on an 8-GPU node -- here with KEDS_BENCH_CPU_DRYRUN=1:
+    the parent starts eight ranks as a child torch.distributed.run, they run THIS file's whole N = 8 flow (pilot of both search
+    placements, packed query all-gather, shard search, packed all-to-all + merge, per-rank report, the self-verification against
+    the oracle over all shards) on CPU tensors over gloo with stand-ins for the encoder and the shard scan, and rank 0's JSON
+    line is the last line on stdout."""
+    res = _run_bench_dry(8)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = res.stdout.strip().splitlines()[-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 8 and out["config"]["db_shards"] == 8 and out["config"]["global_batch"] == 32
+    assert out["value"] > 0 and out["scaling"] == "weak" and "CPU_DRYRUN" in out["diagnostic"]
+    pr = out["per_rank_search"]
+    assert all(len(pr[k]) == 8 for k in ("query_allgather_us", "local_search_us", "partials_alltoall_merge_us"))
+    assert set(out["search_overlap_pilot"]) == {"serial_ms_per_step", "overlapped_ms_per_step"}
+    v = out["verification"]
+    assert v["ok"] and v["id_mismatches"] == 0 and v["rows_searched"] == 4096 and v["queries"] == 4
+    assert out["stage_ms_per_step"]["attention"] is None            # no events: null, not 0.0
+    assert out["recall_parity_measured_in_this_run"] is False
+
+
+def test_bench_rank_failure_exits_nonzero_with_the_failing_ranks_message():
+    """A rank that dies takes the whole job down with a non-zero exit code and its own traceback on stderr (no JSON line is
+    printed for a job that did not finish)."""
+    res = _run_bench_dry(4, {"KEDS_BENCH_DRYRUN_FAIL_RANK": "3"})
+    assert res.returncode != 0
+    assert "rank 3 fails on purpose" in res.stderr
+    assert '"metric"' not in res.stdout
+
+
+def test_bench_self_verification_flags_a_wrong_neighbour_list():
+    """KEDS_BENCH_INJECT_FAULT=2 swaps two neighbours of one query in the last timed step's result: the line still prints, says
+    verification.ok = false with the mismatch count, and the process exits 3 -- a speed for wrong results is not a result."""
+    res = _run_bench_dry(2, {"KEDS_BENCH_INJECT_FAULT": "2"})
+    assert res.returncode != 0, res.stdout[-1500:]
+    out = json.loads([l for l in res.stdout.strip().splitlines() if l.startswith("{") and '"metric"' in l][-1])
+    assert out["verification"]["ok"] is False and out["verification"]["id_mismatches"] == 2

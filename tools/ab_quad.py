@@ -33,10 +33,14 @@ def main():
         stats[:, 1] = int(1.0 * K * 2 ** 28)
         other = torch.zeros(M, 2, device="cuda", dtype=torch.int64)
         out = torch.randn(M, N, device="cuda").half() if epi == _lib.EPI_RESID_STATS_F16 else torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
-        res = {"8 waves": [], "4 waves": [], "4 waves, persistent": [], "4 waves, 2-deep A": [], "4 waves, persistent, no deferred stores": []}
+        forms = (("8 waves", 3 << 11), ("4 waves", 1 << 11), ("4 waves, persistent", 2 << 11), ("4 waves, 2-deep A", (1 << 11) | (1 << 16)),
+                 ("4 waves, persistent, no deferred stores", (2 << 11) | (1 << 17)),
+                 ("dispatcher (round 5: two accumulator sets where it applies)", 0))
+        if os.environ.get("FORMS"):                                      # e.g. FORMS="4 waves, persistent;dispatcher"
+            forms = tuple(f for f in forms if any(f[0].startswith(k) for k in os.environ["FORMS"].split(";")))
+        res = {name: [] for name, _ in forms}
         for rnd in range(rounds):
-            for name, flag in (("8 waves", 3 << 11), ("4 waves", 1 << 11), ("4 waves, persistent", 2 << 11), ("4 waves, 2-deep A", (1 << 11) | (1 << 16)),
-                               ("4 waves, persistent, no deferred stores", (2 << 11) | (1 << 17))):
+            for name, flag in forms:
                 lib.keds_gemm_force_small(flag)
 
                 def run():

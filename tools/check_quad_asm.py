@@ -126,10 +126,76 @@ def check(asm: str):
     return n, errors
 
 
+def check_duo(asm: str):
+    """The two-accumulator-set kernel (gemm_duo.hip): its read-backs are interleaved with the OTHER set's MFMAs over a tile loop
+    with two unit bodies, so there is no linear "tile" to walk.  The rule is stricter instead: the compiler touches NO AGPR at
+    all (it has ~60 VGPRs to spare and no reason to), exactly 256 AGPRs are allocated, every generated read-back reads the
+    set the surrounding MFMAs do NOT write, and the kernel has no scratch traffic and no full vmcnt drain outside its end."""
+    errors, n = [], 0
+    for chunk in re.split(r"\n\s*\.globl\s+", asm)[1:]:
+        name = chunk.split("\n", 1)[0].strip().split(";")[0].strip()
+        if "gemm_bt_duo" not in name:
+            continue
+        n += 1
+        acc = re.search(r"\.amdhsa_accum_offset (\d+)", chunk)
+        nxt = re.search(r"\.amdhsa_next_free_vgpr (\d+)", chunk)
+        if not acc or not nxt or int(nxt.group(1)) - int(acc.group(1)) != 256:
+            errors.append(f"{name}: not exactly 256 AGPRs allocated")
+        code = chunk.split(".amdhsa_", 1)[0]
+        in_asm, last_set, drains, reads = False, None, 0, 0
+        for line in code.splitlines():
+            ins = line.strip()
+            if ins.startswith(";;#ASMSTART"):
+                in_asm = True
+                continue
+            if ins.startswith(";;#ASMEND"):
+                in_asm = False
+                continue
+            if not ins or ins.startswith((";", ".", "//")) or ins.endswith(":"):
+                continue
+            ins = ins.split(";", 1)[0].strip()
+            if re.match(r"scratch_(load|store)", ins):
+                errors.append(f"{name}: scratch traffic: `{ins}`")
+            if re.search(r"s_waitcnt.*vmcnt\(0\)", ins):
+                drains += 1
+            toks = re.findall(r"\ba\[\d+:\d+\]|\ba\d+\b", ins)
+            if not toks:
+                continue
+            if not in_asm:
+                errors.append(f"{name}: the compiler touches an AGPR: `{ins}`")
+                continue
+            op = ins.split()[0]
+            regs = [x for t in toks for x in agprs_of(t)]
+            if op.startswith("v_mfma"):
+                last_set = regs[0] // 128
+            elif op == "v_accvgpr_read_b32":
+                reads += 1
+                if last_set is not None and regs[0] // 128 == last_set and drains == 0:
+                    errors.append(f"{name}: read-back of a{regs[0]} beside MFMAs of the same set: `{ins}`")
+            else:
+                errors.append(f"{name}: unexpected AGPR use in a generated statement: `{ins}`")
+        if drains != 1:
+            errors.append(f"{name}: {drains} full vmcnt drains (expected exactly one, in front of the last unit's epilogue)")
+        if reads != 3 * 128:
+            errors.append(f"{name}: {reads} generated read-backs (expected 384: two unit bodies + the last unit's epilogue)")
+    return n, errors
+
+
 def main():
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
     n, errors = 0, []
     with tempfile.TemporaryDirectory() as td:
+        out = (keep + ".gemm_duo" if keep else os.path.join(td, "gemm_duo.s"))
+        res = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--offload-device-only", "-S",
+                              os.path.join(ROOT, "keds_amd", "csrc", "gemm_duo.hip"), "-o", out], capture_output=True, text=True)
+        if res.returncode != 0:
+            print(res.stderr[-3000:])
+            return 2
+        k, e = check_duo(open(out).read())
+        if k == 0:
+            e.append("gemm_duo.hip: no two-accumulator-set kernel found")
+        n += k
+        errors += e
         for fname in ("gemm", "gemm_fp8"):
             out = (keep + "." + fname if keep else os.path.join(td, fname + ".s"))
             src = os.path.join(ROOT, "keds_amd", "csrc", fname + ".hip")
