@@ -369,7 +369,7 @@ def _cos_rel(a, b):
     return cos, float((a - b).norm() / b.norm())
 
 
-EMBED_LIMITS = {"bf16": (0.9999, 6.0e-3), "fp8": (0.995, 1.0e-1), "fp32": (0.999999, 1.0e-5)}     # (min cosine, max rel-L2): tests/gpu_util.py
+EMBED_LIMITS = {"bf16": (0.9999, 6.0e-3), "fp8": (0.995, 1.0e-1), "fp32": (0.999999, 1.0e-5), "fp32x3": (0.999999, 2.0e-5)}     # (min cosine, max rel-L2): tests/gpu_util.py
 
 
 def verify_topk(index_rows, lo, q_dev, Dk, Ik, k, world, dist, n_check=8):
@@ -416,10 +416,11 @@ def main():
                     help="encode_search = BASELINE configs 1-3, the headline (ViT-L/14 encode + top-10); dual = config 4: the "
                          "dual-stream composed query (encode + 2 x top-16 with rows over two databases + 2 knowledge streams + "
                          "2 text-tower passes + normalise / mixture)")
-    ap.add_argument("--precision", choices=["bf16", "fp8", "fp32"], default="bf16",
+    ap.add_argument("--precision", choices=["bf16", "fp8", "fp32", "fp32x3"], default="bf16",
                     help="fp8 = BASELINE config 5 (MXFP8 GEMM operands in the towers; use with --db-rows 2000000); fp32 = the "
                          "reference's own evaluation arithmetic (no operand rounding, f32-input MFMA: the accuracy operating "
-                         "point, Recall@k equal to the reference); the headline metric is bf16")
+                         "point, Recall@k equal to the reference); fp32x3 = the same flow with the block GEMMs on split fp16 operands "
+                         "(three fp16 MFMA products per product, fp32-grade results); the headline metric is bf16")
     ap.add_argument("--search-overlap", choices=["auto", "on", "off"], default=os.environ.get("KEDS_BENCH_OVERLAP", "auto"),
                     help="N > 1, encode_search: run the search of batch i (its two collectives and short launches) on a second "
                          "stream beside the encoder pass of batch i+1 (on), behind it on the encoder's stream (off), or time "
@@ -633,7 +634,7 @@ def main():
     # (b) an fp32-mode leg of 3 steps: the Recall-equal operating point, timed by the same clock; (c) -- with the cpu_baseline
     # leg, rank 0, N = 1 -- the embeddings of the SAME 8 images the oracle encodes (below, where the oracle's are available).
     verification = None
-    fp32_point = None
+    fp32_point = fp32x3_point = None
     if not dual and not args.no_verify:
         q_chk = model.encode_image(images, normalize=True)       # the same bits as the last step's queries (deterministic kernels)
         verification = verify_topk(local_index.rows, lo, q_chk, Dk, Ik, k, world if use_dist else 1, dist)
@@ -645,6 +646,17 @@ def main():
             model.set_precision("bf16")
             emb16 = model.encode_image(images[:8], normalize=True).float().cpu()
             c32, r32 = _cos_rel(emb16, emb32)
+            model.set_precision("fp32x3")
+            step()
+            msx3 = timed_run(3)
+            embx3 = model.encode_image(images[:8], normalize=True).float().cpu()
+            model.set_precision("bf16")
+            cx3, rx3 = _cos_rel(embx3, emb32)
+            fp32x3_point = {"value": world * B / (msx3 * 1e-3), "unit": "query-images/sec", "ms_per_step": msx3, "steps": 3,
+                            "what": "the same step with set_precision('fp32x3'): the fp32 flow with the block GEMMs on split fp16 operands "
+                                    "(hi.hi + hi.lo + lo.hi on the fp16 MFMA) -- fp32-grade embeddings, Recall@k equal (tests/test_gpu_fp32.py)",
+                            "vs_fp32_embeddings": {"min_cosine": cx3, "rel_l2": rx3, "images": 8},
+                            "fell_back_to_fp32": bool(getattr(model, "x3_range_trips", 0))}
             fp32_point = {"value": world * B / (ms32 * 1e-3), "unit": "query-images/sec", "ms_per_step": ms32, "steps": 3,
                           "what": "the same step with set_precision('fp32'): f32-input MFMA, no operand rounding -- the operating "
                                   "point whose Recall@k equals the reference's (tests/test_gpu_fp32.py)",
@@ -673,8 +685,8 @@ def main():
     if rank == 0:
         steps = args.steps
         psteps = max(prof_steps, 1)                              # timed steps whose launches carried event pairs
-        fp8, f32 = args.precision == "fp8", args.precision == "fp32"
-        side_rows = 0 if (f32 or dry) else _lib.load().keds_tower_side_rows(VITL["vision_width"], 257, B, int(fp8))
+        fp8, f32, x3 = args.precision == "fp8", args.precision == "fp32", args.precision == "fp32x3"
+        side_rows = 0 if (f32 or x3 or dry) else _lib.load().keds_tower_side_rows(VITL["vision_width"], 257, B, int(fp8))
         if dual:
             # every GEMM launch of the step that carried an event pair (image tower, the 2B-row text-tower pass, IM2TEXT /
             # CrossFormer GEMMs, read-outs) with its own 2*M*N*K, counted by the library at launch (keds_prof_read_work);
@@ -688,8 +700,10 @@ def main():
                 tower_mac = 24 * 257 * 1024 * 3072 + 23 * 257 * _PER_TOKEN_TAIL
                 gemm_flops -= 2.0 * tower_mac * B * psteps * side_rows / (B * 257.0)
         ach = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        peak_tf = PEAK_FP8_TFLOPS if fp8 else PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS   # dense MFMA peak of the operand type
-        peak_meas_tf = PEAK_FP8_MEASURED_TFLOPS if fp8 else PEAK_F32_MEASURED_TFLOPS if f32 else PEAK_BF16_MEASURED_TFLOPS
+        # dense MFMA peak of the operand type; fp32x3: three fp16 MFMA products per algorithmic product (hi.hi + hi.lo + lo.hi)
+        peak_tf = PEAK_FP8_TFLOPS if fp8 else PEAK_F32_TFLOPS if f32 else PEAK_BF16_TFLOPS / 3 if x3 else PEAK_BF16_TFLOPS
+        peak_meas_tf = (PEAK_FP8_MEASURED_TFLOPS if fp8 else PEAK_F32_MEASURED_TFLOPS if f32 else
+                        PEAK_BF16_MEASURED_TFLOPS / 3 if x3 else PEAK_BF16_MEASURED_TFLOPS)
         # algorithmic bytes of one search = one pass over this rank's bf16 rows (N_local*D*2 B), charged with the time of
         # every scan launch the search issues
         n_search = psteps * world * (2 if dual else 1)            # query blocks of 128 searched by this rank (profiled steps)
@@ -714,7 +728,7 @@ def main():
             workload = ("ViT-L/14 encode_image (224x224 synthetic, random-init weights) + exact top-%d over a synthetic "
                         "unit-norm %.1fM x 768 database" % (k, N / 1e6))
             par = f"dp{world} encoders + {world}-way row-sharded scan"
-        gemm_traffic, gemm_traffic_note = (None, "PMC passes are of the bf16 encode_search workload only") if (fp8 or f32 or dual) \
+        gemm_traffic, gemm_traffic_note = (None, "PMC passes are of the bf16 encode_search workload only") if (fp8 or f32 or x3 or dual) \
             else pmc_traffic("gemm_256x256_all", B, N, world)
         scan_traffic, scan_traffic_note = (None, "n/a") if dual else pmc_traffic("scan_topk_kernel<768, 16", B, N, world)
         parity, parity_note = recall_parity()
@@ -727,6 +741,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": ("fp8 (MXFP8 e4m3 operands, fp32 accumulate; config 5)" if fp8 else
                       "f32 (f32-input MFMA, no operand rounding: the accuracy operating point)" if f32 else
+                      "fp32x3 (fp32 flow, block GEMMs on split fp16 operands: 3 fp16 MFMA products per product, fp32 accumulate)" if x3 else
                       "bf16/fp16 operands, fp32 accumulate"), "data": "synthetic",
             **({"diagnostic": "KEDS_BENCH_SHARED_GPU=1: all ranks share ONE GPU over a host-staged gloo transport -- a test of the "
                               "N > 1 flow, not a scaling measurement"} if shared_gpu else {}),
@@ -735,7 +750,9 @@ def main():
             "config": {"workload": workload,
                        "batch_per_gpu": B, "global_batch": B * world, "db_rows": N, "dim": D, "k": k,
                        "db_shards": world, "parallelism": par},
-            "roofline": {"kernel": ("gemm_f32_kernel (128x128 tiles, v_mfma_f32_32x32x2_f32)" if f32 else ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_quad_kernel / gemm_bt_quad3_kernel / gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane GEMM launches of the step incl. the few 128x128-tile ones)"), "bound": "mfma",
+            "roofline": {"kernel": ("gemm_f32_kernel (128x128 tiles, v_mfma_f32_32x32x2_f32)" if f32 else
+                                    "gemm_bt_pair_kernel<KEDS_EPI_X3_*> (256x256 tiles, three K segments over split fp16 planes; achieved = algorithmic 2MNK flops, peak = fp16 MFMA / 3)" if x3 else
+                                    ("gemm_mxfp8_kernel" if fp8 else "gemm_bt_quad_kernel / gemm_bt_quad3_kernel / gemm_bt_pair_kernel") + " (256x256 tiles; all main-lane GEMM launches of the step incl. the few 128x128-tile ones)"), "bound": "mfma",
                          "achieved": ach, "peak": peak_tf, "unit": "TFLOP/s", "frac": ach / peak_tf,
                          "traffic": gemm_traffic, "traffic_unit": "bytes/launch (PMC, mean over the 256x256 GEMM launches; committed "
                          "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload; null when they are not of this build)",
@@ -774,6 +791,7 @@ def main():
         }
         if fp32_point is not None:
             out["fp32_point"] = fp32_point
+            out["fp32x3_point"] = fp32x3_point
         if world == 1 and not args.no_cpu_baseline and not dual and not dry:
             out["cpu_baseline"], (s_img8, s_ref8) = cpu_baseline(model, N, D, k)
             if verification is not None:                       # the SAME images through the timed path

@@ -193,6 +193,15 @@ int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery
 #define KEDS_EPI_LN_QGELU_BF16_H 11 /* KEDS_EPI_LN_QGELU_BF16 with fp16 operands */
 #define KEDS_EPI_BIAS_BF16_HEADF32 12 /* out bf16 = acc + bias, and rows m < aux_i also as fp32 to ((float*)aux)[m*3N + n]: IM2TEXT's
                                        * last layer writes the bf16 rows the CrossFormers read AND token slot 2 of [B,3,N] */
+/* Split-operand GEMMs of the "fp32x3" operating point (round 5): BOTH operands are pairs of fp16 planes, x = hi + lo with
+ * hi = fp16(x), lo = fp16(x - hi) (22 significant bits; |x| < 65504), and the product is  hi.hi + hi.lo + lo.hi  on the fp16
+ * MFMA with fp32 accumulation -- three times the matrix work of a bf16 GEMM, ~1/5 of the time of the f32-input MFMA (157 TF),
+ * and fp32-grade results (the dropped lo.lo term is 2^-22 relative).  A = planes [2][rows][K] (keds_split_f16_pair), W = planes
+ * [2][N][K]; called through keds_gemm_x3. */
+#define KEDS_EPI_X3_BIAS_F32 13     /* out f32 = acc + bias */
+#define KEDS_EPI_X3_RESID_F32 14    /* out f32 += acc + bias (in place) */
+#define KEDS_EPI_X3_QGELU_PAIR 15   /* out = fp16 planes [2][rows][N] of qgelu(acc + bias) (full-precision expf / division): the
+                                       next split-operand GEMM's A operand; aux_i = elements between the two planes */
 
 /* out[M,N] = epilogue(A[M,K] . W[N,K]^T + bias[N]).  A, W bf16 row-major (W is the nn.Linear
  * weight as stored).  N % 128 == 0, K % 64 == 0; rows of A / out up to the next multiple of
@@ -260,6 +269,13 @@ int keds_gemm_set_workspace(void* ptr, size_t bytes);
  * only), bit 9 disables split-K; A/B switches of the 256x256 kernels: bit 10 residual tile as the accumulators' initial
  * value, bits 11-12 kernel form (1 = 4 waves, 2 = 4 waves persistent, 3 = 8 waves; 0 = by shape), bits 13-15 stamped
  * diagnostic build, bit 16 no three-deep A ring, bit 17 no deferred epilogue stores in the persistent kernel */
+/* out = epilogue(A . W^T + bias) on split fp16 operands (KEDS_EPI_X3_*): A_hi = a, A_lo = a + a_plane elements (rows of lda
+ * elements), W_hi = w, W_lo = w + w_plane (dense [N, K]).  M, N, K as keds_gemm_bt_ex2; ldc in elements of the output type. */
+int keds_gemm_x3(const void* a, int64_t a_plane, int64_t lda, const void* w, int64_t w_plane, const float* bias, void* out,
+                 int64_t ldc, int M, int N, int K, int epilogue, int aux_i, void* stream);
+/* x fp32 [rows, cols] (row stride ld elements) -> fp16 planes hi = out, lo = out + plane (dense rows of `cols`): the A / W operand
+ * of keds_gemm_x3.  Values beyond the fp16 range raise *overflow (device int32, nullable) instead of going through as inf. */
+int keds_split_f16_pair(const float* x, int64_t ld, int64_t rows, int cols, void* out, int64_t plane, int* overflow, void* stream);
 int keds_gemm_force_small(int on);
 /* The 256 x 256 GEMMs with LayerNorm-folded fp16-operand epilogues (in_proj, c_fc) on the two-accumulator-set kernel (round 5,
  * csrc/gemm_duo.hip: the epilogue of one 128 x 256 unit runs in the gaps between the next unit's MFMAs): 1 on, 0 off (the

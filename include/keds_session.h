@@ -32,7 +32,9 @@
 extern "C" {
 #endif
 
-typedef enum { KEDS_F32 = 0, KEDS_BF16 = 1, KEDS_F16 = 2, KEDS_FP8 = 3 /* compute only: MXFP8 GEMM operands (config 5) */ } keds_dtype;
+typedef enum { KEDS_F32 = 0, KEDS_BF16 = 1, KEDS_F16 = 2, KEDS_FP8 = 3 /* compute only: MXFP8 GEMM operands (config 5) */,
+               KEDS_F32X3 = 4 /* compute only: the fp32 flow with the block GEMMs on split fp16 operands ("fp32x3", keds_hip.h:
+                                 fp32-grade results, Recall@k equal, > 2x KEDS_F32's throughput; |activations| < 65504) */ } keds_dtype;
 
 typedef struct {
     const char* name;        /* state_dict key, e.g. "visual.transformer.resblocks.0.attn.in_proj_weight" */
@@ -53,7 +55,7 @@ int keds_ctx_create(int device, keds_ctx** out);
 int keds_ctx_destroy(keds_ctx* ctx);
 
 /* ---- image tower: keys "visual.*" of a CLIP state_dict (other keys are ignored) ------------- */
-int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute /* KEDS_BF16 | KEDS_FP8 | KEDS_F32 (the fp32-accurate flow, keds_hip.h section 10) */, keds_vit** out);
+int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute /* KEDS_BF16 | KEDS_FP8 | KEDS_F32 (the fp32-accurate flow, keds_hip.h section 10) | KEDS_F32X3 */, keds_vit** out);
 int keds_vit_destroy(keds_vit* vit);
 /* width, layers, heads, resolution, patch, embed_dim inferred from the shapes */
 int keds_vit_info(const keds_vit* vit, int* width, int* layers, int* resolution, int* patch, int* embed_dim);

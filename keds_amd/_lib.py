@@ -23,6 +23,7 @@ EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
 EPI_LN_BIAS_BF16_H, EPI_LN_QGELU_BF16_H = 10, 11
 EPI_BIAS_BF16_HEADF32 = 12
+EPI_X3_BIAS_F32, EPI_X3_RESID_F32, EPI_X3_QGELU_PAIR = 13, 14, 15
 F32_EPI_BIAS, F32_EPI_QGELU, F32_EPI_RESID, F32_EPI_RELU, F32_EPI_PATCH = range(5)
 FP8_EPI_BIAS_BF16, FP8_EPI_LN_BIAS_BF16, FP8_EPI_LN_QGELU_MX, FP8_EPI_RESID_STATS_MX, FP8_EPI_RESID_STATS_MX_H = range(5)
 PROF_GEMM, PROF_ATTN, PROF_SCAN, PROF_LN, PROF_OTHER = range(5)
@@ -81,7 +82,7 @@ class Tensor(C.Structure):
     _fields_ = [("name", C.c_char_p), ("data", vp), ("dtype", i32), ("ndim", i32), ("shape", i64 * 4)]
 
 
-DT_F32, DT_BF16, DT_F16, DT_FP8 = 0, 1, 2, 3
+DT_F32, DT_BF16, DT_F16, DT_FP8, DT_F32X3 = 0, 1, 2, 3, 4
 COMM_ID_BYTES = 128
 pp = C.POINTER(vp)      # handle out-parameter
 
@@ -161,6 +162,8 @@ SIGNATURES = {
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "keds_gemm_set_workspace": (i32, [vp, sz]),
     "keds_gemm_force_small": (i32, [i32]),
+    "keds_gemm_x3": (i32, [vp, C.c_int64, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, i32, i32, i32, i32, i32, vp]),
+    "keds_split_f16_pair": (i32, [vp, C.c_int64, C.c_int64, i32, vp, C.c_int64, vp, vp]),
     "keds_gemm_duo_enable": (i32, [i32]),
     "keds_gemm_bt_ex2": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp]),
     "keds_fold_layernorm": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),

@@ -15,12 +15,14 @@ constexpr int LN_MAXV = 8;  // f32x4 chunks per lane: dim <= 2048
 // NV = dim/256 f32x4 chunks per lane, known at compile time so all row loads (and gamma/beta) are issued
 // back to back before the first reduction (predicated loads were being serialised: 2.6 TB/s -> see profiles/);
 // NV == 0 is the generic fallback (dim == 128 or any dim <= 2048 that is a multiple of 4).
-template <bool OUT_F32, int NV>
+// OUT: 0 = bf16, 1 = fp32, 2 = a PAIR of fp16 planes (hi = out, lo = out + pair_plane elements: y = hi + lo to 22 bits, the A
+// operand of a split-operand GEMM, keds_gemm_x3)
+template <int OUT, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long long x_stride,
                                                         const int* __restrict__ row_map, int row_mul,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, void* __restrict__ out,
-                                                        int rows, int dim) {
+                                                        int rows, int dim, long long pair_plane) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
@@ -61,8 +63,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         const int i = j * 256 + lane * 4;
         if (NV > 0 || i < dim) {
             const f32x4 y = (v[j] - mean) * rstd * gg[j] + bb[j];
-            if constexpr (OUT_F32) {
+            if constexpr (OUT == 1) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + (size_t)r * dim + i) = y;
+            } else if constexpr (OUT == 2) {
+                typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+                const f16x4 hi = f16x4{(f16_t)y[0], (f16_t)y[1], (f16_t)y[2], (f16_t)y[3]};
+                const f16x4 lo = f16x4{(f16_t)(y[0] - (float)hi[0]), (f16_t)(y[1] - (float)hi[1]), (f16_t)(y[2] - (float)hi[2]),
+                                       (f16_t)(y[3] - (float)hi[3])};
+                f16_t* o = reinterpret_cast<f16_t*>(out) + (size_t)r * dim + i;
+                *reinterpret_cast<f16x4*>(o) = hi;
+                *reinterpret_cast<f16x4*>(o + pair_plane) = lo;
             } else {
                 *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(out) + (size_t)r * dim + i) =
                     bf16x4{(bf16_t)y[0], (bf16_t)y[1], (bf16_t)y[2], (bf16_t)y[3]};
@@ -414,11 +424,11 @@ bool ln_dim_ok(int dim) { return dim > 0 && dim <= 2048 && dim % 4 == 0 && (dim 
 
 }  // namespace
 
-template <bool OUT_F32>
+template <int OUT>
 static void ln_launch(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
-                      const float* beta, void* out, int rows, int dim, hipStream_t st) {
+                      const float* beta, void* out, int rows, int dim, hipStream_t st, long long pair_plane = 0) {
     const unsigned grid = (rows + 3) / 4;
-#define KEDS_LN(NV) layernorm_kernel<OUT_F32, NV><<<grid, 256, 0, st>>>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim)
+#define KEDS_LN(NV) layernorm_kernel<OUT, NV><<<grid, 256, 0, st>>>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim, pair_plane)
     switch (dim) {
         case 256: KEDS_LN(1); break;
         case 512: KEDS_LN(2); break;
@@ -432,9 +442,53 @@ static void ln_launch(const float* x, long long x_stride, const int* row_map, in
 int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st) {
     KedsProfScope prof(KEDS_PROF_LN, st);
-    if (out_f32) ln_launch<true>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim, st);
-    else ln_launch<false>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim, st);
+    if (out_f32) ln_launch<1>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim, st);
+    else ln_launch<0>(x, x_stride, row_map, row_mul, gamma, beta, out, rows, dim, st);
     return keds_check_launch("layernorm_kernel");
+}
+
+// LayerNorm whose output is a pair of fp16 planes (hi = out, lo = out + plane elements; dense rows of `dim`)
+int keds_layernorm_pair_impl(const float* x, long long x_stride, const float* gamma, const float* beta, void* out, long long plane,
+                             int rows, int dim, hipStream_t st) {
+    KedsProfScope prof(KEDS_PROF_LN, st);
+    ln_launch<2>(x, x_stride, nullptr, 1, gamma, beta, out, rows, dim, st, plane);
+    return keds_check_launch("layernorm_kernel<pair>");
+}
+
+// x fp32 [rows, cols] -> fp16 planes hi / lo (x = hi + lo to 22 significant bits); one thread per 8 elements.  |x| >= 65504 does
+// not fit an fp16 hi: the flag (nullable) is raised and the caller falls back to the f32-input MFMA flow.
+__global__ __launch_bounds__(256) void split_f16_pair_kernel(const float* __restrict__ x, long long ld, long long rows, int cols,
+                                                             f16_t* __restrict__ out, long long plane, int* __restrict__ overflow) {
+    const int per_row = cols >> 3;
+    const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (id >= rows * per_row) return;
+    const long long r = id / per_row;
+    const int i = (int)(id - r * per_row) << 3;
+    const float* p = x + r * ld + i;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    f16x8 hi, lo;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float v = j < 4 ? a[j] : b[j - 4];
+        bad |= !(fabsf(v) < 65504.0f);
+        hi[j] = (f16_t)v;
+        lo[j] = (f16_t)(v - (float)hi[j]);
+    }
+    f16_t* o = out + r * cols + i;
+    *reinterpret_cast<f16x8*>(o) = hi;
+    *reinterpret_cast<f16x8*>(o + plane) = lo;
+    if (bad && overflow) *overflow = 1;
+}
+
+extern "C" int keds_split_f16_pair(const float* x, int64_t ld, int64_t rows, int cols, void* out, int64_t plane, int* overflow,
+                                   void* stream) {
+    KEDS_REQUIRE(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 4 == 0 && plane >= rows * cols,
+                 "keds_split_f16_pair: bad argument");
+    KedsProfScope prof(KEDS_PROF_OTHER, (hipStream_t)stream);
+    const long long threads = (long long)rows * (cols / 8);
+    split_f16_pair_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, ld, rows, cols, (f16_t*)out, plane, overflow);
+    return keds_check_launch("split_f16_pair_kernel");
 }
 
 extern "C" int keds_layernorm(const float* x, int64_t x_stride, const float* gamma, const float* beta, void* out,

@@ -328,8 +328,76 @@ size_t keds_tower_f32_workspace_bytes(int width, int seq, int B) {
 
 int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st);
 
+int keds_layernorm_pair_impl(const float* x, long long x_stride, const float* gamma, const float* beta, void* out, long long plane,
+                             int rows, int dim, hipStream_t st);
+int* keds_numerics_guard();
+
+// keds_tower_params.f32 == 2: the "fp32x3" operating point (round 5).  The same fp32 flow -- fp32 residual stream, fp32
+// LayerNorm / attention / QuickGELU -- with the four block GEMMs on SPLIT fp16 operands (keds_gemm_x3: x = hi + lo to 22 bits,
+// products hi.hi + hi.lo + lo.hi on the fp16 MFMA, fp32 accumulate): fp32-grade results at about a third of the bf16 GEMMs'
+// rate instead of the f32-input MFMA's sixteenth.  The weights arrive as fp16 planes [2][N][K] (keds_split_f16_pair at packing
+// time); LayerNorm writes its output as planes, the attention output is split by a pass of its own, c_fc's epilogue writes the
+// MLP hidden layer as planes.  A value beyond the fp16 range raises the caller's numerics guard (the host falls back to f32 = 1).
+static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows) {
+    const int w = p->width, S = p->seq, M = B * S;
+    const size_t Mp = keds_align_up((size_t)M, 256);
+    char* base = (char*)ws;
+    _Float16* ln2 = (_Float16*)base;                              // planes [2][Mp][w] (the fp32 flow's ln buffer: same bytes)
+    float* qkv = (float*)(base + keds_align_up(Mp * w * 4, 256));
+    float* att = (float*)((char*)qkv + keds_align_up(Mp * (size_t)w * 3 * 4, 256));
+    _Float16* hid2 = (_Float16*)((char*)att + keds_align_up(Mp * (size_t)w * 4, 256));      // planes [2][Mp][4w]
+    const long long pl = (long long)Mp * w, plh = (long long)Mp * 4 * w;
+    int* guard = keds_numerics_guard();
+    int rc;
+    for (int l = 0; l < p->layers; ++l) {
+        const keds_block_params& k = p->blocks[l];
+        const bool last = l == p->layers - 1;
+        const long long wq = 3LL * w * w, wo = (long long)w * w, wf = 4LL * w * w;     // elements between a weight's planes
+        if ((rc = keds_layernorm_pair_impl(x, w, k.ln1_g, k.ln1_b, ln2, pl, M, w, st))) return rc;
+        if ((rc = keds_gemm_x3(ln2, pl, w, k.qkv_w, wq, k.qkv_b, qkv, 3 * w, M, 3 * w, w, KEDS_EPI_X3_BIAS_F32, 0, st))) return rc;
+        if (last && (last_rows || p->last_cls_only)) {
+            // after the last block one row per sample is read (model.py:412 the CLS row; :587-589, 847-849 the read-out row):
+            // attention (all rows for the text tower, the CLS query for the ViT), then the B rows in compact buffers
+            float* att_c = qkv;                                   // [B, w] fp32 each, in the qkv buffer (dead after the attention)
+            float* x_c = qkv + (size_t)B * w;
+            if (last_rows) {
+                if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
+                if ((rc = keds_gather_rows_impl(att, att_c, last_rows, S, B, w, 2, st))) return rc;
+                if ((rc = keds_gather_rows_impl(x, x_c, last_rows, S, B, w, 2, st))) return rc;
+            } else {
+                if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, 1, st))) return rc;
+                if (hipMemcpy2DAsync(att_c, (size_t)w * 4, att, (size_t)S * w * 4, (size_t)w * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                    hipMemcpy2DAsync(x_c, (size_t)w * 4, x, (size_t)S * w * 4, (size_t)w * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                    keds_set_error("keds_tower_forward_f32: CLS rows: %s", hipGetErrorString(hipGetLastError()));
+                    return KEDS_E_LAUNCH;
+                }
+            }
+            const long long pc = (long long)keds_align_up((size_t)B, 256) * w;
+            if ((rc = keds_split_f16_pair(att_c, w, B, w, ln2, pc, guard, st))) return rc;
+            if ((rc = keds_gemm_x3(ln2, pc, w, k.out_w, wo, k.out_b, x_c, w, B, w, w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
+            if ((rc = keds_layernorm_pair_impl(x_c, w, k.ln2_g, k.ln2_b, ln2, pc, B, w, st))) return rc;
+            if ((rc = keds_gemm_x3(ln2, pc, w, k.fc_w, wf, k.fc_b, hid2, 4 * w, B, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)(4 * pc), st))) return rc;
+            if ((rc = keds_gemm_x3(hid2, 4 * pc, 4 * w, k.proj_w, wf, k.proj_b, x_c, w, B, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
+            // the caller reads row b of a compact x (text tower) or row b * S (ViT: CLS rows in place)
+            if (hipMemcpy2DAsync(x, (size_t)(last_rows ? w : S * w) * 4, x_c, (size_t)w * 4, (size_t)w * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+                keds_set_error("keds_tower_forward_f32: read-out rows: %s", hipGetErrorString(hipGetLastError()));
+                return KEDS_E_LAUNCH;
+            }
+            return KEDS_OK;
+        }
+        if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
+        if ((rc = keds_split_f16_pair(att, w, M, w, ln2, pl, guard, st))) return rc;
+        if ((rc = keds_gemm_x3(ln2, pl, w, k.out_w, wo, k.out_b, x, w, M, w, w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
+        if ((rc = keds_layernorm_pair_impl(x, w, k.ln2_g, k.ln2_b, ln2, pl, M, w, st))) return rc;
+        if ((rc = keds_gemm_x3(ln2, pl, w, k.fc_w, wf, k.fc_b, hid2, 4 * w, M, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)plh, st))) return rc;
+        if ((rc = keds_gemm_x3(hid2, plh, 4 * w, k.proj_w, wf, k.proj_b, x, w, M, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
+    }
+    return KEDS_OK;
+}
+
 // last_rows (device int32 [B], nullable): towers.hip, rows_tail -- the text tower's read-out rows; on return x[b] = that row
 int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows) {
+    if (p->f32 == 2) return tower_forward_x3(p, x, B, ws, st, last_rows);
     const int w = p->width, S = p->seq, M = B * S;
     const size_t Mp = keds_align_up((size_t)M, 256);
     char* base = (char*)ws;

@@ -65,6 +65,20 @@ __device__ __forceinline__ void epilogue_store(f32x4 v0, f32x4 v1, void* __restr
                 *reinterpret_cast<f32x4*>(t + 4) = v1;
             }
         }
+    } else if constexpr (EPI == KEDS_EPI_X3_QGELU_PAIR) {
+        // QuickGELU in full precision (model.py:300-302; f32path.hip's form), then the value as two fp16 planes: hi = fp16(v),
+        // lo = fp16(v - hi) -- the A operand of the next split-operand GEMM (aux_i = elements between the planes)
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float v = j < 4 ? v0[j] : v1[j - 4];
+            v = v / (1.0f + expf(-1.702f * v));
+            hi[j] = (f16_t)v;
+            lo[j] = (f16_t)(v - (float)hi[j]);
+        }
+        f16_t* o = reinterpret_cast<f16_t*>(out) + (size_t)m * ldc + n;
+        *reinterpret_cast<f16x8*>(o) = hi;
+        *reinterpret_cast<f16x8*>(o + (size_t)aux_i) = lo;
     } else if constexpr (EPI == KEDS_EPI_BIAS_RESID_F32) {
         float* o = reinterpret_cast<float*>(out) + (size_t)m * ldc + n;
         const f32x4 r0 = *reinterpret_cast<const f32x4*>(o);
@@ -245,7 +259,7 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = m_lane + 16 * mi;
                 if (m >= M) continue;
-                epilogue_store<EPI>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
+                epilogue_store<epi_base(EPI)>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
             }
         }
     }
@@ -491,7 +505,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
                                                          const float* __restrict__ aux, int aux_i,
                                                          float* __restrict__ part, int k_len, int tiles, int m_pad,
                                                          long long lda, long long ldc, void* __restrict__ aux2,
-                                                         int* __restrict__ guard) {
+                                                         int* __restrict__ guard, long long a_plane, long long w_plane) {
+    // (a_plane / w_plane: KEDS_EPI_X3_* only -- elements between the hi and lo planes of A / W; K-tile p of 3 K / 64 reads
+    // segment p / (K / 64): hi.hi, hi.lo, lo.hi; x3_seg, gemm_shared.h)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int bid_all = xcd_remap(blockIdx.x, gridDim.x);
     const int ks = part ? bid_all / tiles : 0;
@@ -523,11 +539,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     auto stage = [&](int buf, int kt) {
         char* xb = smem + buf * BUF_BYTES + (32 * wave) * 128;
         char* wb = xb + TILE_BYTES;
-        const int koff = (k_begin + kt * BK) * 2;
+        unsigned koff = (k_begin + kt * BK) * 2, kx = 0, kw = 0;
+        if constexpr (epi_x3(EPI)) {
+            const X3Seg sg = x3_seg(kt, K / BK);
+            koff = sg.koff;
+            kx = sg.a_lo ? (unsigned)(a_plane * 2) : 0u;
+            kw = sg.w_lo ? (unsigned)(w_plane * 2) : 0u;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs_, (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, xsrc[i], koff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs_, (__attribute__((address_space(3))) void*)(wb + i * 1024), 16, wsrc[i], koff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs_, (__attribute__((address_space(3))) void*)(xb + i * 1024), 16, xsrc[i], koff + kx, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs_, (__attribute__((address_space(3))) void*)(wb + i * 1024), 16, wsrc[i], koff + kw, 0, 0);
         }
     };
 
@@ -552,7 +574,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     // of K-step s+1 are issued between the 16 MFMAs of K-step s.  K-tile t occupies ring slot t % NST; it is
     // fully read into registers by the end of its kk=0 step, so at the kk=1 step (after one counted wait +
     // barrier that also retires K-tile t+1) its slot is refilled with K-tile t+NST.
-    const int nk = (part ? k_len : K) / BK;
+    const int nk = (epi_x3(EPI) ? 3 : 1) * ((part ? k_len : K) / BK);
 #pragma unroll
     for (int s = 0; s < NST; ++s)
         if (s < nk) stage(s, s);
@@ -707,6 +729,9 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(const float* __
 // every DMA lane group fetch half cache lines, the texture-address path saturates, and the 256 x 256 x 64 kernel below
 // replaced it: +16 % DMA rate from full-line fetches.  profiles/r01_gemm_pmc_ring_kernel.txt keeps its counters.)
 
+// (split-operand GEMMs: the planes' strides of the keds_gemm_x3 call in progress on this thread)
+thread_local long long g_x3_aplane = 0, g_x3_wplane = 0;
+
 template <int EPI, int NST>
 int launch_small_nst(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                      int aux_i, void* aux2, int splits, long long lda, long long ldc, hipStream_t st) {
@@ -720,7 +745,7 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
         const int m_pad = m_tiles * BM;
         gemm_bt_kernel<EPI, NST><<<tiles * splits, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
                                                                                M, N, K, n_tiles, aux, aux_i, g_ws,
-                                                                               K / splits, tiles, m_pad, lda, ldc, aux2, nullptr);
+                                                                               K / splits, tiles, m_pad, lda, ldc, aux2, nullptr, 0, 0);
         int rc = keds_check_launch("gemm_bt_kernel(split-K)");
         if (rc) return rc;
         const int threads = M * (N / 8);
@@ -730,7 +755,7 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
     }
     gemm_bt_kernel<EPI, NST><<<tiles, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
                                                                   n_tiles, aux, aux_i, nullptr, 0, tiles, 0, lda, ldc, aux2,
-                                                                  keds_numerics_guard());
+                                                                  keds_numerics_guard(), g_x3_aplane, g_x3_wplane);
     return keds_check_launch("gemm_bt_kernel");
 }
 
@@ -743,7 +768,7 @@ int launch_small(const void* A, const void* W, const float* bias, void* out, int
     // too few tiles to fill 256 CUs: split K so that ~128+ workgroups stream the weights in parallel
     float* g_ws = nullptr;
     size_t g_ws_bytes = 0;
-    if (tiles <= 64 && K >= 2048 && !g_no_split) keds_splitk_scratch(&g_ws, &g_ws_bytes);
+    if (tiles <= 64 && K >= 2048 && !g_no_split && !epi_x3(EPI)) keds_splitk_scratch(&g_ws, &g_ws_bytes);
     if (g_ws) {   // (tiles <= 64 && K >= 2048; at K = 1024 the second launch costs what the split saves)
         int splits = 1;
         while (splits < 16 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
@@ -794,7 +819,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int M, int N, int K, int n_tiles,
                                                               const float* __restrict__ aux, int aux_i,
-                                                              void* __restrict__ aux2, int* __restrict__ guard) {
+                                                              void* __restrict__ aux2, int* __restrict__ guard,
+                                                              long long a_plane = 0, long long w_plane = 0) {
+    // (a_plane / w_plane: KEDS_EPI_X3_* only, as in gemm_bt_kernel)
     using namespace pr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     unsigned long long t_entry = 0, vm_wait = 0, bar_wait = 0;
@@ -845,7 +872,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
     auto issue = [&](int p, int q) {
         const int i = q & 3;
         char* dst = smem + (p & 1) * PBUF_BYTES + (q < 4 ? 0 : OP_BYTES) + (wave + 8 * i) * 1024;
-        const unsigned so = i * rstride + (unsigned)p * (TK * 2);
+        unsigned so = i * rstride + (unsigned)p * (TK * 2);
+        if constexpr (epi_x3(EPI)) {                                // K-tile p of 3 K / 64: its segment's planes (uniform arithmetic)
+            const X3Seg sg = x3_seg(p, K / TK);
+            so = i * rstride + sg.koff + (q < 4 ? (sg.a_lo ? (unsigned)(a_plane * 2) : 0u) : (sg.w_lo ? (unsigned)(w_plane * 2) : 0u));
+        }
         if (q < 4)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff, so, 0, 0);
         else
@@ -903,7 +934,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         }
     }
 
-    const int np = K / TK;                                         // >= 2
+    const int np = (epi_x3(EPI) ? 3 : 1) * (K / TK);               // >= 2
     // LN epilogues: one row's statistics (threads 0-255) or one column's bias' / column sum (threads 256-511) per thread,
     // fetched BEFORE the DMA pieces (vmcnt retires in order) and turned into the side-area image while those are in flight
     [[maybe_unused]] u32x4 st_raw = u32x4{0, 0, 0, 0};
@@ -1843,7 +1874,7 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
     }
     gemm_bt_pair_kernel<EPI><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
                                                                             M, N, K, n_tiles, aux, aux_i, aux2,
-                                                                            keds_numerics_guard());
+                                                                            keds_numerics_guard(), g_x3_aplane, g_x3_wplane);
     return keds_check_launch("gemm_bt_pair_kernel");
 }
 
@@ -1871,7 +1902,8 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
     const int m_main = M / pr::TM * pr::TM;
     int rc = launch_big<EPI>(A, W, bias, out, m_main, N, K, aux, aux_i, aux2, st);
     if (rc || m_main == M || g_skip_tail) return rc;
-    const size_t esz = (EPI == KEDS_EPI_BIAS_RESID_F32 || EPI == KEDS_EPI_BIAS_F32 || EPI == KEDS_EPI_RESID_STATS_F32) ? 4 : 2;
+    const size_t esz = (EPI == KEDS_EPI_BIAS_RESID_F32 || EPI == KEDS_EPI_BIAS_F32 || EPI == KEDS_EPI_RESID_STATS_F32 ||
+                        EPI == KEDS_EPI_X3_BIAS_F32 || EPI == KEDS_EPI_X3_RESID_F32) ? 4 : 2;
     // the remainder launch numbers its rows from 0: move the per-row side buffers along
     const float* aux_t = aux;
     void* aux2_t = aux2;
@@ -1946,9 +1978,36 @@ extern "C" int keds_gemm_bt_ex2(const void* A, int64_t lda, const void* W, const
         case KEDS_EPI_BIAS_BF16_HEADF32:
             KEDS_REQUIRE(aux && aux_i >= 0, "keds_gemm_bt: EPI_BIAS_BF16_HEADF32 needs the fp32 head buffer and its row count");
             return launch_gemm<KEDS_EPI_BIAS_BF16_HEADF32>(A, W, bias, out, M, N, K, aux, aux_i, aux2, lda, ldc, st);
+        case KEDS_EPI_X3_BIAS_F32:
+        case KEDS_EPI_X3_RESID_F32:
+        case KEDS_EPI_X3_QGELU_PAIR:
+            keds_set_error("keds_gemm_bt: split-operand epilogues go through keds_gemm_x3");
+            return KEDS_E_ARG;
         default: keds_set_error("keds_gemm_bt: unknown epilogue %d", epilogue); return KEDS_E_ARG;
     }
 #undef KEDS_GEMM_CASE
+}
+
+extern "C" int keds_gemm_x3(const void* a, int64_t a_plane, int64_t lda, const void* w, int64_t w_plane, const float* bias, void* out,
+                            int64_t ldc, int M, int N, int K, int epilogue, int aux_i, void* stream) {
+    KEDS_REQUIRE(a && w && out && M > 0 && N > 0 && K > 0, "keds_gemm_x3: bad argument");
+    KEDS_REQUIRE(N % BN == 0 && K % BK == 0 && lda >= K && ldc >= N && lda % 8 == 0 && ldc % 8 == 0, "keds_gemm_x3: bad shape / strides");
+    // buffer offsets are 32-bit: a plane must be reachable from a tile's first row
+    KEDS_REQUIRE(a_plane > 0 && w_plane > 0 && a_plane * 2 + 256LL * lda * 2 < (1LL << 31) && w_plane * 2 + 256LL * K * 2 < (1LL << 31),
+                 "keds_gemm_x3: plane strides out of range");
+    hipStream_t st = (hipStream_t)stream;
+    g_x3_aplane = a_plane;
+    g_x3_wplane = w_plane;
+    switch (epilogue) {
+        case KEDS_EPI_X3_BIAS_F32:
+            return launch_gemm<KEDS_EPI_X3_BIAS_F32>(a, w, bias, out, M, N, K, nullptr, 0, nullptr, lda, ldc, st);
+        case KEDS_EPI_X3_RESID_F32:
+            return launch_gemm<KEDS_EPI_X3_RESID_F32>(a, w, bias, out, M, N, K, nullptr, 0, nullptr, lda, ldc, st);
+        case KEDS_EPI_X3_QGELU_PAIR:
+            KEDS_REQUIRE(aux_i > 0, "keds_gemm_x3: KEDS_EPI_X3_QGELU_PAIR needs the output planes' stride");
+            return launch_gemm<KEDS_EPI_X3_QGELU_PAIR>(a, w, bias, out, M, N, K, nullptr, aux_i, nullptr, lda, ldc, st);
+        default: keds_set_error("keds_gemm_x3: epilogue %d is not a split-operand epilogue", epilogue); return KEDS_E_ARG;
+    }
 }
 
 extern "C" int keds_gemm_bt_ex(const void* A, int64_t lda, const void* W, const float* bias, void* out, int64_t ldc,

@@ -28,9 +28,17 @@
 #include "gemm_duo_gen.h"
 
 // TIMING ONLY (make EXTRA="-DKEDS_DUO_DBG=n", tools/r05_duo_ablate.sh; results are wrong): bit 0 = no sub-slices (the K-loop alone),
-// bit 1 = no DMA pieces, bit 2 = no fragment reads, bit 3 = sub-slices without their stores
+// bit 1 = no DMA pieces, bit 2 = no fragment reads, bit 3 = sub-slices without their stores; what a store costs, and why:
+// bit 4 = every store of a workgroup into the same 64 KiB (never leaves L2 with the plain policy), bit 5 = lane-linear
+// addresses (one store instruction = 1 KiB contiguous = 8 whole lines instead of 16 half lines), bit 6 = every other store only,
+// bit 7 = every other DMA piece only (is the stores' cost a queueing effect of a vector-memory path the pieces nearly fill?),
+// bit 8 = the K-tile waits leave 16 more operations in flight (is it the in-order vmcnt waiting for a store's acknowledgement?)
 #ifndef KEDS_DUO_DBG
 #define KEDS_DUO_DBG 0
+#endif
+// cache policy of the in-loop output stores (keds_common.h, keds_store16: 0 plain, 1 nt, 3 sc1 nt, ...): A/B with EXTRA
+#ifndef KEDS_ST_DUO
+#define KEDS_ST_DUO KEDS_ST_LN
 #endif
 
 namespace {
@@ -55,8 +63,10 @@ struct DuoEpi {
     f32x4 bc[4], cc[4];         // bias' / column sums of the lane's 16 columns: [j]
     const char* side;           // that unit's side area (LDS)
     char* out_tile;             // wave-uniform: first byte of that unit's output rows / columns
+    char* dbg_base;             // (KEDS_DUO_DBG bit 4 only)
     unsigned lane_off;          // (c N + 64 w + 8 g) * 2
-    bool live;                  // (uniform) false for the first unit of a workgroup: nothing to store
+    unsigned nrec;              // (uniform) records of the store descriptor: 0 for the first unit of a workgroup -- the range check
+                                // then DROPS the store, but it is still issued and counted (the K-tile waits count it)
 };
 
 // Single vector instructions (the compiler packs adjacent fp32 multiplies / adds / FMAs into v_pk_*_f32 under -O3, and a packed
@@ -82,9 +92,16 @@ __device__ __forceinline__ float add1(float a, float b) {
 //   v = acc * rstd + (colsum * (-mean rstd) + bias')          (the expression of pair_ln_epilogue, gemm.hip: same contraction)
 // QuickGELU: v * rcp(1 + exp2(-1.702 log2(e) v)).  One kind of instruction per gap, at most four plain or two transcendental
 // ones (8 issue cycles each) beside the gap's memory instruction.
-template <int EPI, int G, int J>
+// INLOOP = false (the last unit's epilogue, nothing beside it): plain C++ arithmetic -- there the stages of a sub-slice follow
+// each other directly, and the hazard recogniser does not see an inline-asm consumer of a transcendental result (no wait state
+// between v_exp_f32 / v_rcp_f32 and the asm instruction that reads it: measured as 16 wrong elements per 16 x 16 block of the
+// first pair, profiles/r05_duo_debug_v1.txt); inside the K-loop two MFMAs sit between any two stages.
+template <int EPI, int G, int J, bool INLOOP = true>
 __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
     constexpr bool GELU = epi_base(EPI) == KEDS_EPI_BIAS_QGELU_BF16;
+    auto fma_ = [](float a, float b, float c) { return INLOOP ? fma1(a, b, c) : __builtin_fmaf(a, b, c); };
+    auto mul_ = [](float a, float b) { return INLOOP ? mul1(a, b) : a * b; };
+    auto add_ = [](float a, float b) { return INLOOP ? add1(a, b) : a + b; };
     if constexpr (G == 0) {
         const int c = threadIdx.x & 15;
         const f32x2 cf = *reinterpret_cast<const f32x2*>(e.side + (16 * mi + c) * 8);
@@ -94,16 +111,16 @@ __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
     // (G == 1: the accumulator read-back, literal registers: KEDS_DUO_READ in the step macro)
     if constexpr (G == 3) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e.t[r] = fma1(e.cc[J][r], e.nm, e.bc[J][r]);
+        for (int r = 0; r < 4; ++r) e.t[r] = fma_(e.cc[J][r], e.nm, e.bc[J][r]);
     }
     if constexpr (G == 4) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) e.a[r] = fma1(e.a[r], e.rs, e.t[r]);
+        for (int r = 0; r < 4; ++r) e.a[r] = fma_(e.a[r], e.rs, e.t[r]);
     }
     if constexpr (GELU) {
         if constexpr (G == 5) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e.t[r] = mul1(e.a[r], -2.4554669595930157f);
+            for (int r = 0; r < 4; ++r) e.t[r] = mul_(e.a[r], -2.4554669595930157f);
         }
         if constexpr (G == 6 || G == 7) {
 #pragma unroll
@@ -111,7 +128,7 @@ __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
         }
         if constexpr (G == 8) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e.t[r] = add1(e.t[r], 1.0f);
+            for (int r = 0; r < 4; ++r) e.t[r] = add_(e.t[r], 1.0f);
         }
         if constexpr (G == 9 || G == 10) {
 #pragma unroll
@@ -119,7 +136,7 @@ __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
         }
         if constexpr (G == 11) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e.a[r] = mul1(e.a[r], e.t[r]);
+            for (int r = 0; r < 4; ++r) e.a[r] = mul_(e.a[r], e.t[r]);
         }
     }
     if constexpr (G == (GELU ? 12 : 5)) {
@@ -127,11 +144,27 @@ __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
         e.pk[2 * (J & 1)] = __builtin_bit_cast(unsigned, p0);
         e.pk[2 * (J & 1) + 1] = __builtin_bit_cast(unsigned, p1);
     }
-    if constexpr (G == (GELU ? 14 : 7) && (J & 1)) {
-        // 8 consecutive columns of row 16 mi + c: the 16-byte store of pair_ln_epilogue (same policy: read once by the next kernel)
-        if (e.live && !(KEDS_DUO_DBG & 8)) {
-            constexpr int aux = KEDS_ST_LN == 1 ? 2 : KEDS_ST_LN == 2 ? 17 : KEDS_ST_LN == 3 ? 18 : KEDS_ST_LN == 4 ? 16 : 0;
-            const auto rs = __builtin_amdgcn_make_buffer_rsrc(e.out_tile, 0, 0x7FFFFFFF, 0x00020000);
+    if constexpr (G == 15 && (J & 1)) {
+        // 8 consecutive columns of row 16 mi + c: the 16-byte store of pair_ln_epilogue.  The LAST memory instruction of its
+        // K-step, behind the step's last DMA piece: vmcnt retires in order and counts stores, and a store's acknowledgement takes
+        // longer than a K-tile -- issued in front of pieces the next K-tile wait needs, every such wait also waited for the
+        // store (first build: 192 us on the qkv shape against 161 without the stores, profiles/r05_duo_ablate_v1.txt).  Here it
+        // is YOUNGER than every piece that wait is for, and the wait leaves it in flight (vmcnt(7)).
+        if constexpr (!(KEDS_DUO_DBG & 8)) {
+            constexpr int aux = KEDS_ST_DUO == 1 ? 2 : KEDS_ST_DUO == 2 ? 17 : KEDS_ST_DUO == 3 ? 18 : KEDS_ST_DUO == 4 ? 16 : 0;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc(e.out_tile, 0, e.nrec, 0x00020000);
+            if constexpr (KEDS_DUO_DBG & 16) {
+                const auto r2 = __builtin_amdgcn_make_buffer_rsrc(e.dbg_base, 0, e.nrec, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.pk[0], e.pk[1], e.pk[2], e.pk[3]}, r2, (int)((threadIdx.x & 255) * 16),
+                                                       ((2 * mi + (J >> 1)) & 15) * 4096, aux);
+            } else if constexpr (KEDS_DUO_DBG & 32) {
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.pk[0], e.pk[1], e.pk[2], e.pk[3]}, rs, (int)((threadIdx.x & 63) * 16 + (threadIdx.x >> 6) * 1024),
+                                                       (16 * mi * N + 4096 * (J >> 1)) * 2, aux);
+            } else if constexpr (KEDS_DUO_DBG & 64) {
+                if (J == 1)
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.pk[0], e.pk[1], e.pk[2], e.pk[3]}, rs, (int)e.lane_off,
+                                                           (16 * mi * N + 32 * (J >> 1)) * 2, aux);
+            } else
             __builtin_amdgcn_raw_buffer_store_b128(u32x4{e.pk[0], e.pk[1], e.pk[2], e.pk[3]}, rs, (int)e.lane_off,
                                                    (16 * mi * N + 32 * (J >> 1)) * 2, aux);
         }
@@ -146,7 +179,7 @@ __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
     if constexpr ((r_) < 8) xn[(r_)] = *reinterpret_cast<const bf16x8*>(smem + xa_ + (r_) * 2048);             \
     else wn_[(r_) - 8] = *reinterpret_cast<const bf16x8*>(smem + wa_ + ((r_) - 8) * 2048);
 #define KEDS_DMEM(n_, xn, wn_, IH)                                                                             \
-    if constexpr ((n_) % 3 == 0) { if constexpr (!(KEDS_DUO_DBG & 2)) issue(6 * (IH) + (n_) / 3) }            \
+    if constexpr ((n_) % 3 == 0) { if constexpr (!(KEDS_DUO_DBG & 2) && !((KEDS_DUO_DBG & 128) && ((n_) / 3) % 2)) issue(6 * (IH) + (n_) / 3) } \
     else if constexpr (KEDS_DUO_DBG & 4) {}                                                                    \
     else if constexpr ((n_) == 1) { KEDS_DRD(0, xn, wn_) KEDS_DRD(1, xn, wn_) }                                                  \
     else if constexpr ((n_) == 2) { KEDS_DRD(2, xn, wn_) }                                                              \
@@ -184,13 +217,16 @@ __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
     KEDS_DMFMA(S, FIRST, j, 6, wc, xc) KEDS_DMFMA(S, FIRST, j, 7, wc, xc) KEDS_DGAP(4 * (j) + 3, xn, wn_, IH, SL, PS, MI, J)
 // One K-step: 32 MFMAs of set S from (xc, wc); the 12 fragment reads of the NEXT K-step go to (xn, wn_) from LDS byte offset
 // `rb` at chunk offset `nslot`; six DMA pieces (half IH of the issue cursor's K-tile); SL: sub-slice (MI, J) of set PS.
-// SYNC: the K-tile the next step reads has landed and every wave is done with the buffer the pieces go to -- the six youngest
-// memory operations (this K-tile's first six pieces; every store of the epilogue is older: it is issued in a SYNC step, in
-// front of that step's last piece) stay in flight.
+// SYNC: the K-tile the next step reads has landed and every wave is done with the buffer the pieces go to -- the youngest
+// memory operations stay in flight: this K-tile's first six pieces and, in front of them, the output store that closed the
+// previous K-tile when that one carried sub-slices (`pend_store`, uniform).
 #define KEDS_DUO_STEP(S, FIRST, xc, wc, xn, wn_, rb, nslot, SYNC, IH, SL, PS, MI, J)                           \
     {                                                                                                          \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
-        if constexpr (SYNC) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)\n\ts_barrier" ::: "memory");           \
+        if constexpr (SYNC) {                                                                                  \
+            if (pend_store) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(((KEDS_DUO_DBG & 128) ? 4 : 7) + ((KEDS_DUO_DBG & 256) ? 16 : 0)) : "memory"); \
+            else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(((KEDS_DUO_DBG & 128) ? 3 : 6) + ((KEDS_DUO_DBG & 256) ? 16 : 0)) : "memory"); \
+        }                                                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                     \
         const int xa_ = xlane + (rb) + (nslot), wa_ = wlane + (rb) + (nslot);                                  \
         const auto xrs_ = make_rs(xbase_i), wrs_ = make_rs(wbase_i);                                           \
@@ -216,6 +252,7 @@ __device__ __forceinline__ void duo_epi_gap(DuoEpi& e, int mi, int N) {
             KEDS_DUO_STEP(S, false, xb, wb, xa, wa, rb_nxt, slot0, true, 1, SL, PS, MI, JB)                    \
         }                                                                                                      \
         advance_issue()                                                                                        \
+        pend_store = (SL) && !(KEDS_DUO_DBG & 9);                                                              \
         const int t_ = rb_cur;                                                                                 \
         rb_cur = rb_nxt;                                                                                       \
         rb_nxt = rb_nn;                                                                                        \
@@ -337,6 +374,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_duo_kernel(const bf16_t* __res
 #undef KEDS_DUO_ISSUE_ALL
     asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
     int rb_cur = 0, rb_nxt = du::BUF, rb_nn = 2 * du::BUF;
+    bool pend_store = false;                                      // (uniform) the previous K-tile closed with an output store
     bf16x8 xa[8], wa[4], xb[8], wb[4];
 #pragma unroll
     for (int mi = 0; mi < 8; ++mi) xa[mi] = *reinterpret_cast<const bf16x8*>(smem + xlane + slot0 + mi * 2048);
@@ -344,9 +382,10 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_duo_kernel(const bf16_t* __res
     for (int j = 0; j < 4; ++j) wa[j] = *reinterpret_cast<const bf16x8*>(smem + wlane + slot0 + j * 2048);
 
     DuoEpi e;
-    e.live = false;
+    e.nrec = 0u;
     e.side = smem + du::SIDE0;
     e.out_tile = reinterpret_cast<char*>(out);
+    e.dbg_base = reinterpret_cast<char*>(out) + (size_t)blockIdx.x * 65536;
     e.lane_off = ((unsigned)c * (unsigned)N + (unsigned)(64 * wave + 8 * g)) * 2u;
     e.rs = e.nm = 0.f;
 #pragma unroll
@@ -356,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_duo_kernel(const bf16_t* __res
 
     // the epilogue context of the unit (rows m0u_, columns n0_, side area `area`) that just finished its K-loop
     auto epi_begin = [&](int m0u_, int n0_, int area) {
-        e.live = true;
+        e.nrec = 0x7FFFFFFFu;
         e.side = smem + du::SIDE0 + area * du::SIDE_BYTES;
         e.out_tile = reinterpret_cast<char*>(out) + ((size_t)m0u_ * N + n0_) * 2;
 #pragma unroll
@@ -408,12 +447,12 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_duo_kernel(const bf16_t* __res
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7\n\ts_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define KEDS_DUO_TAIL(MI, J)                                                                                   \
     {                                                                                                          \
-        duo_epi_gap<EPI, 0, J>(e, MI, N);                                                                      \
+        duo_epi_gap<EPI, 0, J, false>(e, MI, N);                                                               \
         KEDS_DUO_READ_1_##J##_##MI(e.a[0], e.a[1], e.a[2], e.a[3])                                             \
-        duo_epi_gap<EPI, 3, J>(e, MI, N); duo_epi_gap<EPI, 4, J>(e, MI, N); duo_epi_gap<EPI, 5, J>(e, MI, N);  \
-        duo_epi_gap<EPI, 6, J>(e, MI, N); duo_epi_gap<EPI, 7, J>(e, MI, N); duo_epi_gap<EPI, 8, J>(e, MI, N);  \
-        duo_epi_gap<EPI, 9, J>(e, MI, N); duo_epi_gap<EPI, 10, J>(e, MI, N); duo_epi_gap<EPI, 11, J>(e, MI, N); \
-        duo_epi_gap<EPI, 12, J>(e, MI, N); duo_epi_gap<EPI, 13, J>(e, MI, N); duo_epi_gap<EPI, 14, J>(e, MI, N); \
+        duo_epi_gap<EPI, 3, J, false>(e, MI, N); duo_epi_gap<EPI, 4, J, false>(e, MI, N); duo_epi_gap<EPI, 5, J, false>(e, MI, N); \
+        duo_epi_gap<EPI, 6, J, false>(e, MI, N); duo_epi_gap<EPI, 7, J, false>(e, MI, N); duo_epi_gap<EPI, 8, J, false>(e, MI, N); \
+        duo_epi_gap<EPI, 9, J, false>(e, MI, N); duo_epi_gap<EPI, 10, J, false>(e, MI, N); duo_epi_gap<EPI, 11, J, false>(e, MI, N); \
+        duo_epi_gap<EPI, 12, J, false>(e, MI, N); duo_epi_gap<EPI, 15, J, false>(e, MI, N);                    \
     }
 #define KEDS_DUO_TAIL_ROW(MI) KEDS_DUO_TAIL(MI, 0) KEDS_DUO_TAIL(MI, 1) KEDS_DUO_TAIL(MI, 2) KEDS_DUO_TAIL(MI, 3)
     KEDS_DUO_TAIL_ROW(0) KEDS_DUO_TAIL_ROW(1) KEDS_DUO_TAIL_ROW(2) KEDS_DUO_TAIL_ROW(3)

@@ -19,12 +19,26 @@ __device__ __forceinline__ int perm_w(int R) {
 }
 
 // KEDS_EPI_LN_*_H: the same epilogues with fp16 operands (A = the fp16 residual stream, W' folded to fp16)
-constexpr bool epi_f16(int e) { return e == KEDS_EPI_LN_BIAS_BF16_H || e == KEDS_EPI_LN_QGELU_BF16_H; }
-constexpr bool epi_is_ln(int e) { return e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_QGELU_BF16 || epi_f16(e); }
+// KEDS_EPI_X3_*: split-operand GEMMs (keds_hip.h): fp16 MFMA, three K segments (hi.hi, hi.lo, lo.hi) over two operand planes
+constexpr bool epi_x3(int e) { return e == KEDS_EPI_X3_BIAS_F32 || e == KEDS_EPI_X3_RESID_F32 || e == KEDS_EPI_X3_QGELU_PAIR; }
+constexpr bool epi_ln_h(int e) { return e == KEDS_EPI_LN_BIAS_BF16_H || e == KEDS_EPI_LN_QGELU_BF16_H; }
+constexpr bool epi_f16(int e) { return epi_ln_h(e) || epi_x3(e); }          // fp16 (not bf16) MFMA operands
+constexpr bool epi_is_ln(int e) { return e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_QGELU_BF16 || epi_ln_h(e); }
 constexpr int epi_base(int e) {
     return (e == KEDS_EPI_LN_BIAS_BF16 || e == KEDS_EPI_LN_BIAS_BF16_H)     ? KEDS_EPI_BIAS_BF16
            : (e == KEDS_EPI_LN_QGELU_BF16 || e == KEDS_EPI_LN_QGELU_BF16_H) ? KEDS_EPI_BIAS_QGELU_BF16
+           : e == KEDS_EPI_X3_BIAS_F32                                      ? KEDS_EPI_BIAS_F32
+           : e == KEDS_EPI_X3_RESID_F32                                     ? KEDS_EPI_BIAS_RESID_F32
                                                                             : e;
+}
+// K-tile p (of 3 * np1) of a split-operand GEMM: byte offset along K inside a plane, and which plane of A / W it reads
+struct X3Seg {
+    unsigned koff;      // bytes: (p mod np1) * 128
+    bool a_lo, w_lo;
+};
+__device__ __forceinline__ X3Seg x3_seg(int p, int np1) {
+    const int seg = (p >= np1) + (p >= 2 * np1);
+    return X3Seg{(unsigned)(p - seg * np1) * 128u, seg == 2, seg == 1};
 }
 
 constexpr float LN_EPS = 1e-5f;

@@ -177,8 +177,9 @@ struct Loader {
 };
 
 // resblocks of one tower (model.py:305-326): keys <prefix>transformer.resblocks.<i>.*
+// f32: 0 = bf16 / fp8 flows, 1 = KEDS_F32 (weights as stored), 2 = KEDS_F32X3 (the four weights as fp16 planes [2][N][K])
 int load_blocks(const Loader& L, const std::string& prefix, int width, int layers, std::vector<keds_block_params>& blocks,
-                bool fp8, bool f32 = false) {
+                bool fp8, int f32 = 0) {
     blocks.assign(layers, keds_block_params{});
     for (int i = 0; i < layers; ++i) {
         const std::string b = prefix + "transformer.resblocks." + std::to_string(i) + ".";
@@ -201,6 +202,18 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
             p.fc_w = f;
             if ((rc = L.mat<float>(b + "mlp.c_proj.weight", width, 4 * width, &f))) return rc;
             p.proj_w = f;
+            if (f32 == 2) {      // split every weight into its fp16 planes (the fp32 copies stay in the arena: 1.2 GB for ViT-L/14)
+                const void** slots[4] = {&p.qkv_w, &p.out_w, &p.fc_w, &p.proj_w};
+                const int n[4] = {3 * width, width, 4 * width, width}, k[4] = {width, width, width, 4 * width};
+                for (int j = 0; j < 4; ++j) {
+                    void* planes = L.mem.alloc((size_t)2 * n[j] * k[j] * 2);
+                    KEDS_REQUIRE(planes, "%s: out of device memory", L.what);
+                    if ((rc = keds_split_f16_pair((const float*)*slots[j], k[j], n[j], k[j], planes, (int64_t)n[j] * k[j], nullptr, nullptr)))
+                        return rc;
+                    *slots[j] = planes;
+                }
+                HIP_TRY(hipDeviceSynchronize(), L.what);
+            }
             continue;
         }
         if ((rc = L.mat<bf16_t>(b + "attn.in_proj_weight", 3 * width, width, &m))) return rc;
@@ -396,8 +409,8 @@ extern "C" int keds_ctx_destroy(keds_ctx* ctx) {
 extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_vit** out) {
     const char* what = "keds_vit_create";
     KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
-    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8 || compute == KEDS_F32,
-                 "%s: compute dtype must be KEDS_BF16, KEDS_FP8 or KEDS_F32", what);
+    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8 || compute == KEDS_F32 || compute == KEDS_F32X3,
+                 "%s: compute dtype must be KEDS_BF16, KEDS_FP8, KEDS_F32 or KEDS_F32X3", what);
     int rc = use_device(ctx, what);
     if (rc) return rc;
     Weights W(weights, n);
@@ -429,7 +442,7 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
         keds_set_error("%s: KEDS_FP8 needs a width that is a multiple of 256", what);
         return fail(KEDS_E_ARG);
     }
-    const bool f32 = compute == KEDS_F32;
+    const int f32 = compute == KEDS_F32 ? 1 : compute == KEDS_F32X3 ? 2 : 0;
     if ((rc = load_blocks(L, "visual.", width, layers, v->blocks, fp8, f32))) return fail(rc);
     keds_vit_params& p = v->p;
     memset(&p, 0, sizeof(p));
@@ -441,7 +454,7 @@ extern "C" int keds_vit_create(keds_ctx* ctx, const keds_tensor* weights, int n,
     p.tower.blocks = v->blocks.data();
     p.tower.last_cls_only = 1;
     p.tower.fp8 = fp8 ? 1 : 0;
-    p.tower.f32 = f32 ? 1 : 0;
+    p.tower.f32 = f32;
     p.resolution = grid * patch;
     p.patch = patch;
     const int kreal = 3 * patch * patch;
@@ -513,8 +526,8 @@ extern "C" int keds_vit_forward(keds_vit* vit, const void* image, int img_dtype,
 extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n, int compute, keds_text** out) {
     const char* what = "keds_text_create";
     KEDS_REQUIRE(weights && n > 0 && out, "%s: bad argument", what);
-    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8 || compute == KEDS_F32,
-                 "%s: compute dtype must be KEDS_BF16, KEDS_FP8 or KEDS_F32", what);
+    KEDS_REQUIRE(compute == KEDS_BF16 || compute == KEDS_FP8 || compute == KEDS_F32 || compute == KEDS_F32X3,
+                 "%s: compute dtype must be KEDS_BF16, KEDS_FP8, KEDS_F32 or KEDS_F32X3", what);
     int rc = use_device(ctx, what);
     if (rc) return rc;
     Weights W(weights, n);
@@ -540,7 +553,7 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
         return fail(KEDS_E_ARG);
     }
     const bool fp8 = compute == KEDS_FP8 && width % 256 == 0;
-    const bool f32 = compute == KEDS_F32;
+    const int f32 = compute == KEDS_F32 ? 1 : compute == KEDS_F32X3 ? 2 : 0;
     if ((rc = load_blocks(L, "", width, layers, t->blocks, fp8, f32))) return fail(rc);
     keds_text_params& p = t->p;
     memset(&p, 0, sizeof(p));
@@ -552,7 +565,7 @@ extern "C" int keds_text_create(keds_ctx* ctx, const keds_tensor* weights, int n
     p.tower.blocks = t->blocks.data();
     p.tower.last_cls_only = 0;
     p.tower.fp8 = fp8 ? 1 : 0;
-    p.tower.f32 = f32 ? 1 : 0;
+    p.tower.f32 = f32;
     p.vocab = vocab;
     p.embed_dim = embed;
     const bf16_t* proj_t = nullptr;

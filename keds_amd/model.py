@@ -84,7 +84,15 @@ class VisualTransformer(nn.Module):
 def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: bool = False,
                 fp8: bool = False, folded: bool = True, f32: bool = False) -> _lib.TowerParams:
     blocks = (_lib.BlockParams * tr.layers)()
-    wcast = _f32 if f32 else _bf16        # f32: the fp32-accurate flow (csrc/f32path.hip) multiplies the weights as stored
+    # f32 = 1: the fp32-accurate flow (csrc/f32path.hip) multiplies the weights as stored; f32 = 2 ("fp32x3"): the four block
+    # weights as PAIRS of fp16 planes [2, N, K] (w = hi + lo to 22 bits; keds_split_f16_pair) for the split-operand GEMMs
+    def _planes(w):
+        w32 = _f32(w)
+        n, k = w32.shape
+        out = torch.empty((2, n, k), dtype=torch.float16, device=w32.device)
+        check(load().keds_split_f16_pair(ptr(w32), k, n, k, ptr(out), n * k, None, stream()), "keds_split_f16_pair")
+        return out
+    wcast = _planes if f32 == 2 else _f32 if f32 else _bf16
     folded = folded and not f32
     for i, blk in enumerate(tr.resblocks):
         t = dict(
@@ -132,7 +140,7 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
         keep.append(t)
     keep.append(blocks)
     return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks, 1 if fp8 else 0,
-                            1 if cls_only else 0, 1 if f32 else 0)
+                            1 if cls_only else 0, int(f32))
 
 
 class _Packed:
@@ -146,7 +154,8 @@ class _Packed:
         P = v.patch_size
         kreal = 3 * P * P
         self.kpad = (kreal + 63) // 64 * 64
-        f32 = getattr(clip, "precision", "bf16") == "fp32"
+        prec = getattr(clip, "precision", "bf16")
+        f32 = 2 if prec == "fp32x3" else 1 if prec == "fp32" else 0      # (2: the block GEMMs on split fp16 operands, the rest as 1)
         wdt = torch.float32 if f32 else torch.bfloat16
         wcast = _f32 if f32 else _bf16
         self.f32 = f32
@@ -264,9 +273,13 @@ class CLIP(nn.Module):
         when its width is a multiple of 256 too, e.g. 768), or "fp32": the reference's own evaluation arithmetic
         (eval_retrieval.py:108-109, `--precision` params.py:227-232) -- no operand is rounded, every product runs on the
         f32-input matrix instruction, residual stream / LayerNorm / attention stay fp32 (csrc/f32path.hip).  About a tenth
-        of the default flow's throughput; embeddings agree with the fp32 reference to ~1e-6 and Recall@k is equal."""
-        if precision not in ("bf16", "fp8", "fp32"):
-            raise ValueError("precision must be 'bf16', 'fp8' or 'fp32'")
+        of the default flow's throughput; embeddings agree with the fp32 reference to ~1e-6 and Recall@k is equal.
+        "fp32x3" (round 5): the same fp32 flow with the four GEMMs of every block on SPLIT fp16 operands -- x = hi + lo
+        (22 significant bits), hi.hi + hi.lo + lo.hi on the fp16 matrix instruction, fp32 accumulate: fp32-grade embeddings
+        (Recall@k equal) at more than twice "fp32"'s throughput; values beyond the fp16 range (|x| >= 65504) send the model
+        back to "fp32" by themselves."""
+        if precision not in ("bf16", "fp8", "fp32", "fp32x3"):
+            raise ValueError("precision must be 'bf16', 'fp8', 'fp32' or 'fp32x3'")
         if precision == "fp8" and (self.visual.transformer.width % 256 != 0 or self.numerics == "safe"):
             raise ValueError("fp8 needs a vision width that is a multiple of 256 and the folded LayerNorm path")
         self.precision = precision
@@ -344,6 +357,24 @@ class CLIP(nn.Module):
             return run(self._engine())
         self._guard_poll(wait=False)
         eng = self._engine()
+        if self.precision == "fp32x3":
+            # split fp16 operands hold |x| < 65504 only: the split / LayerNorm kernels raise the guard flag beyond that, and a
+            # non-finite output says the MLP hidden layer went there -- either way this pass and all later ones run on the
+            # f32-input matrix instruction instead ("fp32": slower, no range limit).  Checked at once: a pass takes ~80 ms.
+            if self._guard is None or self._guard.device != eng.device:
+                self._guard = torch.zeros(1, dtype=torch.int32, device=eng.device)
+            lib = load()
+            check(lib.keds_numerics_guard_set(ptr(self._guard)), "keds_numerics_guard_set")
+            try:
+                out = run(eng)
+            finally:
+                check(lib.keds_numerics_guard_set(None), "keds_numerics_guard_set")
+            if int(self._guard.item()) == 0 and bool(torch.isfinite(out).all()):
+                return out
+            self._guard.zero_()
+            self.x3_range_trips = getattr(self, "x3_range_trips", 0) + 1
+            self.set_precision("fp32")
+            return run(self._engine())
         if self.numerics != "auto" or not eng.folded or self.precision in ("fp8", "fp32"):
             return run(eng)
         if self._guard is None or self._guard.device != eng.device:
@@ -689,7 +720,7 @@ class KnowledgeStream:
     def __call__(self, q: torch.Tensor, nbr_img: torch.Tensor, nbr_txt: torch.Tensor, precision: str = "bf16") -> torch.Tensor:
         """precision "fp32": the fp32-accurate flow (no operand rounding, keds_knowledge_run_f32) -- what
         compose_query_features passes when the CLIP model is on set_precision("fp32")."""
-        f32 = precision == "fp32"
+        f32 = precision in ("fp32", "fp32x3")
         kp = _lib.KnowledgeParams(self.img2text.params(f32), self.retrieval_fuse.params(f32), self.text_condition.params(f32))
         lib = load()
         B, K, dim = nbr_img.shape

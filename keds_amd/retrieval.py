@@ -169,7 +169,7 @@ def compose_query_features(model: CLIP, stream_image: KnowledgeStream, stream_te
             repeat=repeat, w_text_stream=w_text_stream, verify=False))
     q = model.encode_image(ref_images).float()
     topk_image, topk_text = get_retrieved_features(q, database, None, topk=topk)
-    prec = "fp32" if getattr(model, "precision", "bf16") == "fp32" else "bf16"       # fp32: no operand is rounded anywhere
+    prec = "fp32" if getattr(model, "precision", "bf16") in ("fp32", "fp32x3") else "bf16"   # fp32: no operand is rounded anywhere
     tok_a = stream_image(q, topk_image, topk_text, precision=prec)                   # [B,3,D]
     tok_b = stream_text(q, topk_image, topk_text, precision=prec)
     if not repeat and text_with_blank.shape[0] == tok_a.shape[0] == tok_b.shape[0]:

@@ -26,7 +26,13 @@ TINY = dict(embed_dim=128, image_resolution=56, vision_layers=2, vision_width=12
 VITL = dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024, vision_patch_size=14,
             context_length=77, vocab_size=49408, transformer_width=768, transformer_layers=12)
 REL_F32 = 1e-5          # the stated tolerance of this mode against the reference's fp32 outputs
+REL_X3 = 2e-5           # ... and of "fp32x3" (round 5): the block GEMMs on split fp16 operands (22-bit hi + lo, three products)
+MODES = ("fp32", "fp32x3")
 KS = (1, 5, 10, 50, 100)
+
+
+def _rel(mode):
+    return REL_F32 if mode == "fp32" else REL_X3
 
 
 def _close32(name, got, want, rel=REL_F32):
@@ -117,28 +123,38 @@ def test_tiny_clip_fp32_matches_reference_golden():
     _close32("fp32.tiny.encode_image.again", m.encode_image(img), g["encode_image"])
 
 
-def test_vitl14_fp32_embeddings_within_1e_5_of_the_reference():
-    """ViT-L/14 (24 x 1024) + the 12-layer text tower at B = 2 against the reference's own fp32 outputs (clip_vitl14.npz)."""
+@pytest.mark.parametrize("mode", MODES)
+def test_vitl14_fp32_embeddings_within_1e_5_of_the_reference(mode):
+    """ViT-L/14 (24 x 1024) + the 12-layer text tower at B = 2 against the reference's own fp32 outputs (clip_vitl14.npz):
+    rel-L2 <= 1e-5 in "fp32" mode, <= 2e-5 in "fp32x3" mode (B = 33 and B = 130 send rows through the 256 x 256 kernel too)."""
     g = dict(np.load(golden_path("clip_vitl14.npz")))
     sd = O.synth_clip_state_dict(**VITL, seed=7)
-    m = keds_amd.build_model(sd, fp16=False).cuda().set_precision("fp32")
+    m = keds_amd.build_model(sd, fp16=False).cuda().set_precision(mode)
     del sd
     img, text = torch.from_numpy(g["image"]).cuda(), torch.from_numpy(g["text"]).cuda()
-    _close32("fp32.vitl.encode_image", m.encode_image(img), g["encode_image"])
-    _close32("fp32.vitl.encode_text", m.encode_text(text), g["encode_text"])
-    _close32("fp32.vitl.eti3", m.encode_text_img_retrieval(text, torch.from_numpy(g["tok3"]).cuda(), split_ind=265, repeat=False), g["eti3"])
-    _close32("fp32.vitl.eti2", m.encode_text_img_retrieval(text, torch.from_numpy(g["tok2"]).cuda(), split_ind=265, repeat=False), g["eti2"])
-    big = torch.cat([img, torch.from_numpy(O.synth_tensor("imgs", [31, 3, 224, 224], 1.0).numpy()).cuda()])
-    _close32("fp32.vitl.encode_image.in_B33", m.encode_image(big)[:2], g["encode_image"])
+    r = _rel(mode)
+    _close32(f"{mode}.vitl.encode_image", m.encode_image(img), g["encode_image"], r)
+    assert m.precision == mode and m._engine().vit.tower.f32 == (1 if mode == "fp32" else 2)
+    _close32(f"{mode}.vitl.encode_text", m.encode_text(text), g["encode_text"], r)
+    _close32(f"{mode}.vitl.eti3", m.encode_text_img_retrieval(text, torch.from_numpy(g["tok3"]).cuda(), split_ind=265, repeat=False), g["eti3"], r)
+    _close32(f"{mode}.vitl.eti2", m.encode_text_img_retrieval(text, torch.from_numpy(g["tok2"]).cuda(), split_ind=265, repeat=False), g["eti2"], r)
+    big = torch.cat([img, torch.from_numpy(O.synth_tensor("imgs", [128, 3, 224, 224], 1.0).numpy()).cuda()])
+    _close32(f"{mode}.vitl.encode_image.in_B33", m.encode_image(big[:33])[:2], g["encode_image"], r)
+    if mode == "fp32x3":
+        _close32(f"{mode}.vitl.encode_image.in_B130", m.encode_image(big)[:2], g["encode_image"], r)
+        many = torch.from_numpy(np.tile(g["text"], (64, 1))).cuda()
+        _close32(f"{mode}.vitl.encode_text.in_B128", m.encode_text(many)[:2], g["encode_text"], r)
+        assert m.precision == mode and getattr(m, "x3_range_trips", 0) == 0          # nothing left the fp16 range
 
 
-def test_recall_at_k_vitl14_1k_gallery_is_equal_in_fp32_mode():
+@pytest.mark.parametrize("mode", MODES)
+def test_recall_at_k_vitl14_1k_gallery_is_equal_in_fp32_mode(mode):
     """BASELINE config 1 / north_star "Recall@k equal to the CPU reference on identical inputs": the reference-minted
     fixture recall_vitl14.npz (1,000 gallery images + 256 queries through ViT-L/14, recalls from the reference's own
     get_metrics_cirr, src/eval_utils.py:1040-1067).  In fp32 mode NO (query, k) outcome may differ: 0 of 1,280."""
     g = dict(np.load(golden_path("recall_vitl14.npz")))
     sd = O.sharpen_clip(O.synth_clip_state_dict(**VITL, seed=7))
-    m = keds_amd.build_model({k: v for k, v in sd.items()}, fp16=False).cuda().set_precision("fp32")
+    m = keds_amd.build_model({k: v for k, v in sd.items()}, fp16=False).cuda().set_precision(mode)
     del sd
     G, Q = g["gallery"].shape[0], g["query"].shape[0]
     tgt, ref, sigma = O.synth_recall_plan(G, Q)
@@ -146,8 +162,8 @@ def test_recall_at_k_vitl14_1k_gallery_is_equal_in_fp32_mode():
                      for i in range(0, G, 125)])
     qf = torch.cat([m.encode_image(O.synth_recall_queries(tgt, sigma, start=i, count=min(128, Q - i)).cuda(), normalize=True)
                     for i in range(0, Q, 128)])
-    _close32("fp32.recall_vitl14.gallery_features", gal, g["gallery"])
-    _close32("fp32.recall_vitl14.query_features", qf, g["query"])
+    _close32(f"{mode}.recall_vitl14.gallery_features", gal, g["gallery"], _rel(mode))
+    _close32(f"{mode}.recall_vitl14.query_features", qf, g["query"], _rel(mode))
     index_names = [f"/data/cirr/dev/img_{i:05d}.png" for i in range(G)]
     ref_names = [os.path.basename(index_names[i]) for i in ref]
     tgt_names = [os.path.basename(index_names[i]) for i in tgt]
@@ -160,28 +176,31 @@ def test_recall_at_k_vitl14_1k_gallery_is_equal_in_fp32_mode():
     rank_r = (dr < dr[rows, tg][:, None]).sum(1)
     rank_g = (dg < dg[rows, tg][:, None]).sum(1)
     flipped = sum(int(((rank_r < k) != (rank_g < k)).sum()) for k in KS)
-    report("recall_vitl14.fp32", **{f"R@{k}": got[f"recall_R@{k}"] for k in KS},
+    report(f"recall_vitl14.{mode}", **{f"R@{k}": got[f"recall_R@{k}"] for k in KS},
            **{f"ref_R@{k}": float(g[f"recall_R_at_{k}"]) for k in KS}, target_rank_changes=int((rank_r != rank_g).sum()),
            outcomes_flipped_inside_tolerance=flipped)
-    assert flipped == 0, f"{flipped} of {Q * len(KS)} (query, k) outcomes differ from the reference in fp32 mode"
+    assert flipped == 0, f"{flipped} of {Q * len(KS)} (query, k) outcomes differ from the reference in {mode} mode"
+    assert m.precision == mode
     for k in KS:
         assert abs(got[f"recall_R@{k}"] - float(g[f"recall_R_at_{k}"])) < 1e-9, f"Recall@{k} differs from the reference"
 
 
-def test_session_handles_run_the_fp32_flow_with_kedsf32_compute():
-    """The handle layer of the C ABI (keds_vit_create / keds_text_create with compute = KEDS_F32) returns the same bits as
-    the torch facade in fp32 mode."""
+@pytest.mark.parametrize("mode", MODES)
+def test_session_handles_run_the_fp32_flow_with_kedsf32_compute(mode):
+    """The handle layer of the C ABI (keds_vit_create / keds_text_create with compute = KEDS_F32 / KEDS_F32X3) returns the same
+    bits as the torch facade in that mode."""
     from keds_amd import session
     g = dict(np.load(golden_path("clip_tiny.npz")))
     sd = O.synth_clip_state_dict(**TINY, seed=7)
-    m = keds_amd.build_model(dict(sd), fp16=False).cuda().set_precision("fp32")
+    m = keds_amd.build_model(dict(sd), fp16=False).cuda().set_precision(mode)
+    DT = _lib.DT_F32 if mode == "fp32" else _lib.DT_F32X3
     img = torch.from_numpy(g["image"]).cuda()
     want = m.encode_image(img)
     ctx = session.Context(0)
     try:
-        vit = session.Vit(ctx, sd, compute=_lib.DT_F32)
+        vit = session.Vit(ctx, sd, compute=DT)
         assert torch.equal(vit.forward(img), want)
-        txt = session.Text(ctx, sd, compute=_lib.DT_F32)
+        txt = session.Text(ctx, sd, compute=DT)
         text = torch.from_numpy(g["text"]).cuda()
         eot = (text == TINY["vocab_size"] - 1).to(torch.int32).argmax(dim=1)
         assert torch.equal(txt.forward(text, eot), m.encode_text(text))
@@ -220,24 +239,79 @@ def test_cirr_batch_composition_tiny_in_fp32_mode():
     assert int(same.min()) == 16                                  # every retrieved row is the reference's
 
 
-def test_dual_stream_composed_query_full_size_in_fp32_mode():
+@pytest.mark.parametrize("mode", MODES)
+def test_dual_stream_composed_query_full_size_in_fp32_mode(mode):
     """BASELINE config 4 at full size (ViT-L/14, 8 queries, two 0.5 M x 768 databases, two stream checkpoints) in fp32 mode:
     the composed features within 1e-5 of the reference's, the 16 neighbours of every query in both databases the reference's."""
     g = dict(np.load(golden_path("dual_vitl14_full.npz")))
     B, n_db, dim, middle = int(g["batch"]), int(g["n_db"]), 768, 512
     sd = O.synth_clip_state_dict(**VITL, seed=7)
-    m = keds_amd.build_model({k: v for k, v in sd.items()}, fp16=False).cuda().set_precision("fp32")
+    m = keds_amd.build_model({k: v for k, v in sd.items()}, fp16=False).cuda().set_precision(mode)
     del sd
     database = keds_amd.build_database(O.synth_database(n_db, dim, seed=2002), O.synth_database(n_db, dim, seed=2003, clustered=True),
                                        None, device="cuda")
     img = torch.from_numpy(np.random.RandomState(1001).standard_normal((B, 3, 224, 224)).astype(np.float32)).cuda()
     txt = O.synth_tokens(B, seed=4004).cuda()
     out = keds_amd.compose_query_features(m, _streams(dim, middle, 21), _streams(dim, middle, 22), img, txt, database, id_split=265)
-    _close32("fp32.dual_full.query_image_features", out["query_image_features"], g["query_image_features"])
+    _close32(f"{mode}.dual_full.query_image_features", out["query_image_features"], g["query_image_features"], _rel(mode))
     for name, index, Iref in (("image", database[3], g["I_image"]), ("text", database[4], g["I_text"])):
         _, I, _ = index.search_gather(out["query_image_features"], 16, normalize=True)
         same = sum(set(I[r].tolist()) == set(Iref[r, :16].tolist()) for r in range(B))
-        report(f"fp32.dual_full.neighbour_sets_identical.{name}", rows=int(same), of=B)
+        report(f"{mode}.dual_full.neighbour_sets_identical.{name}", rows=int(same), of=B)
         assert same == B
     for key in [k for k in ("composed", "image", "mixture", "tokens_image_stream", "tokens_text_stream") if k in g]:
-        _close32(f"fp32.dual_full.{key}", out[key], g[key])
+        _close32(f"{mode}.dual_full.{key}", out[key], g[key], _rel(mode))
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 256, 64), (129, 128, 1024), (4352 + 96, 1024, 1024), (2048, 4096, 1024), (1280, 1024, 4096)])
+def test_gemm_x3_every_epilogue_against_float64(M, N, K):
+    """keds_gemm_x3 (round 5): both operands as pairs of fp16 planes (x = hi + lo, keds_split_f16_pair), the product as
+    hi.hi + hi.lo + lo.hi on the fp16 MFMA with fp32 accumulation.  Against float64 on the ORIGINAL fp32 operands: the error of a
+    length-K dot product stays at fp32 grade (the dropped lo.lo term is 2^-22 relative) -- asserted relative to sum |a||w|, the
+    scale rounding errors live on.  Shapes cover the 128 x 128 kernel, the 256 x 256 kernel + its remainder launch, K = 4096;
+    epilogues: bias -> fp32, in-place fp32 residual, QuickGELU -> fp16 planes (the next GEMM's operand)."""
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device="cuda") * 2.0
+    a[:, ::97] *= 30.0                                                     # a few large columns: hi / lo of very different size
+    w = torch.randn(N, K, generator=g, device="cuda") * K ** -0.5
+    b = torch.randn(N, generator=g, device="cuda") * 0.1
+    Mp = (M + 255) // 256 * 256
+
+    def planes(x, rows_pad):
+        r, c = x.shape
+        out = torch.zeros((2, rows_pad, c), dtype=torch.float16, device="cuda")
+        flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.check(lib.keds_split_f16_pair(_lib.ptr(x), c, r, c, _lib.ptr(out), rows_pad * c, _lib.ptr(flag), _lib.stream()), "split")
+        assert int(flag.item()) == 0
+        return out
+    a2, w2 = planes(a, Mp), planes(w, N)
+    # the planes really are x = hi + lo to 22 bits (lo may be a subnormal fp16: absolute 2^-25)
+    rec = a2[0, :M].double() + a2[1, :M].double()
+    assert float(((rec - a.double()).abs() / (a.double().abs() * 2.0 ** -21 + 2.0 ** -24)).max()) <= 1.0
+    want = a.double() @ w.double().t() + b.double()
+    scale = (a.double().abs() @ w.double().abs().t()) + 1e-30              # sum |a||w| per output
+    _lib.ensure_gemm_workspace("cuda")
+    out = torch.zeros((Mp, N), dtype=torch.float32, device="cuda")
+    _lib.check(lib.keds_gemm_x3(_lib.ptr(a2), Mp * K, K, _lib.ptr(w2), N * K, _lib.ptr(b), _lib.ptr(out), N, M, N, K,
+                                _lib.EPI_X3_BIAS_F32, 0, _lib.stream()), "x3 bias")
+    err = float(((out[:M].double() - want).abs() / scale).max())
+    f32 = a @ w.t() + b
+    err_f32 = float(((f32.double() - want).abs() / scale).max())
+    report("gemm_x3", M=M, N=N, K=K, max_err_over_sum_abs=err, torch_fp32_same_metric=err_f32, rel_l2=rel_l2(out[:M], want))
+    rel_f32 = rel_l2(f32, want)
+    report("gemm_x3.rel", M=M, N=N, K=K, rel_l2=rel_l2(out[:M], want), torch_fp32_rel_l2=rel_f32)
+    # as good as torch's own fp32 GEMM on both metrics (fp32 accumulation over K is what is left: ~1.5e-6 at K = 4096 for either)
+    assert err <= 2.0 * err_f32 + 1e-7 and rel_l2(out[:M], want) <= 1.5 * rel_f32 + 2e-7
+    assert bool((out[M:] == 0).all())
+    res = torch.randn(Mp, N, generator=g, device="cuda")
+    r0 = res.clone()
+    _lib.check(lib.keds_gemm_x3(_lib.ptr(a2), Mp * K, K, _lib.ptr(w2), N * K, _lib.ptr(b), _lib.ptr(res), N, M, N, K,
+                                _lib.EPI_X3_RESID_F32, 0, _lib.stream()), "x3 resid")
+    assert rel_l2(res[:M], r0[:M].double() + want) <= 1.5 * rel_f32 + 2e-7 and torch.equal(res[M:], r0[M:])
+    pair = torch.zeros((2, Mp, N), dtype=torch.float16, device="cuda")
+    _lib.check(lib.keds_gemm_x3(_lib.ptr(a2), Mp * K, K, _lib.ptr(w2), N * K, _lib.ptr(b), _lib.ptr(pair), N, M, N, K,
+                                _lib.EPI_X3_QGELU_PAIR, Mp * N, _lib.stream()), "x3 gelu")
+    gelu = want * torch.sigmoid(1.702 * want)
+    got = pair[0, :M].double() + pair[1, :M].double()
+    assert rel_l2(got, gelu) <= 2.0 * rel_f32 + 1e-6

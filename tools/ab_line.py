@@ -6,4 +6,4 @@ d = json.loads(sys.stdin.read())
 st = d["stage_ms_per_step"]
 ws = d["roofline_scan"].get("whole_search") or {}
 print("   %.0f img/s  %.3f ms/step  gemm %.3f ms  attn %.3f ms  frac %.4f  search %.1f us  guard tripped: %s" % (
-    d["value"], d["ms_per_step"], st["gemm"], st["attention"], d["roofline"]["frac"], ws.get("ms", 0.0) * 1e3, d["numerics_guard"]["tripped"]))
+    d["value"], d["ms_per_step"], st["gemm"] or 0.0, st["attention"] or 0.0, d["roofline"]["frac"], ws.get("ms", 0.0) * 1e3, d["numerics_guard"]["tripped"]))
