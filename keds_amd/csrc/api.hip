@@ -26,7 +26,7 @@ int keds_check_launch(const char* what) {
 
 extern "C" int keds_abi_version(void) { return KEDS_ABI_VERSION; }
 // the compiler flags this library was built with BEYOND the Makefile's defaults (the -D switches of a timing-only or A/B
-// build: tools/ab_build.sh, tools/r05_noepi_bound.sh); "" for the product build.  keds_amd._lib.source_digest folds it into
+// build: tools/ab_build.sh, tools/rounds/r05_noepi_bound.sh); "" for the product build.  keds_amd._lib.source_digest folds it into
 // the digest that ties committed measurements to a build, so evidence taken on a variant build is never accepted as "this build".
 #ifndef KEDS_BUILD_EXTRA
 #define KEDS_BUILD_EXTRA ""

@@ -22,6 +22,9 @@ int keds_gemm_duo_launch(int epi, const void* A, const void* W, const float* bia
 #ifndef KEDS_QUAD_NOEPI
 #define KEDS_QUAD_NOEPI 0
 #endif
+#ifndef KEDS_QUAD_TIDDMA
+#define KEDS_QUAD_TIDDMA 0
+#endif
 
 namespace {
 
@@ -760,6 +763,17 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
 }
 
 int g_no_split = 0;   // test hook
+// thread-local request of the calling composite (towers.hip): small launches take the 64 KiB kernel form; KEDS_SMALL_NST=2 in the
+// environment forces it everywhere (A/B)
+thread_local int tl_small_lds = 0;
+bool keds_small_lds_scope() {
+    static int env = -1;
+    if (env < 0) {
+        const char* e = getenv("KEDS_SMALL_NST");
+        env = e && e[0] == '2';
+    }
+    return env || tl_small_lds;
+}
 
 template <int EPI>
 int launch_small(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
@@ -774,10 +788,13 @@ int launch_small(const void* A, const void* W, const float* bias, void* out, int
         while (splits < 16 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
         const size_t need = (size_t)splits * ((M + BM - 1) / BM * BM) * N * sizeof(float);
         if (splits > 1 && need <= g_ws_bytes)
-            return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, splits, lda, ldc, st);
+            return keds_small_lds_scope() ? launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, aux2, splits, lda, ldc, st)
+                                          : launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, splits, lda, ldc, st);
     }
-    // fewer workgroups than 2 per CU: nothing else hides the DMA latency, so use the deep ring
-    if (tiles < 512) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
+    // fewer workgroups than 2 per CU: nothing else hides the DMA latency, so use the deep ring -- unless the launch is meant to run
+    // BESIDE another kernel's workgroups (the towers' remainder-row chain beside the attention launch, round 5): the deep ring's
+    // 128 KiB of LDS needs an EMPTY CU, the two-deep ring's 64 KiB fits next to one resident attention workgroup (74 KiB)
+    if (tiles < 512 && !keds_small_lds_scope()) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
     return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
 }
 
@@ -1155,7 +1172,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
 #ifndef KEDS_QUAD_ORDER
 #define KEDS_QUAD_ORDER 1
 #endif
-// TIMING ONLY (tools/r05_noepi_bound.sh): KEDS_QUAD_FILL plain + KEDS_QUAD_FILLX transcendental vector instructions in EVERY gap
+// TIMING ONLY (tools/rounds/r05_noepi_bound.sh): KEDS_QUAD_FILL plain + KEDS_QUAD_FILLX transcendental vector instructions in EVERY gap
 // of the K-loop -- how much epilogue arithmetic the gaps between the MFMA pairs can carry before the K-tile grows
 #ifndef KEDS_QUAD_FILL
 #define KEDS_QUAD_FILL 0
@@ -1287,18 +1304,44 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     // ONE loop-invariant VGPR per operand, the piece / K-tile part a scalar -- no vector add per piece
     // (a macro, not a lambda: a lambda RETURNING the descriptor type makes hipcc 7.2 drop the kernel's host-side stub without
     // a diagnostic -- every instantiation then links as an undefined symbol)
+#if KEDS_QUAD_TIDDMA   // TIMING ONLY (tools/rounds/r05_tid_dma.sh): what the K-loop would cost if a DMA piece needed NO address VGPR -- the
+    // descriptor adds the lane id itself (ADD_TID_ENABLE, stride 16: lane l reads base + offset + 16 l, a contiguous 1 KiB: the
+    // traffic shape of a tiled operand layout in which a piece is contiguous in memory).  Wrong operands, same bytes.
+#define make_rs_tid(base) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(base)), 16, 0x7FFFFFFF, 0x00800000)
+#define make_rs_lin(base) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(base)), 0, 0x7FFFFFFF, 0x00020000)
+#define make_rs(base) make_rs_lin(base)
+#define make_rsx(base) ((KEDS_QUAD_TIDDMA & 1) ? make_rs_tid(base) : make_rs_lin(base))
+#define make_rsw(base) ((KEDS_QUAD_TIDDMA & 2) ? make_rs_tid(base) : make_rs_lin(base))
+#else
 #define make_rs(base) __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(static_cast<const void*>(base)), 0, 0x7FFFFFFF, 0x00020000)
+#define make_rsx(base) make_rs(base)
+#define make_rsw(base) make_rs(base)
+#endif
     // (xrs / wrs: buffer descriptors of the CURRENT tile's operand panels; re-pointed at the next tile once this tile's last
     // piece has been requested)
-    auto xrs = make_rs(X), wrs = make_rs(W);
+    auto xrs = make_rsx(X), wrs = make_rsw(W);
     auto issue = [&](int p, int q) {                               // DMA piece q (0..15: X pieces 0..7, W pieces 0..7) of K-tile p
         const int i = q & 7;
         char* dst = smem + (p & 1) * PBUF_BYTES + (q < 8 ? 0 : OP_BYTES) + (wave + 4 * i) * 1024;
         const unsigned so = i * rstride + (unsigned)p * (TK * 2);
+#if KEDS_QUAD_TIDDMA
+        if (q < 8) {
+            if (KEDS_QUAD_TIDDMA & 1)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, 0, so + (unsigned)wave * 8u * (unsigned)K * 2u, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff, so, 0, 0);
+        } else {
+            if (KEDS_QUAD_TIDDMA & 2)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, 0, so + (unsigned)wave * 8u * (unsigned)K * 2u, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, woff, so, 0, 0);
+        }
+#else
         if (q < 8)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff, so, 0, 0);
         else
             __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, woff, so, 0, 0);
+#endif
     };
     const int f = (c >> 1) & 7;
     const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
@@ -1346,8 +1389,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     int tm, tn;
     quad_tile_coords(xcd_remap(id, ntiles), m_tiles, n_tiles, tm, tn);
     int m0 = tm * TM, n0 = tn * TN;
-    xrs = make_rs(X + (size_t)m0 * K);
-    wrs = make_rs(W + (size_t)n0 * K);
+    xrs = make_rsx(X + (size_t)m0 * K);
+    wrs = make_rsw(W + (size_t)n0 * K);
     side_request(m0, n0);
 #pragma unroll
     for (int q = 0; q < 16; ++q) issue(0, q);
@@ -1438,8 +1481,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
                 pc = bias[N + nn0 + tid];
             }
             if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) pb = bias ? bias[nn0 + tid] : 0.f;
-            xrs = make_rs(X + (size_t)nm0 * K);
-            wrs = make_rs(W + (size_t)nn0 * K);
+            xrs = make_rsx(X + (size_t)nm0 * K);
+            wrs = make_rsw(W + (size_t)nn0 * K);
 #pragma unroll
             for (int q = 0; q < 16; ++q) issue(0, q);
 #pragma unroll
@@ -1451,7 +1494,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         [[maybe_unused]] const bool defer_now = more && aux_i != 0 && np >= 8;
         [[maybe_unused]] void* stamp_out = aux2;
         void* aux2e = STAMP ? nullptr : aux2;                             // (stamped build: aux2 carries the stamp buffer)
-#if KEDS_QUAD_NOEPI   // TIMING ONLY (-DKEDS_QUAD_NOEPI=1, tools/r05_noepi_bound.sh): no read-back, no epilogue arithmetic, no stores
+#if KEDS_QUAD_NOEPI   // TIMING ONLY (-DKEDS_QUAD_NOEPI=1, tools/rounds/r05_noepi_bound.sh): no read-back, no epilogue arithmetic, no stores
         if (more) { id = nid; m0 = nm0; n0 = nn0; side_write(smem + qd::SIDE0 + ((it + 1) & 1) * 4096, n0);
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); continue; }
         break;
@@ -1925,6 +1968,8 @@ int launch_gemm(const void* A, const void* W, const float* bias, void* out, int 
 // true when a dense [M,K] x [N,K]^T problem sends its full 256-row tiles to the 256^2 kernel (and M % 256 rows to a
 // second, small launch): the towers then run those remainder rows as their own chain on the side lane
 bool keds_gemm_splits_rows(int M, int N, int K) { return big_tiles_ok(M, N, K) && M % pr::TM != 0; }
+// (towers.hip) small GEMM launches of the calling thread take the 64 KiB-LDS kernel form while `on`
+void keds_gemm_small_lds(int on) { tl_small_lds = on; }
 
 extern "C" int keds_gemm_force_small(int on) {
     g_force_small = on & 1;

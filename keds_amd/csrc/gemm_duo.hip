@@ -27,7 +27,7 @@
 #include "gemm_shared.h"
 #include "gemm_duo_gen.h"
 
-// TIMING ONLY (make EXTRA="-DKEDS_DUO_DBG=n", tools/r05_duo_ablate.sh; results are wrong): bit 0 = no sub-slices (the K-loop alone),
+// TIMING ONLY (make EXTRA="-DKEDS_DUO_DBG=n", tools/rounds/r05_duo_ablate.sh; results are wrong): bit 0 = no sub-slices (the K-loop alone),
 // bit 1 = no DMA pieces, bit 2 = no fragment reads, bit 3 = sub-slices without their stores; what a store costs, and why:
 // bit 4 = every store of a workgroup into the same 64 KiB (never leaves L2 with the plain policy), bit 5 = lane-linear
 // addresses (one store instruction = 1 KiB contiguous = 8 whole lines instead of 16 half lines), bit 6 = every other store only,

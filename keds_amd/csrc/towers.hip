@@ -16,6 +16,7 @@ int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const floa
                            int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream);
 
 bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
+void keds_gemm_small_lds(int on);                  // gemm.hip: small GEMM launches of this thread take the 64 KiB-LDS kernel form
 
 // f32path.hip: the fp32-accurate flow (keds_tower_params.f32)
 size_t keds_tower_f32_workspace_bytes(int width, int seq, int B);
@@ -303,6 +304,15 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         // beside an attention workgroup either, so the wait only moves.
         const int b_tail = lanes.split && tail_attention_on_side() ? Mm / S : B;      // first tail sample (B: none)
         const bool tail_side = b_tail > 0 && b_tail < B;
+        // Round 5: with the tail samples' attention on the side lane the WHOLE remainder chain of a block (out-proj, c_fc, c_proj,
+        // the next in_proj of the remainder rows) starts beside the main ATTENTION launch instead of beside the main GEMMs, whose
+        // one-wave-per-SIMD workgroups own every register of their CU -- provided its workgroups fit next to a resident attention
+        // workgroup (74 KiB of LDS, half the CU's registers): the 64 KiB kernel form (keds_gemm_small_lds) instead of the 128 KiB one.
+        struct SmallLds {
+            bool on;
+            explicit SmallLds(bool o) : on(o) { if (on) keds_gemm_small_lds(1); }
+            ~SmallLds() { if (on) keds_gemm_small_lds(0); }
+        } small_lds(tail_side);
         for (int l = 0; l < p->layers; ++l) {
             const keds_block_params& k = p->blocks[l];
             const bool last = l == p->layers - 1;

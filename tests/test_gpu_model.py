@@ -469,7 +469,8 @@ def test_text_tower_does_only_the_work_that_reaches_the_readout(size, tiny_model
       * the read-out-row TAIL (mode 1 = cut + tail) runs the last block's second half in the fp32-stream form (stand-alone
         LayerNorm, fp32 residual: what the ViT's CLS tail does) where the all-rows flow uses the folded form on the fp16
         stream: two roundings of the same fp32 function, asserted inside the operand-rounding class;
-      * in fp32 mode (no operand rounding) all flows agree to 2e-6.
+      * in fp32 mode (no operand rounding) all flows agree to 2e-6 (measured: equal bits); in fp8 mode the cut changes which rows
+        run on MXFP8 operands (full 256-row tiles) and which on bf16 (remainder rows): the fp8 tower's own error class.
     Ragged EOT sweep: EOT at column 6 (with the splice: read-out at 8), 40, 73 (the last column a 3-token splice allows), mixed."""
     from keds_amd import _lib
     lib = _lib.load()
@@ -511,8 +512,8 @@ def test_text_tower_does_only_the_work_that_reaches_the_readout(size, tiny_model
                                bit_equal=bool(torch.equal(out[mode], out[0])), min_cosine=c, rel_l2=r)
                         if precision == "fp32":
                             assert r <= 2e-6, (size, tag, name, what, r)
-                        elif precision == "fp8":
-                            assert c >= 0.999 and r <= 4e-2, (size, precision, tag, name, what, c, r)
+                        elif precision == "fp8":      # which rows sit in full 256-row tiles (MXFP8) and which in the remainder (bf16)
+                            assert c >= 0.99 and r <= 0.15, (size, precision, tag, name, what, c, r)    # changes with the cut: fp8's own class
                         elif mode == 2 and size == "tiny":
                             assert torch.equal(out[mode], out[0]), (size, precision, tag, name, what, c, r)     # measured: equal bits
                         else:               # (ViT-L/14 width: small-M launches split K, another summation order -- the batch-size sweep's class)

@@ -1,5 +1,5 @@
 #!/bin/bash
-# copy the files of the last tools/r04_final.sh call from gpurun_out/r04 into profiles/ and refresh the parity record (run HERE, repo root)
+# copy the files of the last tools/rounds/r04_final.sh call from gpurun_out/r04 into profiles/ and refresh the parity record (run HERE, repo root)
 O=gpurun_out/r04
 for f in r04_bench_final r04_bench_dual_final r04_bench_fp8_final r04_bench_fp8_2m_final r04_bench_fp32_final r04_bench_dist1 r04_bench_gpus2_shared_gpu r04_bench_train; do cp $O/$f.json profiles/$f.json; done
 cp $O/r04_final_bench.json profiles/r04_bench_final_under_rocprof.json

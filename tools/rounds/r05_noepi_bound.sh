@@ -3,7 +3,7 @@
 # measured it for fp8.  Same box, the library rebuilt per variant (timing-only builds: results are wrong):
 #   base | no epilogue at all (K-loop + prologue only) | 1 / 2 plain vector instructions in EVERY K-loop gap | 1 plain + 1
 #   transcendental per gap (what a QuickGELU epilogue spread over the next half-tile's K-loop would add)
-# Run on the GPU box from the repo root: bash tools/r05_noepi_bound.sh > gpurun_out/r05_noepi_bound.txt 2>&1
+# Run on the GPU box from the repo root: bash tools/rounds/r05_noepi_bound.sh > gpurun_out/r05_noepi_bound.txt 2>&1
 set -u
 build() {   # $1 = extra flags; a failed build is reported and SKIPPED (the previous library must not run under the new label)
   (cd keds_amd/csrc && make -j8 EXTRA="$1" > /tmp/mk.log 2>&1) || { echo "BUILD FAILED: $1"; tail -5 /tmp/mk.log; return 1; }
