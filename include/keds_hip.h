@@ -569,6 +569,12 @@ int keds_gemm_f32(const float* A, int64_t lda, const float* W, const float* bias
                   int epilogue, const float* aux, int aux_i, void* stream);
 /* keds_attention_ex on fp32 qkv [B*S, 3*d] -> out fp32 [B*S, d]; q_limit <= 0: all rows; S <= 288 */
 int keds_attention_f32(const float* qkv, float* out, int B, int S, int heads, int causal, int q_limit, void* stream);
+/* keds_attention_f32 at fp32 grade on the fp16 matrix instruction (the fp32x3 operating point, csrc/attention_x3.hip): q, k, v
+ * and the probabilities as two fp16 planes each, three products per product, fp32 softmax.  out: fp32 [B*S, d] (nullable);
+ * pair: fp16 planes [2][plane] of the same rows (nullable; what keds_gemm_x3 reads as its A operand); at least one of them.
+ * overflow (nullable int on the device): raised when |q / 8|, |k| or |v| >= 65504.  Reference: src/model/model.py:319-321 */
+int keds_attention_x3(const float* qkv, float* out, void* pair, int64_t plane, int B, int S, int heads, int causal, int q_limit,
+                      int* overflow, void* stream);
 /* keds_im2col with an fp32 patch matrix [B*G, Kpad] (Kpad % 16 == 0) */
 int keds_im2col_f32(const float* image, float* out, int B, int R, int P, int Kpad, void* stream);
 /* keds_knowledge_run with EVERY weight pointer of the params an FP32 array (per-layer weights; `fused` unused): one stream

@@ -198,6 +198,7 @@ SIGNATURES = {
     "keds_tower_workspace_bytes_ex": (sz, [C.POINTER(TowerParams), i32]),
     "keds_gemm_f32": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp]),
     "keds_attention_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "keds_attention_x3": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
     "keds_im2col_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
     "keds_knowledge_f32_workspace_bytes": (sz, [C.POINTER(KnowledgeParams), i32, i32]),
     "keds_knowledge_run_f32": (i32, [C.POINTER(KnowledgeParams), vp, vp, vp, i32, i32, vp, vp, sz, vp]),

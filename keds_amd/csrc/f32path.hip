@@ -18,6 +18,9 @@
 int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
 
+extern "C" int keds_attention_x3(const float* qkv, float* out, void* pair, int64_t plane, int B, int S, int heads, int causal,
+                                 int q_limit, int* overflow, void* stream);
+
 namespace {
 
 namespace g32 {
@@ -331,6 +334,7 @@ int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S,
 int keds_layernorm_pair_impl(const float* x, long long x_stride, const float* gamma, const float* beta, void* out, long long plane,
                              int rows, int dim, hipStream_t st);
 int* keds_numerics_guard();
+bool keds_gemm_splits_rows(int M, int N, int K);
 
 // keds_tower_params.f32 == 2: the "fp32x3" operating point (round 5).  The same fp32 flow -- fp32 residual stream, fp32
 // LayerNorm / attention / QuickGELU -- with the four block GEMMs on SPLIT fp16 operands (keds_gemm_x3: x = hi + lo to 22 bits,
@@ -349,23 +353,50 @@ static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* w
     const long long pl = (long long)Mp * w, plh = (long long)Mp * 4 * w;
     int* guard = keds_numerics_guard();
     int rc;
+    const long long wq = 3LL * w * w, wo = (long long)w * w, wf = 4LL * w * w;         // elements between a weight's planes
+    // Two lanes, as in the default flow (towers.hip, RowLanes): the rows beyond the last full 256-row tile (ViT-L/14 at B = 128:
+    // 128 of 32,896) are a handful of workgroups per GEMM whose time is pure latency -- 150 us per block when they run between
+    // the full-tile launches.  Rows only meet in the attention: the remainder rows' chain (out-proj, ln_2, MLP, next ln_1, next
+    // in_proj) runs on the side lane beside the same chain on the full tiles; fork behind the attention, join in front of the next.
+    struct Span {
+        size_t r0;
+        int n;
+        hipStream_t st;
+    };
+    const int m_main = M / 256 * 256;
+    KedsSideLane* lane = (m_main > 0 && m_main < M && keds_gemm_splits_rows(M, 3 * w, w)) ? keds_side_lane() : nullptr;
+    Span spans[2] = {{0, lane ? m_main : M, st}, {(size_t)m_main, M - m_main, lane ? lane->s : st}};
+    const int nspan = lane ? 2 : 1;
+    auto pre = [&](const keds_block_params& k, const Span& sp) -> int {               // ln_1 + in_proj
+        int r = keds_layernorm_pair_impl(x + sp.r0 * w, w, k.ln1_g, k.ln1_b, ln2 + sp.r0 * w, pl, sp.n, w, sp.st);
+        if (r) return r;
+        return keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.qkv_w, wq, k.qkv_b, qkv + sp.r0 * 3 * w, 3 * w, sp.n, 3 * w, w, KEDS_EPI_X3_BIAS_F32, 0, sp.st);
+    };
+    auto post = [&](const keds_block_params& k, const Span& sp) -> int {              // out-proj + ln_2 + MLP
+        int r;
+        if ((r = keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.out_w, wo, k.out_b, x + sp.r0 * w, w, sp.n, w, w, KEDS_EPI_X3_RESID_F32, 0, sp.st))) return r;
+        if ((r = keds_layernorm_pair_impl(x + sp.r0 * w, w, k.ln2_g, k.ln2_b, ln2 + sp.r0 * w, pl, sp.n, w, sp.st))) return r;
+        if ((r = keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.fc_w, wf, k.fc_b, hid2 + sp.r0 * 4 * w, 4 * w, sp.n, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)plh, sp.st))) return r;
+        return keds_gemm_x3(hid2 + sp.r0 * 4 * w, plh, 4 * w, k.proj_w, wf, k.proj_b, x + sp.r0 * w, w, sp.n, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, sp.st);
+    };
+    if (lane && (rc = keds_stream_order(st, lane->fork, lane->s))) return rc;
+    for (int i = 0; i < nspan; ++i)
+        if ((rc = pre(p->blocks[0], spans[i]))) return rc;
     for (int l = 0; l < p->layers; ++l) {
         const keds_block_params& k = p->blocks[l];
         const bool last = l == p->layers - 1;
-        const long long wq = 3LL * w * w, wo = (long long)w * w, wf = 4LL * w * w;     // elements between a weight's planes
-        if ((rc = keds_layernorm_pair_impl(x, w, k.ln1_g, k.ln1_b, ln2, pl, M, w, st))) return rc;
-        if ((rc = keds_gemm_x3(ln2, pl, w, k.qkv_w, wq, k.qkv_b, qkv, 3 * w, M, 3 * w, w, KEDS_EPI_X3_BIAS_F32, 0, st))) return rc;
+        if (lane && (rc = keds_stream_order(lane->s, lane->join, st))) return rc;      // every row's q, k, v before the attention
         if (last && (last_rows || p->last_cls_only)) {
             // after the last block one row per sample is read (model.py:412 the CLS row; :587-589, 847-849 the read-out row):
             // attention (all rows for the text tower, the CLS query for the ViT), then the B rows in compact buffers
             float* att_c = qkv;                                   // [B, w] fp32 each, in the qkv buffer (dead after the attention)
             float* x_c = qkv + (size_t)B * w;
             if (last_rows) {
-                if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
+                if ((rc = keds_attention_x3(qkv, att, nullptr, 0, B, S, p->heads, p->causal, S, guard, st))) return rc;
                 if ((rc = keds_gather_rows_impl(att, att_c, last_rows, S, B, w, 2, st))) return rc;
                 if ((rc = keds_gather_rows_impl(x, x_c, last_rows, S, B, w, 2, st))) return rc;
             } else {
-                if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, 1, st))) return rc;
+                if ((rc = keds_attention_x3(qkv, att, nullptr, 0, B, S, p->heads, p->causal, 1, guard, st))) return rc;
                 if (hipMemcpy2DAsync(att_c, (size_t)w * 4, att, (size_t)S * w * 4, (size_t)w * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess ||
                     hipMemcpy2DAsync(x_c, (size_t)w * 4, x, (size_t)S * w * 4, (size_t)w * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
                     keds_set_error("keds_tower_forward_f32: CLS rows: %s", hipGetErrorString(hipGetLastError()));
@@ -385,14 +416,15 @@ static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* w
             }
             return KEDS_OK;
         }
-        if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
-        if ((rc = keds_split_f16_pair(att, w, M, w, ln2, pl, guard, st))) return rc;
-        if ((rc = keds_gemm_x3(ln2, pl, w, k.out_w, wo, k.out_b, x, w, M, w, w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
-        if ((rc = keds_layernorm_pair_impl(x, w, k.ln2_g, k.ln2_b, ln2, pl, M, w, st))) return rc;
-        if ((rc = keds_gemm_x3(ln2, pl, w, k.fc_w, wf, k.fc_b, hid2, 4 * w, M, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)plh, st))) return rc;
-        if ((rc = keds_gemm_x3(hid2, plh, 4 * w, k.proj_w, wf, k.proj_b, x, w, M, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
+        // (the attention writes the out-projection's A operand planes itself: no fp32 copy of its output, no split pass)
+        if ((rc = keds_attention_x3(qkv, nullptr, ln2, pl, B, S, p->heads, p->causal, S, guard, st))) return rc;
+        if (lane && (rc = keds_stream_order(st, lane->fork, lane->s))) return rc;
+        for (int i = 0; i < nspan; ++i) {
+            if ((rc = post(k, spans[i]))) return rc;
+            if (!last && (rc = pre(p->blocks[l + 1], spans[i]))) return rc;
+        }
     }
-    return KEDS_OK;
+    return lane ? keds_stream_order(lane->s, lane->join, st) : KEDS_OK;
 }
 
 // last_rows (device int32 [B], nullable): towers.hip, rows_tail -- the text tower's read-out rows; on return x[b] = that row

@@ -100,6 +100,47 @@ def test_attention_f32_against_float64(S, causal, q_limit):
         assert float(got[:, nq:].abs().max()) == 0.0            # rows beyond q_limit are not written
 
 
+@pytest.mark.parametrize("S,causal,q_limit", [(257, False, 0), (77, True, 0), (43, True, 0), (257, False, 1), (33, True, 5), (288, False, 0)])
+def test_attention_x3_against_float64(S, causal, q_limit):
+    """The split-operand attention of the fp32x3 mode (csrc/attention_x3.hip): fp32-grade against float64, on the fp32 output
+    and on the fp16 planes it writes for the out-projection (hi + lo), with the error of the f32-input kernel beside it."""
+    lib = _lib.load()
+    B, H = 3, 2
+    d = 64 * H
+    g = torch.Generator().manual_seed(S)
+    qkv = (torch.randn(B * S, 3 * d, generator=g) * 1.5).cuda()
+    out = torch.zeros((B * S, d), device="cuda")
+    plane = B * S * d + 256
+    pair = torch.zeros((2, plane), dtype=torch.float16, device="cuda")
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.keds_attention_x3(_lib.ptr(qkv), _lib.ptr(out), _lib.ptr(pair), plane, B, S, H, int(causal), q_limit, _lib.ptr(flag),
+                                     _lib.stream()), "attention_x3")
+    f32 = torch.zeros((B * S, d), device="cuda")
+    _lib.check(lib.keds_attention_f32(_lib.ptr(qkv), _lib.ptr(f32), B, S, H, int(causal), q_limit, _lib.stream()), "attention_f32")
+    q, k, v = (t.cpu().double().reshape(B, S, H, 64).transpose(1, 2) for t in qkv.split(d, dim=1))
+    s = q @ k.transpose(-1, -2) / 8.0
+    if causal:
+        s = s.masked_fill(torch.ones(S, S, dtype=torch.bool).triu(1), float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, S, d)
+    nq = q_limit if q_limit > 0 else S
+    got = out.reshape(B, S, d)
+    r = rel_l2(got[:, :nq], ref[:, :nq].float())
+    r32 = rel_l2(f32.reshape(B, S, d)[:, :nq], ref[:, :nq].float())
+    planes = (pair[0, :B * S * d].double() + pair[1, :B * S * d].double()).reshape(B, S, d)
+    rp = float(((planes[:, :nq].cpu() - ref[:, :nq]).norm() / ref[:, :nq].norm()))
+    report(f"attention_x3.S{S}.causal{int(causal)}.q{q_limit}", rel_l2=r, rel_l2_planes=rp, rel_l2_f32_kernel=r32)
+    assert r <= 2e-6 and rp <= 2e-6, (r, rp, r32)
+    assert int(flag.item()) == 0
+    if nq < S:
+        assert float(got[:, nq:].abs().max()) == 0.0 and float(planes[:, nq:].abs().max()) == 0.0   # rows beyond q_limit are not written
+    # an operand beyond fp16's range raises the flag (the caller then takes the f32-input flow)
+    big = qkv.clone()
+    big[5, d + 3] = 7.0e4
+    _lib.check(lib.keds_attention_x3(_lib.ptr(big), _lib.ptr(out), None, 0, B, S, H, int(causal), q_limit, _lib.ptr(flag), _lib.stream()),
+               "attention_x3 (overflow)")
+    assert int(flag.item()) == 1
+
+
 def test_tiny_clip_fp32_matches_reference_golden():
     """Every method of the tiny CLIP fixture (reference-minted, tools/mint_golden.py) in fp32 mode."""
     g = dict(np.load(golden_path("clip_tiny.npz")))
