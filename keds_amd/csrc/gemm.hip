@@ -1280,7 +1280,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
                                                               const float* __restrict__ bias, void* __restrict__ out,
                                                               int M, int N, int K, int n_tiles,
                                                               const float* __restrict__ aux, int aux_i,
-                                                              void* __restrict__ aux2, int* __restrict__ guard, int ntiles) {
+                                                              void* __restrict__ aux2, int* __restrict__ guard, int ntiles,
+                                                              long long a_plane = 0, long long w_plane = 0) {
+    // (a_plane / w_plane: KEDS_EPI_X3_* only, as in gemm_bt_pair_kernel: K-tile p of 3 K / 64 reads segment p / (K / 64))
     using namespace pr;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     [[maybe_unused]] unsigned long long t_entry = 0, t_loop0 = 0;
@@ -1323,7 +1325,11 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     auto issue = [&](int p, int q) {                               // DMA piece q (0..15: X pieces 0..7, W pieces 0..7) of K-tile p
         const int i = q & 7;
         char* dst = smem + (p & 1) * PBUF_BYTES + (q < 8 ? 0 : OP_BYTES) + (wave + 4 * i) * 1024;
-        const unsigned so = i * rstride + (unsigned)p * (TK * 2);
+        unsigned so = i * rstride + (unsigned)p * (TK * 2);
+        if constexpr (epi_x3(EPI)) {                                // K-tile p of 3 K / 64: its segment's planes (uniform arithmetic)
+            const X3Seg sg = x3_seg(p, K / TK);
+            so = i * rstride + sg.koff + (q < 8 ? (sg.a_lo ? (unsigned)(a_plane * 2) : 0u) : (sg.w_lo ? (unsigned)(w_plane * 2) : 0u));
+        }
 #if KEDS_QUAD_TIDDMA
         if (q < 8) {
             if (KEDS_QUAD_TIDDMA & 1)
@@ -1347,7 +1353,7 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     const int slot0 = ((0 + g) ^ f) << 4, slot1 = ((4 + g) ^ f) << 4;
     const int xrow = (128 * wm + c) * 128;                         // + mi * 2048
     const int wrow = OP_BYTES + (128 * wn2 + c) * 128;             // + j * 2048, j = 4 h + ni
-    const int np = K / TK;                                         // >= 2
+    const int np = (epi_x3(EPI) ? 3 : 1) * (K / TK);               // >= 2
     const int step = PERSIST ? (int)gridDim.x : ntiles;            // (not persistent: one tile per workgroup)
     [[maybe_unused]] float fill_v[6] = {1.f + K, 2.f, 3.f, 4.f, 0.5f, 0.25f};   // (KEDS_QUAD_FILLER)
 
@@ -1810,10 +1816,20 @@ static int resid_quad_min_k() {
     }
     return v;
 }
+// (KEDS_X3_QUAD=0 in the environment: the 8-wave kernel for the split-operand GEMMs, A/B)
+static bool x3_quad_env() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_X3_QUAD");
+        v = !(e && e[0] == '0');
+    }
+    return v != 0;
+}
 template <int EPI>
 bool quad_by_shape(int N, int K) {
     if constexpr (epi_is_ln(EPI)) return K >= 512;
     if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) return K >= resid_quad_min_k();
+    if constexpr (epi_x3(EPI)) return x3_quad_env();               // split-operand GEMMs: a K-loop of 3 K / 64 K-tiles, the form that wins where the K-loop dominates
     return false;
 }
 // fp16-residual GEMMs: residual + bias as the accumulators' initial value instead of 16 loads per lane in the epilogue (round 3,
@@ -1887,11 +1903,11 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         // the tile loop no longer spills (209 VGPRs), and still does not pay: out-proj 66.7 vs 66.3 us, c_proj 216 vs 203.5 on
         // its three-deep ring -- two tiles per workgroup leave one prologue to hide, and the epilogue's residual loads queue
         // behind the 32 DMA pieces of the next tile in the in-order vmcnt)
-        if (quad == 2 && ntiles > cus && cus >= 8 && EPI != KEDS_EPI_RESID_STATS_F16) {
+        if (quad == 2 && ntiles > cus && cus >= 8 && EPI != KEDS_EPI_RESID_STATS_F16 && EPI != KEDS_EPI_X3_RESID_F32) {
             if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 0, 1>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
             gemm_bt_quad_kernel<EPI, 0, 1><<<cus, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
                                                                             n_tiles, aux, epi_is_ln(EPI) ? (g_quad_defer && quad_defer_env()) : aux_i, aux2,
-                                                                            keds_numerics_guard(), ntiles);
+                                                                            keds_numerics_guard(), ntiles, g_x3_aplane, g_x3_wplane);
             return keds_check_launch("gemm_bt_quad_kernel<persistent>");
         }
         if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
@@ -1904,7 +1920,7 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         }
         if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
         gemm_bt_quad_kernel<EPI><<<ntiles, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles,
-                                                                     aux, aux_i, aux2, keds_numerics_guard(), ntiles);
+                                                                     aux, aux_i, aux2, keds_numerics_guard(), ntiles, g_x3_aplane, g_x3_wplane);
         return keds_check_launch("gemm_bt_quad_kernel");
     }
     if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
