@@ -111,57 +111,47 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
         return r;
     };
     // the wave's first own query tile and the shared query travel while K and V are staged
-    QRaw q_own = fetch_q((wave < nqt_own ? wave : 0) * 32 + j), q_lone = fetch_q(nq - 1);
-    // ---- staging: one item = two adjacent keys x four dims (adjacent keys are adjacent in the V^T row); every load of the
-    // workgroup is in flight before the first conversion (S <= 288: at most five items per thread)
-    {
-        constexpr int IT = (288 / 2 * 16 + 64 * AX_WAVES - 1) / (64 * AX_WAVES);
-        const int items = (KEDS_AX_DBG & 2) ? 0 : (SP >> 1) * 16;
-        f32x4 kv[IT][4];
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int idx = threadIdx.x + it * 64 * AX_WAVES;
-            const int c4 = idx & 15, row = 2 * (idx >> 4);
-            const f32x4 z = f32x4{0.f, 0.f, 0.f, 0.f};
-            kv[it][0] = kv[it][1] = kv[it][2] = kv[it][3] = z;
-            if (idx < items && row < S) {
-                kv[it][0] = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + d + 4 * c4);
-                kv[it][2] = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + 2 * d + 4 * c4);
-            }
-            if (idx < items && row + 1 < S) {
-                kv[it][1] = *reinterpret_cast<const f32x4*>(base + (size_t)(row + 1) * ld + d + 4 * c4);
-                kv[it][3] = *reinterpret_cast<const f32x4*>(base + (size_t)(row + 1) * ld + 2 * d + 4 * c4);
-            }
+#ifndef KEDS_AX_QPF
+#define KEDS_AX_QPF 2      // (A/B) bit 0: the own tile's q requested before the staging, bit 1: the shared query's
+#endif
+    QRaw q_own, q_lone;
+    if (KEDS_AX_QPF & 1) q_own = fetch_q((wave < nqt_own ? wave : 0) * 32 + j);
+    if (KEDS_AX_QPF & 2) q_lone = fetch_q(nq - 1);
+    // ---- staging: one item = two adjacent keys x four dims (adjacent keys are adjacent in the V^T row).  (All of a thread's
+    // loads in flight before its first conversion -- 80 registers -- is SLOWER: 22 k instead of 15 k cycles, r05_x3_attention_stamps.)
+    for (int idx = threadIdx.x; idx < ((KEDS_AX_DBG & 2) ? 0 : (SP >> 1) * 16); idx += 64 * AX_WAVES) {
+        const int c4 = idx & 15, row = 2 * (idx >> 4);
+        f32x4 k0 = f32x4{0.f, 0.f, 0.f, 0.f}, k1 = k0, v0 = k0, v1 = k0;
+        if (row < S) {
+            k0 = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + d + 4 * c4);
+            v0 = *reinterpret_cast<const f32x4*>(base + (size_t)row * ld + 2 * d + 4 * c4);
         }
+        if (row + 1 < S) {
+            k1 = *reinterpret_cast<const f32x4*>(base + (size_t)(row + 1) * ld + d + 4 * c4);
+            v1 = *reinterpret_cast<const f32x4*>(base + (size_t)(row + 1) * ld + 2 * d + 4 * c4);
+        }
+        f16x4 h0, l0, h1, l1;
 #pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int idx = threadIdx.x + it * 64 * AX_WAVES;
-            if (idx >= items) break;
-            const int c4 = idx & 15, row = 2 * (idx >> 4);
-            const f32x4 k0 = kv[it][0], k1 = kv[it][1], v0 = kv[it][2], v1 = kv[it][3];
-            f16x4 h0, l0, h1, l1;
+        for (int e = 0; e < 4; ++e) {
+            bad = bad || !(fabsf(k0[e]) < 65504.0f) || !(fabsf(k1[e]) < 65504.0f) || !(fabsf(v0[e]) < 65504.0f) || !(fabsf(v1[e]) < 65504.0f);
+            f16_t a, c;
+            ax_split(k0[e], a, c);
+            h0[e] = a, l0[e] = c;
+            ax_split(k1[e], a, c);
+            h1[e] = a, l1[e] = c;
+        }
+        *reinterpret_cast<f16x4*>(Kh + (size_t)row * AX_KP + 4 * c4) = h0;
+        *reinterpret_cast<f16x4*>(Kl + (size_t)row * AX_KP + 4 * c4) = l0;
+        *reinterpret_cast<f16x4*>(Kh + (size_t)(row + 1) * AX_KP + 4 * c4) = h1;
+        *reinterpret_cast<f16x4*>(Kl + (size_t)(row + 1) * AX_KP + 4 * c4) = l1;
+        const int vp = (row & ~31) + ax_vpos(row & 31);   // even: the pair (row, row + 1) is one dword
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bad = bad || !(fabsf(k0[e]) < 65504.0f) || !(fabsf(k1[e]) < 65504.0f) || !(fabsf(v0[e]) < 65504.0f) || !(fabsf(v1[e]) < 65504.0f);
-                f16_t a, c;
-                ax_split(k0[e], a, c);
-                h0[e] = a, l0[e] = c;
-                ax_split(k1[e], a, c);
-                h1[e] = a, l1[e] = c;
-            }
-            *reinterpret_cast<f16x4*>(Kh + (size_t)row * AX_KP + 4 * c4) = h0;
-            *reinterpret_cast<f16x4*>(Kl + (size_t)row * AX_KP + 4 * c4) = l0;
-            *reinterpret_cast<f16x4*>(Kh + (size_t)(row + 1) * AX_KP + 4 * c4) = h1;
-            *reinterpret_cast<f16x4*>(Kl + (size_t)(row + 1) * AX_KP + 4 * c4) = l1;
-            const int vp = (row & ~31) + ax_vpos(row & 31);   // even: the pair (row, row + 1) is one dword
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                f16_t a0, c0, a1, c1;
-                ax_split(v0[e], a0, c0);
-                ax_split(v1[e], a1, c1);
-                *reinterpret_cast<f16x2*>(Vh + (size_t)(4 * c4 + e) * VP + vp) = f16x2{a0, a1};
-                *reinterpret_cast<f16x2*>(Vl + (size_t)(4 * c4 + e) * VP + vp) = f16x2{c0, c1};
-            }
+        for (int e = 0; e < 4; ++e) {
+            f16_t a0, c0, a1, c1;
+            ax_split(v0[e], a0, c0);
+            ax_split(v1[e], a1, c1);
+            *reinterpret_cast<f16x2*>(Vh + (size_t)(4 * c4 + e) * VP + vp) = f16x2{a0, a1};
+            *reinterpret_cast<f16x2*>(Vl + (size_t)(4 * c4 + e) * VP + vp) = f16x2{c0, c1};
         }
     }
     AX_STAMP(1);
@@ -284,7 +274,7 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
     for (int e = 0; e < 16; ++e) r0[e] = 0.f, r1[e] = 0.f;
     for (int qt = wave; qt < nqt_own; qt += AX_WAVES) {
         const int q = qt * 32 + j;
-        split_q(qt == wave ? q_own : fetch_q(q));
+        split_q((qt == wave && (KEDS_AX_QPF & 1)) ? q_own : fetch_q(q));
         AX_STAMP(3);
         int kt_end = nkt;
         if (causal) {                                                            // key tiles that hold a key <= the tile's last query
@@ -301,7 +291,7 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
     AX_STAMP(5);
     if (lone) {                                                                  // (uniform over the workgroup)
         const int q = nq - 1;
-        split_q(q_lone);                                                         // every lane of the tile holds the one query
+        split_q((KEDS_AX_QPF & 2) ? q_lone : fetch_q(q));                        // every lane of the tile holds the one query
         for (int kt = wave; kt < nkt; kt += AX_WAVES) key_tile(kt, q);
         const float lt = ax_halves_sum(l);
         if (j == 0) {                                                            // lanes 0 and 32: dims (r & 3) + 8 (r >> 2) + 4 h (+ 32)
