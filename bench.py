@@ -805,6 +805,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline_dual(model, s_img, s_txt, N, D)
         if verification is not None:
             emb = verification.get("embedding")
+            if emb is None:                                    # said, not implied: this line vouches for the search only
+                verification["embedding"] = None
+                verification["embedding_not_checked"] = ("no oracle embeddings in this run (--no-cpu-baseline, the dual workload, N > 1 "
+                                                         "or the dry run): the top-k check above does not see a wrong ENCODER")
             verification["ok"] = bool(verification["id_mismatches"] == 0 and verification["max_abs_distance_error"] <= 4e-6 and
                                       (emb is None or (emb["min_cosine"] >= emb["limit_min_cosine"] and emb["rel_l2"] <= emb["limit_rel_l2"]))
                                       and not guard_tripped)

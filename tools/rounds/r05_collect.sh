@@ -1,7 +1,7 @@
 #!/bin/bash
 # copy the files of the last tools/rounds/r05_final.sh call from gpurun_out/r05 into profiles/ and refresh the parity record (run HERE, repo root)
 O=gpurun_out/r05
-for f in r05_bench_final r05_bench_dual_final r05_bench_fp8_final r05_bench_fp8_2m_final r05_bench_fp32_final r05_bench_fp32x3_final r05_bench_fp32x3_dual_final r05_bench_dist1 r05_bench_gpus2_shared_gpu r05_bench_injected_fault r05_bench_train; do cp $O/$f.json profiles/$f.json; done
+for f in r05_bench_final r05_bench_dual_final r05_bench_fp8_final r05_bench_fp8_2m_final r05_bench_fp32_final r05_bench_fp32x3_final r05_bench_fp32x3_dual_final r05_bench_dist1 r05_bench_gpus2_shared_gpu r05_bench_injected_fault r05_bench_injected_fault_encoder r05_bench_train; do cp $O/$f.json profiles/$f.json; done
 cp $O/r05_final_bench.json profiles/r05_bench_final_under_rocprof.json
 cp $O/r05_final_kernel_stats.csv profiles/r05_bench_kernel_stats_final.csv
 cp $O/r05_final_pmc_traffic.json profiles/r05_pmc_traffic.json

@@ -15,7 +15,8 @@ timeout 300 python bench.py --precision fp32x3 --steps 20 --warmup 3 --no-cpu-ba
 timeout 300 python bench.py --precision fp32x3 --workload dual --steps 10 --warmup 2 --no-cpu-baseline > $O/r05_bench_fp32x3_dual_final.json 2>/dev/null; echo "fp32x3 dual rc=$?"
 KEDS_BENCH_FORCE_DIST=1 timeout 300 python bench.py --steps 60 --no-cpu-baseline > $O/r05_bench_dist1.json 2>/dev/null; echo "dist1 rc=$?"
 KEDS_BENCH_SHARED_GPU=1 timeout 300 python bench.py --gpus 2 --steps 10 --warmup 2 --no-cpu-baseline > $O/r05_bench_gpus2_shared_gpu.json 2>/dev/null; echo "shared-gpu 2 ranks rc=$?"
-KEDS_BENCH_INJECT_FAULT=1 timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/r05_bench_injected_fault.json 2>/dev/null; echo "injected fault rc=$? (3 expected)"
+KEDS_BENCH_INJECT_FAULT=2 timeout 300 python bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/r05_bench_injected_fault.json 2>/dev/null; echo "injected fault (a corrupted result list) rc=$? (3 expected)"
+KEDS_BENCH_INJECT_FAULT=1 timeout 400 python bench.py --steps 5 --warmup 1 > $O/r05_bench_injected_fault_encoder.json 2>/dev/null; echo "injected fault (a corrupted encoder; needs the oracle's embeddings, i.e. the cpu_baseline leg) rc=$? (3 expected)"
 timeout 300 python tools/bench_train.py > $O/r05_bench_train.json 2>/dev/null; echo "train rc=$?"
 timeout 900 bash tools/profile_round.sh r05_final > $O/profile_round.log 2>&1; echo "profile rc=$?"; tail -4 $O/profile_round.log
 cp gpurun_out/r05_final_* $O/ 2>/dev/null
