@@ -22,6 +22,15 @@ int keds_gemm_duo_launch(int epi, const void* A, const void* W, const float* bia
 #ifndef KEDS_QUAD_NOEPI
 #define KEDS_QUAD_NOEPI 0
 #endif
+// cache policy of the persistent 4-wave kernel's LDS-DMA pieces per operand (aux bits of the buffer load: 1 = sc0, 2 = nt, 16 = sc1).
+// Per supertile (8 row panels x 4 column tiles on one XCD's 32 CUs) the A panels are 4 MB that nobody on this XCD reads again
+// and the W panels 2 MB that the XCD's NEXT supertile reads again (same column group): round 5 A/B, tools/rounds/r05_quad_policy.sh
+#ifndef KEDS_QUAD_AUX_X
+#define KEDS_QUAD_AUX_X 0
+#endif
+#ifndef KEDS_QUAD_AUX_W
+#define KEDS_QUAD_AUX_W 0
+#endif
 #ifndef KEDS_QUAD_TIDDMA
 #define KEDS_QUAD_TIDDMA 0
 #endif
@@ -1344,9 +1353,9 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
         }
 #else
         if (q < 8)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (__attribute__((address_space(3))) void*)dst, 16, xoff, so, 0, KEDS_QUAD_AUX_X);
         else
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, woff, so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (__attribute__((address_space(3))) void*)dst, 16, woff, so, 0, KEDS_QUAD_AUX_W);
 #endif
     };
     const int f = (c >> 1) & 7;
