@@ -447,10 +447,110 @@ int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, 
     return keds_check_launch("layernorm_kernel");
 }
 
+// The fp32x3 flow's LayerNorm -> planes pass as a STREAM (round 5): 2 x 24 launches per step at 84 us each (3.2 TB/s of read +
+// write) in the one-wave-one-row form above -- every wave's life is one load latency, one reduction chain and one store burst,
+// and gamma / beta come in again for every row.  Here a wave walks rows r, r + W, r + 2 W, ... with the NEXT row's loads in flight
+// while it reduces and splits the current one, gamma / beta in registers for its whole life, a lane owning runs of 8 consecutive
+// columns (16-byte plane stores, whole 128-byte lines per eight lanes), reductions on the VALU (DPP + permlane swaps, no LDS
+// round trips).  dim = NJ * 512.  The arithmetic is the kernel's above (two-pass mean / variance in fp32) with another summation
+// order inside the wave.
+#define KEDS_LNS_DPP(x, CTRL) __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x), (CTRL), 0xF, 0xF, false))
+__device__ __forceinline__ float lns_wave_sum(float x) {
+    x += KEDS_LNS_DPP(x, 0xB1);     // lane ^ 1
+    x += KEDS_LNS_DPP(x, 0x4E);     // lane ^ 2
+    x += KEDS_LNS_DPP(x, 0x141);    // row_half_mirror: the other group of four
+    x += KEDS_LNS_DPP(x, 0x140);    // row_mirror: the other half of the 16-lane row
+    return rows_sum(x);             // the four rows (permlane16 / permlane32 swaps)
+}
+template <int NJ>
+__global__ __launch_bounds__(256) void layernorm_pair_stream_kernel(const float* __restrict__ x, long long x_stride,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    f16_t* __restrict__ out, long long plane, int rows) {
+    constexpr int dim = NJ * 512;
+    const int lane = threadIdx.x & 63;
+    const int nw = gridDim.x * 4;
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    f32x4 gg[NJ][2], bb[NJ][2];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            gg[j][h] = *reinterpret_cast<const f32x4*>(gamma + j * 512 + lane * 8 + 4 * h);
+            bb[j][h] = *reinterpret_cast<const f32x4*>(beta + j * 512 + lane * 8 + 4 * h);
+        }
+    f32x4 cur[NJ][2], nxt[NJ][2];
+    auto fetch = [&](int row, f32x4 (&v)[NJ][2]) {
+        const float* p = x + (long long)row * x_stride + lane * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            v[j][0] = *reinterpret_cast<const f32x4*>(p + j * 512);
+            v[j][1] = *reinterpret_cast<const f32x4*>(p + j * 512 + 4);
+        }
+    };
+    fetch(r, cur);
+    while (true) {
+        const int rn = r + nw;
+        if (rn < rows) fetch(rn, nxt);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) s += (cur[j][h][0] + cur[j][h][1]) + (cur[j][h][2] + cur[j][h][3]);
+        const float mean = lns_wave_sum(s) * (1.0f / (float)dim);
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 dv = cur[j][h] - mean;
+                q += (dv[0] * dv[0] + dv[1] * dv[1]) + (dv[2] * dv[2] + dv[3] * dv[3]);
+            }
+        const float rstd = rsqrtf(lns_wave_sum(q) * (1.0f / (float)dim) + LN_EPS);
+        f16_t* o = out + (size_t)r * dim + lane * 8;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            f16x8 hi, lo;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const f32x4 y = (cur[j][h] - mean) * rstd * gg[j][h] + bb[j][h];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    hi[4 * h + e] = (f16_t)y[e];
+                    lo[4 * h + e] = (f16_t)(y[e] - (float)hi[4 * h + e]);
+                }
+            }
+            *reinterpret_cast<f16x8*>(o + j * 512) = hi;
+            *reinterpret_cast<f16x8*>(o + j * 512 + plane) = lo;
+        }
+        if (rn >= rows) break;
+        r = rn;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) cur[j][0] = nxt[j][0], cur[j][1] = nxt[j][1];
+    }
+}
+static bool ln_stream_env() {          // KEDS_LN_STREAM=0 in the environment: the one-row-per-wave form (A/B)
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_LN_STREAM");
+        v = !(e && e[0] == '0');
+    }
+    return v != 0;
+}
+
 // LayerNorm whose output is a pair of fp16 planes (hi = out, lo = out + plane elements; dense rows of `dim`)
 int keds_layernorm_pair_impl(const float* x, long long x_stride, const float* gamma, const float* beta, void* out, long long plane,
                              int rows, int dim, hipStream_t st) {
     KedsProfScope prof(KEDS_PROF_LN, st);
+    if ((dim == 1024 || dim == 512) && rows >= 2048 && x_stride % 4 == 0 && plane % 8 == 0 && ln_stream_env()) {
+        // every wave resident at once (82 VGPRs: five per SIMD, five blocks per CU); at 32,768 rows a wave walks six or seven
+        const int cus = keds_device_cus();
+        int grid = cus * 5;
+        if (grid * 4 > rows) grid = (rows + 3) / 4;
+        if (dim == 1024) layernorm_pair_stream_kernel<2><<<grid, 256, 0, st>>>(x, x_stride, gamma, beta, (f16_t*)out, plane, rows);
+        else layernorm_pair_stream_kernel<1><<<grid, 256, 0, st>>>(x, x_stride, gamma, beta, (f16_t*)out, plane, rows);
+        return keds_check_launch("layernorm_pair_stream_kernel");
+    }
     ln_launch<2>(x, x_stride, nullptr, 1, gamma, beta, out, rows, dim, st, plane);
     return keds_check_launch("layernorm_kernel<pair>");
 }
