@@ -188,6 +188,27 @@ def test_vitl14_fp32_embeddings_within_1e_5_of_the_reference(mode):
         assert m.precision == mode and getattr(m, "x3_range_trips", 0) == 0          # nothing left the fp16 range
 
 
+def test_fp32x3_leaves_the_fp16_range_and_falls_back_to_the_f32_input_flow():
+    """Split fp16 operands hold |x| < 65,504.  A model whose first ln_1 gain is 1e5 sends LayerNorm outputs beyond that: the pass
+    must not return garbage -- the guard flag / the non-finite output is seen, the pass is repeated on the f32-input flow
+    ("fp32": no range limit), the model stays there, and the result is that flow's result."""
+    sd = O.synth_clip_state_dict(**TINY, seed=7)
+    key = next(k for k in sd if k.endswith("visual.transformer.resblocks.0.ln_1.weight"))
+    sd[key] = sd[key] * 1.0e5
+    g = dict(np.load(golden_path("clip_tiny.npz")))
+    img = torch.from_numpy(g["image"]).cuda()
+    ref = keds_amd.build_model(dict(sd), fp16=False).cuda().set_precision("fp32").encode_image(img)
+    assert torch.isfinite(ref).all()
+    m = keds_amd.build_model(dict(sd), fp16=False).cuda().set_precision("fp32x3")
+    out = m.encode_image(img)
+    assert torch.isfinite(out).all()
+    assert getattr(m, "x3_range_trips", 0) == 1 and m.precision == "fp32"
+    r = rel_l2(out, ref)
+    report("fp32x3.range_fallback", rel_l2=r)
+    assert r <= 1e-6, r                                                   # the same flow ran: the same numbers
+    assert getattr(m, "x3_range_trips", 0) == 1 and torch.equal(m.encode_image(img), out)     # and it stays there
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_recall_at_k_vitl14_1k_gallery_is_equal_in_fp32_mode(mode):
     """BASELINE config 1 / north_star "Recall@k equal to the CPU reference on identical inputs": the reference-minted
