@@ -306,7 +306,43 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
         }
         AX_STAMP(6);
         __syncthreads();
-        if (wave < nqt_own) store_tile(wave * 32 + j, r0, r1);
+        if (wave < nqt_own) {
+            if (pair && !out) {
+                // Planes only (every block but the last): a lane holds 4-dim pieces of one query -- 32 stores of 8 bytes, each
+                // instruction a scatter of partial lines.  K / V are dead behind the barrier: the wave turns its 32 x 64 tile
+                // through its own 9 KiB of their LDS (144-byte rows) and stores 16 bytes per lane, eight whole 128-byte rows per
+                // instruction, 4 + 4 instead of 32 + 32.
+                f16_t* tl = ax_lds + (size_t)wave * (2 * 32 * AX_KP);            // [2 planes][32 queries][72 halves]
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x16& o = blk ? r1 : r0;
+                        f16x4 vh, vl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            f16_t x, y;
+                            ax_split(o[4 * g + e], x, y);
+                            vh[e] = x, vl[e] = y;
+                        }
+                        f16_t* w = tl + (size_t)j * AX_KP + 32 * blk + 8 * g + 4 * hh;
+                        *reinterpret_cast<f16x4*>(w) = vh;
+                        *reinterpret_cast<f16x4*>(w + 32 * AX_KP) = vl;
+                    }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the wave's own writes; no other wave touches this region)
+                const size_t row0 = ((size_t)b * S + wave * 32) * d + hd * 64;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = 8 * i + (lane >> 3), ch = lane & 7;          // (lone mode: all 32 queries of an own tile exist)
+                    const f16x8 vh = *reinterpret_cast<const f16x8*>(tl + (size_t)row * AX_KP + 8 * ch);
+                    const f16x8 vl = *reinterpret_cast<const f16x8*>(tl + (size_t)(32 + row) * AX_KP + 8 * ch);
+                    *reinterpret_cast<f16x8*>(pair + row0 + (size_t)row * d + 8 * ch) = vh;
+                    *reinterpret_cast<f16x8*>(pair + plane + row0 + (size_t)row * d + 8 * ch) = vl;
+                }
+            } else {
+                store_tile(wave * 32 + j, r0, r1);
+            }
+        }
         if (wave == AX_WAVES - 1) {                                              // lane = output dim
             float mm = -1.0e30f;
 #pragma unroll

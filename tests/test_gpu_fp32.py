@@ -133,6 +133,11 @@ def test_attention_x3_against_float64(S, causal, q_limit):
     assert int(flag.item()) == 0
     if nq < S:
         assert float(got[:, nq:].abs().max()) == 0.0 and float(planes[:, nq:].abs().max()) == 0.0   # rows beyond q_limit are not written
+    # planes only (what every block but the last asks for): whole-line stores through LDS for full tiles -- the same numbers
+    pair2 = torch.zeros_like(pair)
+    _lib.check(lib.keds_attention_x3(_lib.ptr(qkv), None, _lib.ptr(pair2), plane, B, S, H, int(causal), q_limit, _lib.ptr(flag),
+                                     _lib.stream()), "attention_x3 (planes only)")
+    assert torch.equal(pair2, pair)
     # an operand beyond fp16's range raises the flag (the caller then takes the f32-input flow)
     big = qkv.clone()
     big[5, d + 3] = 7.0e4
