@@ -1948,10 +1948,25 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
 
 int g_force_small = 0;   // test hook: route everything through the 128^2 kernel
 
+static int big_tiles_pct() {          // KEDS_BIG_TILES_PCT in the environment (A/B): the fill a 256^2 launch needs, default 85
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_BIG_TILES_PCT");
+        v = e && e[0] ? atoi(e) : 85;
+    }
+    return v;
+}
+// (round 5) A launch whose rows are whole 256-row tiles (no remainder launch behind it) and whose K-loop is short needs only HALF
+// of its last round filled: the 128^2 kernel's alternative is four times the workgroups on 512 slots, and 11,008 x 768 x 768 (the
+// dual workload's 2B-row text pass at 43 columns: 516 workgroups, four more than fit at once) pays a whole second round for
+// them -- 60 us against 30 on 129 tiles of 256^2; in_proj 61 -> 43, c_fc 82 -> 70.  Not for long K (c_proj, K = 3072: 76 us on the
+// one-tile-per-workgroup kernel against 60).  profiles/r05_text_big_tiles_ab.txt
 bool big_tiles_ok(int M, int N, int K) {
     const long bt = (long)(M / pr::TM) * (N / pr::TN);
     const long rounds = (bt + 255) / 256;
-    return !g_force_small && N % pr::TN == 0 && K % 64 == 0 && K >= 128 && bt > 0 && bt * 100 >= rounds * 256 * 85;
+    int pct = big_tiles_pct();
+    if (pct == 85 && M % pr::TM == 0 && K <= 1024) pct = 50;
+    return !g_force_small && N % pr::TN == 0 && K % 64 == 0 && K >= 128 && bt > 0 && bt * 100 >= rounds * 256 * pct;
 }
 
 template <int EPI>
