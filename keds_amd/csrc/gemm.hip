@@ -772,6 +772,14 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
 }
 
 int g_no_split = 0;   // test hook
+static bool nosplit_env() {     // KEDS_NO_SPLITK=1 in the environment (A/B): no split-K anywhere
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("KEDS_NO_SPLITK");
+        v = e && e[0] == '1';
+    }
+    return v != 0;
+}
 // thread-local request of the calling composite (towers.hip): small launches take the 64 KiB kernel form; KEDS_SMALL_NST=2 in the
 // environment forces it everywhere (A/B)
 thread_local int tl_small_lds = 0;
@@ -791,7 +799,7 @@ int launch_small(const void* A, const void* W, const float* bias, void* out, int
     // too few tiles to fill 256 CUs: split K so that ~128+ workgroups stream the weights in parallel
     float* g_ws = nullptr;
     size_t g_ws_bytes = 0;
-    if (tiles <= 64 && K >= 2048 && !g_no_split && !epi_x3(EPI)) keds_splitk_scratch(&g_ws, &g_ws_bytes);
+    if (tiles <= 64 && K >= 2048 && !g_no_split && !nosplit_env() && !epi_x3(EPI)) keds_splitk_scratch(&g_ws, &g_ws_bytes);
     if (g_ws) {   // (tiles <= 64 && K >= 2048; at K = 1024 the second launch costs what the split saves)
         int splits = 1;
         while (splits < 16 && tiles * splits * 2 <= 256 && K % (splits * 2 * BK) == 0 && K / (splits * 2) >= 2 * BK) splits *= 2;
