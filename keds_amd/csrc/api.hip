@@ -80,9 +80,21 @@ KedsSideLane* keds_side_lane() {
 // A stream wait binds to the event's most recent record AT THE TIME OF THE CALL, and the lane's two events are shared by
 // every caller on the device (keds_session.h allows different handles on different threads): record + wait are one
 // critical section, so no other thread's record of the same event can slip in between and re-aim this caller's wait.
+static std::mutex g_order_mu;
+// (round 5) the same critical section for an event that a LAUNCH records: keds_order_lock(); launch with the event as its stop
+// event (hipExtLaunchKernelGGL: the kernel's own completion signal -- no marker packet behind it on the launching stream);
+// keds_stream_wait_locked(ev, to); keds_order_unlock()
+void keds_order_lock() { g_order_mu.lock(); }
+void keds_order_unlock() { g_order_mu.unlock(); }
+int keds_stream_wait_locked(hipEvent_t ev, hipStream_t to) {
+    if (hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
+        keds_set_error("stream ordering failed: %s", hipGetErrorString(hipGetLastError()));
+        return KEDS_E_LAUNCH;
+    }
+    return KEDS_OK;
+}
 int keds_stream_order(hipStream_t from, hipEvent_t ev, hipStream_t to) {
-    static std::mutex order_mu;
-    std::lock_guard<std::mutex> g(order_mu);
+    std::lock_guard<std::mutex> g(g_order_mu);
     if (hipEventRecord(ev, from) != hipSuccess || hipStreamWaitEvent(to, ev, 0) != hipSuccess) {
         keds_set_error("stream ordering failed: %s", hipGetErrorString(hipGetLastError()));
         return KEDS_E_LAUNCH;
@@ -207,12 +219,17 @@ ProfState& prof() {
 }
 }  // namespace
 
-KedsProfScope::KedsProfScope(int k, hipStream_t s) : klass(k), stream(s), slot(nullptr) {
+static thread_local KedsProfScope* tl_lazy_scope = nullptr;
+
+KedsProfScope::KedsProfScope(int k, hipStream_t s, bool lz)
+    : klass(k), stream(s), slot(nullptr), lazy(lz), taken(false), work_units(0.0), ev_a(nullptr), ev_b(nullptr), outer(nullptr) {
     ProfState& p = prof();
     if (!(p.mask >> klass & 1u)) return;
     // side-lane launches overlap the caller's stream (and their event pairs would also time the wait for a free CU):
     // summing them with the main-lane durations would double-count the time, so they carry no events
     if (s && is_side_stream(s)) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (lazy && (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) lazy = false;
     std::lock_guard<std::mutex> g(p.mu);
     EvPair ev;
     if (!p.pool.empty()) {
@@ -221,23 +238,52 @@ KedsProfScope::KedsProfScope(int k, hipStream_t s) : klass(k), stream(s), slot(n
     } else {
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) return;
     }
+    ev_a = ev.a;
+    ev_b = ev.b;
+    slot = (void*)1;
+    if (lazy) {                              // the launches bind the pair (KEDS_LAUNCH); it joins `used` when one did
+        outer = tl_lazy_scope;
+        tl_lazy_scope = this;
+        return;
+    }
     (void)hipEventRecord(ev.a, stream);
     p.used[klass].push_back(ev);
-    slot = (void*)1;
 }
 
 KedsProfScope::~KedsProfScope() {
     if (!slot) return;
     ProfState& p = prof();
     std::lock_guard<std::mutex> g(p.mu);
-    (void)hipEventRecord(p.used[klass].back().b, stream);
+    if (lazy) {
+        tl_lazy_scope = outer;
+        if (taken) {
+            p.used[klass].push_back(EvPair{ev_a, ev_b});
+            p.work[klass] += work_units;
+        } else {
+            p.pool.push_back(EvPair{ev_a, ev_b});          // no launch of this scope went through KEDS_LAUNCH: nothing was timed
+        }
+        return;
+    }
+    (void)hipEventRecord(ev_b, stream);
 }
 
 void KedsProfScope::work(double units) {
     if (!slot) return;
+    if (lazy) {
+        work_units += units;
+        return;
+    }
     ProfState& p = prof();
     std::lock_guard<std::mutex> g(p.mu);
     p.work[klass] += units;
+}
+
+KedsLaunchEvents keds_prof_launch_events(hipStream_t st) {
+    KedsProfScope* sc = tl_lazy_scope;
+    if (!sc || sc->stream != st) return KedsLaunchEvents{nullptr, nullptr};
+    const bool first = !sc->taken;
+    sc->taken = true;
+    return KedsLaunchEvents{first ? sc->ev_a : nullptr, sc->ev_b};
 }
 
 extern "C" int keds_prof_read_work(int klass, double* units) {

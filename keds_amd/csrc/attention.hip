@@ -13,6 +13,7 @@
 // match: k-slot (g, j) of step u is key 32u + 16*(j>>2) + 4g + (j&3); V^T is staged in that order).
 #include "keds_common.h"
 #include <math.h>
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -967,12 +968,31 @@ int launch_attn_s257_dbg(const void* qkv, void* out, int B, int heads, int q_lim
     return keds_check_launch("attention_s257_kernel<dbg>");
 }
 
+// The towers fork their remainder-row chain behind this launch.  An event RECORDED on the launching stream is a marker packet of
+// its own between two kernels (a kernel trace shows 7.9 us between the attention's end and the next GEMM's start with it, 1.4
+// without: profiles/r05_trace_block.txt); as the launch's STOP event it is the kernel's completion signal and costs nothing.
+thread_local hipEvent_t tl_attn_stop = nullptr;
+thread_local bool tl_attn_stop_taken = false;
+template <typename K, typename... A>
+void launch_s257(K kernel, int grid, hipStream_t st, A... args) {
+    hipEvent_t stop = tl_attn_stop;
+    tl_attn_stop = nullptr;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (stop && (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone)) stop = nullptr;   // (a graph capture records it itself)
+    if (stop) {
+        hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(512), s257::LDS, st, nullptr, stop, 0, args...);
+        tl_attn_stop_taken = true;
+    } else {
+        kernel<<<grid, 512, s257::LDS, st>>>(args...);
+    }
+}
+
 int launch_attn_s257_q8(const void* qkv, void* out, int B, int heads, int q_limit, void* q8, void* s8, int q8_rows,
                         hipStream_t st) {
     if (int rc = keds_func_lds_once((const void*)attention_s257_kernel<0, true>, s257::LDS, "attention_s257_kernel<q8>")) return rc;
     KedsProfScope prof(KEDS_PROF_ATTN, st);
-    attention_s257_kernel<0, true><<<B * heads, 512, s257::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, heads, q_limit, nullptr,
-                                                                      (unsigned char*)q8, (unsigned char*)s8, q8_rows);
+    launch_s257(attention_s257_kernel<0, true>, B * heads, st, (const bf16_t*)qkv, (bf16_t*)out, heads, q_limit,
+                (unsigned long long*)nullptr, (unsigned char*)q8, (unsigned char*)s8, q8_rows);
     return keds_check_launch("attention_s257_kernel<q8>");
 }
 
@@ -991,7 +1011,8 @@ int launch_attn_s257(const void* qkv, void* out, int B, int heads, int q_limit, 
     }
     if (int rc = keds_func_lds_once((const void*)attention_s257_kernel<0>, s257::LDS, "attention_s257_kernel")) return rc;
     KedsProfScope prof(KEDS_PROF_ATTN, st);
-    attention_s257_kernel<0><<<B * heads, 512, s257::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, heads, q_limit, nullptr);
+    launch_s257(attention_s257_kernel<0>, B * heads, st, (const bf16_t*)qkv, (bf16_t*)out, heads, q_limit, (unsigned long long*)nullptr,
+                (unsigned char*)nullptr, (unsigned char*)nullptr, 0);
     return keds_check_launch("attention_s257_kernel");
 }
 
@@ -1026,6 +1047,15 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit
 }
 
 }  // namespace
+
+void keds_attention_stop_event(hipEvent_t ev) {
+    tl_attn_stop = ev;
+    tl_attn_stop_taken = false;
+}
+bool keds_attention_stop_event_taken() {
+    tl_attn_stop = nullptr;                 // (a kernel form that does not take it: the caller records the event itself)
+    return tl_attn_stop_taken;
+}
 
 extern "C" int keds_attention_stamp_buffer(void* buf) {      // diagnostic: B * heads * 64 uint64 for keds_attention_debug(64 + 8)
     g_attn_stamp = (unsigned long long*)buf;

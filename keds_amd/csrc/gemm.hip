@@ -755,19 +755,17 @@ int launch_small_nst(const void* A, const void* W, const float* bias, void* out,
         size_t g_ws_bytes = 0;
         keds_splitk_scratch(&g_ws, &g_ws_bytes);
         const int m_pad = m_tiles * BM;
-        gemm_bt_kernel<EPI, NST><<<tiles * splits, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
-                                                                               M, N, K, n_tiles, aux, aux_i, g_ws,
-                                                                               K / splits, tiles, m_pad, lda, ldc, aux2, nullptr, 0, 0);
+        KEDS_LAUNCH((gemm_bt_kernel<EPI, NST>), tiles * splits, 256, NST * BUF_BYTES, st, (const bf16_t*)A, (const bf16_t*)W, bias, out,
+                    M, N, K, n_tiles, aux, aux_i, g_ws, K / splits, tiles, m_pad, lda, ldc, aux2, (int*)nullptr, 0LL, 0LL);
         int rc = keds_check_launch("gemm_bt_kernel(split-K)");
         if (rc) return rc;
         const int threads = M * (N / 8);
-        gemm_splitk_reduce_kernel<EPI><<<(threads + 255) / 256, 256, 0, st>>>(g_ws, splits, m_pad, bias, out, M, N, K, aux,
-                                                                              aux_i, ldc, aux2, keds_numerics_guard());
+        KEDS_LAUNCH((gemm_splitk_reduce_kernel<EPI>), (threads + 255) / 256, 256, 0, st, (const float*)g_ws, splits, m_pad, bias, out, M, N, K,
+                    aux, aux_i, ldc, aux2, keds_numerics_guard());
         return keds_check_launch("gemm_splitk_reduce_kernel");
     }
-    gemm_bt_kernel<EPI, NST><<<tiles, 256, NST * BUF_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                  n_tiles, aux, aux_i, nullptr, 0, tiles, 0, lda, ldc, aux2,
-                                                                  keds_numerics_guard(), g_x3_aplane, g_x3_wplane);
+    KEDS_LAUNCH((gemm_bt_kernel<EPI, NST>), tiles, 256, NST * BUF_BYTES, st, (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
+                n_tiles, aux, aux_i, (float*)nullptr, 0, tiles, 0, lda, ldc, aux2, keds_numerics_guard(), g_x3_aplane, g_x3_wplane);
     return keds_check_launch("gemm_bt_kernel");
 }
 
@@ -1922,35 +1920,34 @@ int launch_big(const void* A, const void* W, const float* bias, void* out, int M
         // behind the 32 DMA pieces of the next tile in the in-order vmcnt)
         if (quad == 2 && ntiles > cus && cus >= 8 && EPI != KEDS_EPI_RESID_STATS_F16 && EPI != KEDS_EPI_X3_RESID_F32) {
             if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI, 0, 1>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
-            gemm_bt_quad_kernel<EPI, 0, 1><<<cus, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                            n_tiles, aux, epi_is_ln(EPI) ? (g_quad_defer && quad_defer_env()) : aux_i, aux2,
-                                                                            keds_numerics_guard(), ntiles, g_x3_aplane, g_x3_wplane);
+            KEDS_LAUNCH((gemm_bt_quad_kernel<EPI, 0, 1>), cus, 256, qd::LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
+                        n_tiles, aux, (int)(epi_is_ln(EPI) ? (g_quad_defer && quad_defer_env()) : aux_i), aux2,
+                        keds_numerics_guard(), ntiles, g_x3_aplane, g_x3_wplane);
             return keds_check_launch("gemm_bt_quad_kernel<persistent>");
         }
         if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
             if (g_quad3 && K >= 1024 && K / pr::TK >= 4) {               // long K: A operand through a three-deep ring
                 if (int rc = keds_func_lds_once((const void*)gemm_bt_quad3_kernel<EPI>, 5 * pr::OP_BYTES, "gemm_bt_quad3_kernel")) return rc;
-                gemm_bt_quad3_kernel<EPI><<<ntiles, 256, 5 * pr::OP_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
-                                                                                n_tiles, aux, ntiles);
+                KEDS_LAUNCH((gemm_bt_quad3_kernel<EPI>), ntiles, 256, 5 * pr::OP_BYTES, st, (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K,
+                            n_tiles, aux, ntiles);
                 return keds_check_launch("gemm_bt_quad3_kernel");
             }
         }
         if (int rc = keds_func_lds_once((const void*)gemm_bt_quad_kernel<EPI>, qd::LDS_BYTES, "gemm_bt_quad_kernel")) return rc;
-        gemm_bt_quad_kernel<EPI><<<ntiles, 256, qd::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles,
-                                                                     aux, aux_i, aux2, keds_numerics_guard(), ntiles, g_x3_aplane, g_x3_wplane);
+        KEDS_LAUNCH((gemm_bt_quad_kernel<EPI>), ntiles, 256, qd::LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles,
+                    aux, aux_i, aux2, keds_numerics_guard(), ntiles, g_x3_aplane, g_x3_wplane);
         return keds_check_launch("gemm_bt_quad_kernel");
     }
     if constexpr (EPI == KEDS_EPI_RESID_STATS_F16) {
         if (g_resid_prologue) {
             if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI, 0, 1>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
-            gemm_bt_pair_kernel<EPI, 0, 1><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>(
-                (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles, aux, aux_i, aux2, keds_numerics_guard());
+            KEDS_LAUNCH((gemm_bt_pair_kernel<EPI, 0, 1>), m_tiles * n_tiles, 512, pr::LDS_BYTES, st,
+                        (const bf16_t*)A, (const bf16_t*)W, bias, out, M, N, K, n_tiles, aux, aux_i, aux2, keds_numerics_guard(), 0LL, 0LL);
             return keds_check_launch("gemm_bt_pair_kernel");
         }
     }
-    gemm_bt_pair_kernel<EPI><<<m_tiles * n_tiles, 512, pr::LDS_BYTES, st>>>((const bf16_t*)A, (const bf16_t*)W, bias, out,
-                                                                            M, N, K, n_tiles, aux, aux_i, aux2,
-                                                                            keds_numerics_guard(), g_x3_aplane, g_x3_wplane);
+    KEDS_LAUNCH((gemm_bt_pair_kernel<EPI>), m_tiles * n_tiles, 512, pr::LDS_BYTES, st, (const bf16_t*)A, (const bf16_t*)W, bias, out,
+                M, N, K, n_tiles, aux, aux_i, aux2, keds_numerics_guard(), g_x3_aplane, g_x3_wplane);
     return keds_check_launch("gemm_bt_pair_kernel");
 }
 
@@ -1980,7 +1977,7 @@ bool big_tiles_ok(int M, int N, int K) {
 template <int EPI>
 int launch_gemm(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                 int aux_i, void* aux2, long long lda, long long ldc, hipStream_t st) {
-    KedsProfScope prof(KEDS_PROF_GEMM, st);
+    KedsProfScope prof(KEDS_PROF_GEMM, st, /*lazy: the launches bind the event pair (KEDS_LAUNCH)*/ true);
     prof.work(2.0 * M * N * K);
     // Large problems: full 256-row tiles go to the 256^2 kernel, the remainder rows (< 256) to the 128^2 one.
     // (ViT-L/14 at B=128: M = 32896 = 128*256 + 128, so 512..2048 big tiles = whole rounds on 256 CUs.)

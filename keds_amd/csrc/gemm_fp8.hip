@@ -919,9 +919,9 @@ int launch_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, cons
                  void* out, int M, int N, int K, float* aux, float* aux2, void* qout, void* qscale, int q_pad, hipStream_t st) {
     if (int rc = keds_func_lds_once((const void*)gemm_mxfp8_kernel<EPI, DBG>, LDS_BYTES, "gemm_mxfp8_kernel")) return rc;
     const int m_tiles = M / TM, n_tiles = N / TN;
-    gemm_mxfp8_kernel<EPI, DBG><<<m_tiles * n_tiles, 512, LDS_BYTES, st>>>(
-        (const unsigned char*)Aq, (const unsigned char*)As, (const unsigned char*)Wq, (const unsigned char*)Ws, bias, out, M, N, K,
-        n_tiles, m_pad, n_pad, aux, aux2, (unsigned char*)qout, (unsigned char*)qscale, q_pad);
+    KEDS_LAUNCH((gemm_mxfp8_kernel<EPI, DBG>), m_tiles * n_tiles, 512, LDS_BYTES, st,
+                (const unsigned char*)Aq, (const unsigned char*)As, (const unsigned char*)Wq, (const unsigned char*)Ws, bias, out, M, N, K,
+                n_tiles, m_pad, n_pad, aux, aux2, (unsigned char*)qout, (unsigned char*)qscale, q_pad);
     return keds_check_launch("gemm_mxfp8_kernel");
 }
 
@@ -946,9 +946,9 @@ int launch_mxfp8_quad(const void* Aq, const void* As, int m_pad, const void* Wq,
     // small launches slot in between them: the GEMM class takes 0.5 ms more per step, the gaps in front of the attention launches
     // shrink by as much -- 14.87-15.06 against 14.92-15.00 ms per step, four alternating runs on one box)
     const int grid = (cus >= 8 && ntiles > cus) ? cus : ntiles;
-    gemm_mxfp8_quad_kernel<EPI><<<grid, 256, fq::LDS_BYTES, st>>>(
-        (const unsigned char*)Aq, (const unsigned char*)As, (const unsigned char*)Wq, (const unsigned char*)Ws, bias, out, M, N, K,
-        n_tiles, m_pad, n_pad, aux, aux2, (unsigned char*)qout, (unsigned char*)qscale, q_pad, ntiles);
+    KEDS_LAUNCH((gemm_mxfp8_quad_kernel<EPI>), grid, 256, fq::LDS_BYTES, st,
+                (const unsigned char*)Aq, (const unsigned char*)As, (const unsigned char*)Wq, (const unsigned char*)Ws, bias, out, M, N, K,
+                n_tiles, m_pad, n_pad, aux, aux2, (unsigned char*)qout, (unsigned char*)qscale, q_pad, ntiles);
     return keds_check_launch("gemm_mxfp8_quad_kernel");
 }
 }  // namespace
@@ -961,7 +961,7 @@ extern "C" int keds_gemm_mxfp8_ex(const void* Aq, const void* As, int m_pad, con
     KEDS_REQUIRE(K % TKB == 0 && K >= 2 * TKB, "keds_gemm_mxfp8: K=%d must be a multiple of 128, >= 256", K);
     KEDS_REQUIRE(m_pad >= M && n_pad >= N && m_pad % 4 == 0 && n_pad % 4 == 0, "keds_gemm_mxfp8: bad scale row padding");
     hipStream_t st = (hipStream_t)stream;
-    KedsProfScope prof(KEDS_PROF_GEMM, st);
+    KedsProfScope prof(KEDS_PROF_GEMM, st, /*lazy: KEDS_LAUNCH binds the pair*/ true);
     prof.work(2.0 * M * N * K);
     // keds_mxfp8_debug(16): the 8-wave kernel whatever the shape (the bit-identity test's reference).  The fp32-residual epilogue
     // (3: API only, the towers keep their stream in fp16) stays on the 8-wave kernel: beside its 256-bit residual chunks the

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libkeds_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stddef.h>
 #include "../../include/keds_hip.h"
@@ -35,10 +36,31 @@ struct KedsProfScope {
     int klass;
     hipStream_t stream;
     void* slot;
-    KedsProfScope(int klass, hipStream_t s);
+    bool lazy, taken;          // lazy: the launches under this scope bind the pair themselves (KEDS_LAUNCH below)
+    double work_units;
+    hipEvent_t ev_a, ev_b;
+    KedsProfScope* outer;
+    KedsProfScope(int klass, hipStream_t s, bool lazy = false);
     ~KedsProfScope();
     void work(double units);   // algorithmic flops (GEMM) / bytes (scan) of this launch; counted only if it carries events
 };
+// Round 5: an event RECORDED on a stream is a marker packet of its own between two kernels (~3.5 us per pair: 0.9 % of the bench
+// step with the pairs of every fourth step's 100 GEMM launches); as the START / STOP events of the launch itself
+// (hipExtLaunchKernelGGL) they are the kernel's own dispatch signals and cost nothing.  A `lazy` scope records nothing: its
+// launches go through KEDS_LAUNCH, which hands the first launch the start event and every launch the stop event (stream order: the
+// last one's completion stays).  A lazy scope under which no KEDS_LAUNCH ran drops its pair.
+struct KedsLaunchEvents {
+    hipEvent_t start, stop;
+};
+KedsLaunchEvents keds_prof_launch_events(hipStream_t st);
+#define KEDS_LAUNCH(kernel, grid, block, lds, st, ...)                                                                    \
+    do {                                                                                                                  \
+        const KedsLaunchEvents le_ = keds_prof_launch_events(st);                                                         \
+        if (le_.stop)                                                                                                     \
+            hipExtLaunchKernelGGL((kernel), dim3(grid), dim3(block), (unsigned)(lds), (st), le_.start, le_.stop, 0, __VA_ARGS__); \
+        else                                                                                                              \
+            hipLaunchKernelGGL((kernel), dim3(grid), dim3(block), (unsigned)(lds), (st), __VA_ARGS__);                    \
+    } while (0)
 
 // ---- side lane (host): a second, high-priority stream per device for the remainder-row chain of the towers ----------
 // Callers fork to it / join from it with their own events (keds_stream_order).  nullptr when disabled (KEDS_SIDE_STREAM=0)
@@ -52,6 +74,14 @@ KedsSideLane* keds_side_lane();
 bool keds_side_lane_enabled();
 // record on `from`, make `to` wait: everything enqueued on `to` afterwards runs after everything enqueued on `from` so far
 int keds_stream_order(hipStream_t from, hipEvent_t ev, hipStream_t to);
+// an event recorded BY A LAUNCH (its stop event): lock, launch, keds_stream_wait_locked(ev, to), unlock (api.hip)
+void keds_order_lock();
+void keds_order_unlock();
+int keds_stream_wait_locked(hipEvent_t ev, hipStream_t to);
+// (attention.hip) the next S = 257 attention launch of this thread records `ev` as its stop event; returns through
+// keds_attention_stop_event_taken() whether a launch consumed it (other kernel forms do not: the caller records it itself then)
+void keds_attention_stop_event(hipEvent_t ev);
+bool keds_attention_stop_event_taken();
 
 static inline size_t keds_align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -1207,7 +1207,7 @@ int launch_scan(const void* packed, int stage_begin, int total_stages, const bf1
                  "keds_index_search: %d stages over %d workgroups: a workgroup's key stream would span 2 GiB or more "
                  "(search the index in row ranges)", total_stages, nwg);
     if (int rc = keds_func_lds_once((const void*)scan_topk_kernel<D, L>, (int)lds, "scan_topk_kernel")) return rc;
-    KedsProfScope prof(KEDS_PROF_SCAN, st);
+    KedsProfScope prof(KEDS_PROF_SCAN, st, /*lazy*/ !g_scan_debug);
     if constexpr (D == 768 && L == LISTK) {
         if (g_scan_debug) {
 #define KEDS_SCAN_DBG(V)                                                                                            \
@@ -1229,13 +1229,13 @@ int launch_scan(const void* packed, int stage_begin, int total_stages, const bf1
     if constexpr (D == 768 && L == LISTK) {
         if (g_scan_nt) {
             if (int rc = keds_func_lds_once((const void*)scan_topk_kernel<D, L, 0, 1>, (int)lds, "scan_topk_kernel<nt>")) return rc;
-            scan_topk_kernel<D, L, 0, 1><<<dim3(nwg, nqb), SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb,
-                                                                                     thr, lval, lidx);
+            KEDS_LAUNCH((scan_topk_kernel<D, L, 0, 1>), dim3(nwg, nqb), SCAN_THREADS, lds, st, (const char*)packed, stage_begin, total_stages, qb,
+                        thr, lval, lidx);
             return keds_check_launch("scan_topk_kernel<nt>");
         }
     }
-    scan_topk_kernel<D, L><<<dim3(nwg, nqb), SCAN_THREADS, lds, st>>>((const char*)packed, stage_begin, total_stages, qb, thr, lval,
-                                                           lidx);
+    KEDS_LAUNCH((scan_topk_kernel<D, L>), dim3(nwg, nqb), SCAN_THREADS, lds, st, (const char*)packed, stage_begin, total_stages, qb, thr, lval,
+                lidx);
     return keds_check_launch("scan_topk_kernel");
 }
 

@@ -97,6 +97,27 @@ struct RowLanes {
         return KEDS_OK;
     }
     int to_side() { return split ? keds_stream_order(main, fork, side) : KEDS_OK; }
+    // the fork behind an attention launch: the launch records the event itself (its stop event: no marker packet between it and
+    // the next GEMM on the main stream); kernel forms that do not take it get the recorded event.  KEDS_FORK_EXT=0: always recorded (A/B)
+    template <typename F>
+    int attention_then_side(F launch) {
+        static const bool ext = [] {
+            const char* e = getenv("KEDS_FORK_EXT");
+            return !(e && e[0] == '0');
+        }();
+        if (!split || !ext) {
+            const int rc = launch();
+            return rc ? rc : to_side();
+        }
+        keds_order_lock();
+        keds_attention_stop_event(fork);
+        int rc = launch();
+        const bool taken = keds_attention_stop_event_taken();
+        if (!rc && taken) rc = keds_stream_wait_locked(fork, side);
+        keds_order_unlock();
+        if (!rc && !taken) rc = to_side();
+        return rc;
+    }
     int to_main() { return split ? keds_stream_order(side, join, main) : KEDS_OK; }
 };
 
@@ -331,8 +352,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
                 if ((rc = lanes.to_main())) return rc;               // main: behind the tail samples' attention
             } else {
                 if ((rc = lanes.to_main())) return rc;
-                if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
-                if ((rc = lanes.to_side())) return rc;
+                if ((rc = lanes.attention_then_side([&] { return keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st); }))) return rc;
             }
             if ((rc = out_rows(t, k, w, body))) return rc;
             if (rem.n && (rc = out_rows(t, k, w, rem))) return rc;
