@@ -250,8 +250,8 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
         if (last && last_rows) return rows_tail(p, k, t, x, t.h, B, last_rows, st);
         if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, t.h, B, st);
         // attention writes its output as MXFP8 for the full-tile rows and as bf16 for the remainder rows
-        if ((rc = keds_attention_mx(t.qkv, t.att, B, S, p->heads, p->causal, S, t.aq, t.as, Mm, st))) return rc;
-        if ((rc = lanes.to_side())) return rc;
+        if ((rc = lanes.attention_then_side([&] { return keds_attention_mx(t.qkv, t.att, B, S, p->heads, p->causal, S, t.aq, t.as, Mm, st); })))
+            return rc;
         if ((rc = keds_gemm_mxfp8_ex(t.aq, t.as, Mm, k.out_q8, k.out_s8, w, k.out_b, t.h, Mm, w, w,
                                      KEDS_FP8_EPI_RESID_STATS_MX_H, (float*)t.st2, nullptr, t.xq, t.xs, Mm, st)))
             return rc;
