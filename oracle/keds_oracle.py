@@ -486,17 +486,26 @@ def synth_tensor(key: str, shape: Sequence[int], std: float, seed: int = 0) -> T
 
 def synth_clip_state_dict(embed_dim=768, image_resolution=224, vision_layers=24, vision_width=1024,
                           vision_patch_size=14, context_length=77, vocab_size=49408,
-                          transformer_width=768, transformer_layers=12, seed: int = 0) -> Dict[str, Tensor]:
+                          transformer_width=768, transformer_layers=12, seed: int = 0,
+                          visual_only: bool = False) -> Dict[str, Tensor]:
     """Seeded random-init weights with the reference's init stds
     (src/model/model.py:383-391,511-541).  LayerNorm gains get a small perturbation
-    around 1 so a gain/bias mix-up cannot hide."""
+    around 1 so a gain/bias mix-up cannot hide.  Every tensor has its own key-derived seed, so
+    `visual_only=True` (text-tower tensors left zero: right shapes, no random draw; a third of the
+    generation time) yields the SAME visual tower as the full dictionary."""
     sd: Dict[str, Tensor] = {}
     g = image_resolution // vision_patch_size
 
     def t(key, shape, std):
+        if visual_only and not key.startswith("visual."):
+            sd[key] = torch.zeros(tuple(shape), dtype=torch.float32)
+            return
         sd[key] = synth_tensor(key, shape, std, seed)
 
     def ln(key, d):
+        if visual_only and not key.startswith("visual."):
+            sd[key + ".weight"], sd[key + ".bias"] = torch.ones(d), torch.zeros(d)
+            return
         sd[key + ".weight"] = 1.0 + synth_tensor(key + ".weight", [d], 0.05, seed)
         sd[key + ".bias"] = synth_tensor(key + ".bias", [d], 0.05, seed)
 
