@@ -166,7 +166,11 @@ __device__ __forceinline__ void mx_epilogue_rows(const f32x4 (&a)[4], int mi, co
         const f32x2 cf = *reinterpret_cast<const f32x2*>(side + (128 * wm + 16 * mi + c) * 8);
         rstd = cf[0];
         nmr = cf[1];
-        if (aux2 && n0 == 0 && wn == 0 && g == 0) keds_stat_zero(reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)m);
+        if (aux2 && n0 == 0 && wn == 0 && g == 0) {               // (a zero made HERE: as a hoisted constant it is four registers held -- or spilled -- across the K-loop)
+            unsigned z;
+            asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+            *reinterpret_cast<u32x4*>(reinterpret_cast<keds_stat_t*>(aux2) + 2 * (size_t)m) = u32x4{z, z, z, z};
+        }
     }
     [[maybe_unused]] float rs = 0.f, rss = 0.f;
     [[maybe_unused]] uint2 mxk = uint2{0u, 0u};
@@ -521,6 +525,14 @@ __global__ __launch_bounds__(512, 2) void gemm_mxfp8_kernel(const unsigned char*
 //     odd gaps (W fragment j at gaps 8j + 7 / 8j + 9), scale dwords in gaps n % 4 == 2 (read in one gap, packed into the byte
 //     the instruction's op_sel picks in the next: four e8m0 scales per register);
 //   tiles: persistent walk, the next tile's first two K-tiles and side data requested before this tile's epilogue.
+// the lane id from the execution mask, made where it is used: thread-id arithmetic kept in registers across the K-loop is what the
+// 4-wave kernel has no room for (round 6: the allocator spilled the thread id and reloaded it behind `s_waitcnt vmcnt(0)` -- a wait
+// for every DMA piece in flight -- in front of the epilogue)
+__device__ __forceinline__ int lane_now() {
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 namespace fq {
 // LDS: X0 | X1 | W0 | W1 | sX0 | sX1 | sW0 | sW1 | side areas.  The two K-tile buffers of an operand are 32 KiB (scales: 1 KiB)
 // apart, so the buffer is part of a read's 16-bit immediate offset and ONE address register per (operand, chunk) serves both.
@@ -610,15 +622,16 @@ constexpr int LDS_BYTES = RAW + 6144;            // 146 KiB
     KEDS_FQ_ONE(FIRST, j, 6, xc, sxc, swc, xn, sxn, swn, nb, ISSUE, ip, PF)                                      \
     KEDS_FQ_ONE(FIRST, j, 7, xc, sxc, swc, xn, sxn, swn, nb, ISSUE, ip, PF)
 // One K-tile: 64 MFMAs from (w, xc) with the scales (swc, sxc); the next K-tile's fragments / scales go to (w in place, xn,
-// swn, sxn) from buffer `nb`; ISSUE: the DMA pieces of K-tile `ip`; SYNC: the next K-tile has landed and its predecessor's
-// buffer is free (wait + barrier)
+// swn, sxn) from buffer `nb`; ISSUE: the DMA pieces of K-tile `ip`; SYNC_ 1: the next K-tile has landed and its predecessor's
+// buffer is free (wait + barrier), 2: the buffer is free (every wave's fragment reads of it are done; no wait for pieces)
 #define KEDS_FQ_STEP(FIRST, xc, sxc, swc, xn, sxn, swn, nb, SYNC_, ISSUE_, ip, PF_)                              \
     {                                                                                                            \
-        constexpr bool SYNC = (SYNC_) && !(KEDS_FQ_ABL & 256), ISSUE = (ISSUE_) && !(KEDS_FQ_ABL & 64),          \
+        constexpr int SYNCM = (KEDS_FQ_ABL & 256) ? 0 : (int)(SYNC_);                                            \
+        constexpr bool SYNC = SYNCM == 1, ISSUE = (ISSUE_) && !(KEDS_FQ_ABL & 64),                               \
                        PF = (PF_) && !(KEDS_FQ_ABL & 128);                                                       \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
         if constexpr (SYNC && (KEDS_FQ_ABL & 512)) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     \
-        else if constexpr (SYNC && (KEDS_FQ_ABL & 1024)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+        else if constexpr ((SYNC && (KEDS_FQ_ABL & 1024)) || SYNCM == 2) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
         else if constexpr (SYNC && (KEDS_FQ_ABL & 2048)) asm volatile("s_barrier" ::: "memory");                  \
         else if constexpr (SYNC) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        \
         __builtin_amdgcn_sched_barrier(0);                                                                       \
@@ -700,28 +713,16 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
         if constexpr (LN) {
             // (buffer form: a FLAT-encoded global_load_lds makes the compiler's wait-count pass treat every later LDS wait as
             // out of order -- lgkmcnt(0) in front of each scale pack, a stall per gap)
+            // (lane offsets made here: as loop invariants they would be two more registers held -- or spilled -- across the K-loop)
+            const int te = wave * 64 + lane_now();
             const auto strs = make_rs(reinterpret_cast<const keds_stat_t*>(aux) + 2 * (size_t)m0_);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(strs, (__attribute__((address_space(3))) void*)(smem + fq::RAW + wave * 1024), 16,
-                                                     soff + wave * 1024, 0, 0, 0);
+                                                     te * 16, 0, 0, 0);
             if (wave < 2) {
                 const auto brs = make_rs(bias + (wave ? N : 0) + n0_);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(brs, (__attribute__((address_space(3))) void*)(smem + fq::RAW + 4096 + wave * 1024), 16,
-                                                         soff, 0, 0, 0);
+                                                         (te & 63) * 16, 0, 0, 0);
             }
-        }
-    };
-    auto side_write = [&](char* side) {
-        if constexpr (LN) {
-            const u32x4 st_raw = *reinterpret_cast<const u32x4*>(smem + fq::RAW + tid * 16);
-            const float pb = *reinterpret_cast<const float*>(smem + fq::RAW + 4096 + tid * 4);
-            const float pc = *reinterpret_cast<const float*>(smem + fq::RAW + 5120 + tid * 4);
-            const float invk_ = 1.0f / (float)K;
-            const float mean = keds_stat_value((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0])) * invk_;
-            const float ss = keds_stat_value((keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]));
-            const float rsd = rsqrtf(fmaxf(ss * invk_ - mean * mean, 0.f) + 1e-5f);
-            *reinterpret_cast<f32x2*>(side + tid * 8) = f32x2{rsd, -mean * rsd};
-            *reinterpret_cast<float*>(side + 2048 + tid * 4) = pb;
-            *reinterpret_cast<float*>(side + 3072 + tid * 4) = pc;
         }
     };
 
@@ -749,11 +750,15 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
 #endif
     for (int it = 0;; ++it) {
         KEDS_FQ_TS(0)
-        // this tile's K-tiles 0 and 1 and its raw side data have landed (requested before the previous tile's epilogue)
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        // this tile's K-tiles 0 and 1 and its raw side data have landed.  They were requested in the last two K-steps of the previous
+        // tile, AHEAD of its epilogue's stores; vmcnt retires in order (loads and stores alike on this family), so the wait leaves
+        // the epilogue's last NST stores in flight instead of sitting out their write latency (~1 k cycles per tile, round 4 stamps)
+        // (12: every epilogue issues at least 32 stores behind the last DMA piece; a store takes ~250 cycles to issue and ~1-2 k to
+        // retire, so the youngest dozen are the ones still in flight here)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         KEDS_FQ_TS(1)
         char* side = smem + fq::SIDE0 + (it & 1) * 4096;
-        side_write(side);                                          // (read in the epilogue, a dozen barriers from here)
         const int nid = id + step;
         const bool more = nid < ntiles;
         int nm0 = 0, nn0 = 0;
@@ -763,15 +768,21 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
             nm0 = ntm * TM;
             nn0 = ntn * TN;
         }
-        // K-tile 0: all fragments and scales from buffer 0
+        // K-tile 0: all fragments and scales from buffer 0.  EVERY LDS read of the tile start is issued back to back -- raw side
+        // data, the 32 fragment chunks, the 16 scale dwords -- and only then does arithmetic begin: the side data (a dependent chain
+        // of fp64 conversions) under the fragment reads, the scale bytes packed last.  (Round 4's order -- side data read, converted
+        // and written first, the scale dwords read two at a time between their shifts -- cost four LDS round trips behind the other
+        // waves' 32 KiB of fragment reads: 4.2 k cycles per tile where the reads themselves need ~1.2 k, profiles/r04_fp8_tile_phases.txt.)
         i32x8 xa[8], xb[8], w[8];
         unsigned sxa[2], sxb[2], swa[2], swb[2], sct[3];
         {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const i32x4 lo = *reinterpret_cast<const i32x4*>(smem + wrd0 + j * 2048);
-                const i32x4 hi = *reinterpret_cast<const i32x4*>(smem + wrd1 + j * 2048);
-                w[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            [[maybe_unused]] u32x4 st_raw = u32x4{0, 0, 0, 0};
+            [[maybe_unused]] float pb = 0.f, pc = 0.f;
+            const int te = wave * 64 + lane_now();                 // (see side_load)
+            if constexpr (LN) {
+                st_raw = *reinterpret_cast<const u32x4*>(smem + fq::RAW + te * 16);
+                pb = *reinterpret_cast<const float*>(smem + fq::RAW + 4096 + te * 4);
+                pc = *reinterpret_cast<const float*>(smem + fq::RAW + 5120 + te * 4);
             }
 #pragma unroll
             for (int mi = 0; mi < 8; ++mi) {
@@ -779,12 +790,34 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
                 const i32x4 hi = *reinterpret_cast<const i32x4*>(smem + xrd1 + mi * 2048);
                 xa[mi] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
-            const unsigned sh8 = 8 * g;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const i32x4 lo = *reinterpret_cast<const i32x4*>(smem + wrd0 + j * 2048);
+                const i32x4 hi = *reinterpret_cast<const i32x4*>(smem + wrd1 + j * 2048);
+                w[j] = i32x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            unsigned sraw[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                sraw[k] = *reinterpret_cast<const unsigned*>(smem + sx_off + k * 64);
+                sraw[8 + k] = *reinterpret_cast<const unsigned*>(smem + sw_base + (64 * (k >> 2) + 32 * ((k >> 1) & 1) + 4 * (k & 1)) * 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LN) {
+                const float invk_ = 1.0f / (float)K;
+                const float mean = keds_stat_value((keds_stat_t)(((unsigned long long)st_raw[1] << 32) | st_raw[0])) * invk_;
+                const float ss = keds_stat_value((keds_stat_t)(((unsigned long long)st_raw[3] << 32) | st_raw[2]));
+                const float rsd = rsqrtf(fmaxf(ss * invk_ - mean * mean, 0.f) + 1e-5f);
+                *reinterpret_cast<f32x2*>(side + te * 8) = f32x2{rsd, -mean * rsd};      // (read in the epilogue, a dozen barriers from here)
+                *reinterpret_cast<float*>(side + 2048 + te * 4) = pb;
+                *reinterpret_cast<float*>(side + 3072 + te * 4) = pc;
+            }
+            const unsigned sh8 = 8 * ((unsigned)(te & 63) >> 4);   // 8 g
             sxa[0] = sxa[1] = swa[0] = swa[1] = 0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
-                sxa[k >> 2] |= ((*reinterpret_cast<const unsigned*>(smem + sx_off + k * 64) >> sh8) & 0xFFu) << (8 * (k & 3));
-                swa[k >> 2] |= ((*reinterpret_cast<const unsigned*>(smem + sw_base + (64 * (k >> 2) + 32 * ((k >> 1) & 1) + 4 * (k & 1)) * 4) >> sh8) & 0xFFu) << (8 * (k & 3));
+                sxa[k >> 2] |= ((sraw[k] >> sh8) & 0xFFu) << (8 * (k & 3));
+                swa[k >> 2] |= ((sraw[8 + k] >> sh8) & 0xFFu) << (8 * (k & 3));
             }
         }
         // K-tiles 0 | 1 | [2j, 2j + 1] | np - 2 | np - 1
@@ -792,20 +825,39 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
         KEDS_FQ_TS(2)
-        KEDS_FQ_STEP(true, xa, sxa, swa, xb, sxb, swb, 1, true, true, 2, true)
-        KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, true, true, 3, true)
+        // (step 0 syncs in mode 2: K-tile 1 landed behind the wait that opened the tile; what the step needs is buffer 0 free of
+        // every wave's K-tile-0 reads -- and a vmcnt(0) here would sit out the previous epilogue's stores after all)
+        KEDS_FQ_STEP(true, xa, sxa, swa, xb, sxb, swb, 1, 2, true, 2, true)
+        KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, 1, true, 3, true)
         for (int p = 2; p + 2 < np && !(KEDS_FQ_ABL & 2); p += 2) {
-            KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, true, true, p + 2, true)
-            KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, true, true, p + 3, true)
+            KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, 1, true, p + 2, true)
+            KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, 1, true, p + 3, true)
         }
-        KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, true, false, 0, true)
-        KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, false, false, 0, false)
+        // the last two K-steps.  FOLD: their DMA slots carry the NEXT tile's K-tiles 0 and 1 (and its raw side data goes out in
+        // front of them): K-tile np - 2's fragments are in registers when step np - 2 starts, so buffer 0 is free behind that step's
+        // barrier, and buffer 1 behind the last step's (mode 2: every wave's reads of K-tile np - 1 are done; no wait for pieces).
+        // Round 4 issued these 34 requests between the K-loop and the epilogue -- 3.6 k cycles per tile with the matrix pipe idle
+        // (profiles/r04_fp8_tile_phases.txt).  The fp16-residual epilogue keeps that order: its residual chunks must leave ahead of the
+        // pieces (below); folded, out-proj gains 3 % alone and the step nothing (profiles/r06_fp8_tile_switch_ab.txt).  A workgroup on its last tile re-requests its own tile's K-tiles (same code path, 132 KB
+        // once per launch) and waits for them before it ends.
+        constexpr bool FOLD = EPI != 4;
+        if constexpr (FOLD) {
+            if (more) {
+                side_load(nm0, nn0);
+                point_at(nm0, nn0);
+            }
+            KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, 1, true, 0, true)
+            KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, 2, true, 1, false)
+        } else {
+            KEDS_FQ_STEP(false, xa, sxa, swa, xb, sxb, swb, 1, 1, false, 0, true)
+            KEDS_FQ_STEP(false, xb, sxb, swb, xa, sxa, swa, 0, 0, false, 0, false)
+        }
 
         KEDS_FQ_TS(3)
         // (the lane coordinates through an opaque move: everything the epilogue derives from them is otherwise loop invariant, and
         // hoisted out of the tile loop it is ~60 registers the K-loop does not have)
-        int ge = g, ce = c;
-        asm volatile("" : "+v"(ge), "+v"(ce));
+        const int le = lane_now();
+        const int ge = le >> 4, ce = le & 15;
         // fp16 residual epilogue: the tile's residual chunks are requested HERE, in front of the next tile's 34 DMA pieces (vmcnt
         // retires in order: behind them a chunk waits for all of them, and loaded one by one between the stores of the epilogue --
         // the compiler cannot move a load above a store to the same array -- each chunk pays its own round trip: a cold
@@ -824,18 +876,20 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
                     rpre[h][mi][pp] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(ors, voff, (16 * mi * N + 64 * h + 32 * pp) * 2, 0));
         };
         if constexpr (EPI == 4) resid_request(0);
-        if (more) {
-            // every wave has issued its last fragment reads (they completed before its last step's MFMAs could start): both
-            // buffers are free for the next tile's K-tiles 0, 1
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            side_load(nm0, nn0);
-            point_at(nm0, nn0);
+        if constexpr (!FOLD) {
+            if (more) {
+                // every wave has issued its last fragment reads (they completed before its last step's MFMAs could start): both
+                // buffers are free for the next tile's K-tiles 0, 1
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                side_load(nm0, nn0);
+                point_at(nm0, nn0);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) issue(0, q);
-            issue_scales(0);
+                for (int q = 0; q < 16; ++q) issue(0, q);
+                issue_scales(0);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) issue(1, q);
-            issue_scales(1);
+                for (int q = 0; q < 16; ++q) issue(1, q);
+                issue_scales(1);
+            }
         }
         if constexpr (EPI == 4) resid_request(1);
         KEDS_FQ_TS(4)
@@ -884,6 +938,7 @@ __global__ __launch_bounds__(256, 1) void gemm_mxfp8_quad_kernel(const unsigned 
         m0 = nm0;
         n0 = nn0;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the last tile's re-requested K-tiles: no LDS-DMA write may outlive the workgroup)
 #undef KEDS_FQ_TS
 #undef make_rs
 }
