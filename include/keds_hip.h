@@ -30,7 +30,7 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 7
+#define KEDS_ABI_VERSION 8        /* 8 (round 6): keds_gemm_x3 takes w_exp, keds_split_f16_weight, keds_block_params.x3_exp; keds_gemm_duo_enable left the product */
 
 int keds_abi_version(void);
 /* compiler flags of this build beyond the Makefile's defaults ("" for the product build; `make EXTRA="-D..."` variants of the
@@ -194,10 +194,12 @@ int keds_label_hits(const int32_t* order, int nq, int ng, const int32_t* gallery
 #define KEDS_EPI_BIAS_BF16_HEADF32 12 /* out bf16 = acc + bias, and rows m < aux_i also as fp32 to ((float*)aux)[m*3N + n]: IM2TEXT's
                                        * last layer writes the bf16 rows the CrossFormers read AND token slot 2 of [B,3,N] */
 /* Split-operand GEMMs of the "fp32x3" operating point (round 5): BOTH operands are pairs of fp16 planes, x = hi + lo with
- * hi = fp16(x), lo = fp16(x - hi) (22 significant bits; |x| < 65504), and the product is  hi.hi + hi.lo + lo.hi  on the fp16
- * MFMA with fp32 accumulation -- three times the matrix work of a bf16 GEMM, ~1/5 of the time of the f32-input MFMA (157 TF),
- * and fp32-grade results (the dropped lo.lo term is 2^-22 relative).  A = planes [2][rows][K] (keds_split_f16_pair), W = planes
- * [2][N][K]; called through keds_gemm_x3. */
+ * hi = fp16(x), lo = fp16(x - hi) (|x| < 65504; 22 significant bits while lo is a normal fp16 number, i.e. |x| >= 2^-3 -- below
+ * that an absolute 2^-25), and the product is  hi.hi + hi.lo + lo.hi  on the fp16 MFMA with fp32 accumulation -- three times
+ * the matrix work of a bf16 GEMM, ~1/5 of the time of the f32-input MFMA (157 TF), and fp32-grade results (the dropped lo.lo term
+ * is 2^-22 relative).  A = planes [2][rows][K] (keds_split_f16_pair: activations are O(1)), W = planes [2][N][K] of W 2^e
+ * (keds_split_f16_weight: an exact per-matrix power of two that lifts small weights out of the subnormal range; the epilogue
+ * takes it out again); called through keds_gemm_x3. */
 #define KEDS_EPI_X3_BIAS_F32 13     /* out f32 = acc + bias */
 #define KEDS_EPI_X3_RESID_F32 14    /* out f32 += acc + bias (in place) */
 #define KEDS_EPI_X3_QGELU_PAIR 15   /* out = fp16 planes [2][rows][N] of qgelu(acc + bias) (full-precision expf / division): the
@@ -269,18 +271,21 @@ int keds_gemm_set_workspace(void* ptr, size_t bytes);
  * only), bit 9 disables split-K; A/B switches of the 256x256 kernels: bit 10 residual tile as the accumulators' initial
  * value, bits 11-12 kernel form (1 = 4 waves, 2 = 4 waves persistent, 3 = 8 waves; 0 = by shape), bits 13-15 stamped
  * diagnostic build, bit 16 no three-deep A ring, bit 17 no deferred epilogue stores in the persistent kernel */
-/* out = epilogue(A . W^T + bias) on split fp16 operands (KEDS_EPI_X3_*): A_hi = a, A_lo = a + a_plane elements (rows of lda
- * elements), W_hi = w, W_lo = w + w_plane (dense [N, K]).  M, N, K as keds_gemm_bt_ex2; ldc in elements of the output type. */
+/* out = epilogue(A . W^T 2^-w_exp + bias) on split fp16 operands (KEDS_EPI_X3_*): A_hi = a, A_lo = a + a_plane elements (rows of
+ * lda elements), W_hi = w, W_lo = w + w_plane (dense [N, K]); the W planes hold W 2^w_exp (keds_split_f16_weight; 0 for planes
+ * of the matrix as stored).  M, N, K as keds_gemm_bt_ex2; ldc in elements of the output type. */
 int keds_gemm_x3(const void* a, int64_t a_plane, int64_t lda, const void* w, int64_t w_plane, const float* bias, void* out,
-                 int64_t ldc, int M, int N, int K, int epilogue, int aux_i, void* stream);
-/* x fp32 [rows, cols] (row stride ld elements) -> fp16 planes hi = out, lo = out + plane (dense rows of `cols`): the A / W operand
- * of keds_gemm_x3.  Values beyond the fp16 range raise *overflow (device int32, nullable) instead of going through as inf. */
+                 int64_t ldc, int M, int N, int K, int epilogue, int aux_i, int w_exp, void* stream);
+/* x fp32 [rows, cols] (row stride ld elements) -> fp16 planes hi = out, lo = out + plane (dense rows of `cols`): the A operand
+ * of keds_gemm_x3.  x = hi + lo to 22 significant bits for |x| >= 2^-3; below that the low plane is an fp16 subnormal and the pair
+ * carries x to an ABSOLUTE 2^-25 (activations are O(1): LayerNorm outputs, attention outputs, QuickGELU values).  Values beyond
+ * the fp16 range raise *overflow (device int32, nullable) instead of going through as inf. */
 int keds_split_f16_pair(const float* x, int64_t ld, int64_t rows, int cols, void* out, int64_t plane, int* overflow, void* stream);
+/* A WEIGHT matrix w fp32 dense [n, k] -> the planes of w 2^e, with e = *w_exp (host int, written) chosen so that max |w| 2^e lies
+ * in [2^13, 2^14): small weights (|w| ~ 1e-2 .. 1e-3 in real checkpoints) then keep 22 bits -- split as stored their low plane
+ * falls into the fp16 subnormals and keeps 14-17.  Pass *w_exp to keds_gemm_x3.  Packing-time call: waits for the stream once. */
+int keds_split_f16_weight(const float* w, int64_t n, int k, void* out, int64_t plane, int* w_exp, void* stream);
 int keds_gemm_force_small(int on);
-/* The 256 x 256 GEMMs with LayerNorm-folded fp16-operand epilogues (in_proj, c_fc) on the two-accumulator-set kernel (round 5,
- * csrc/gemm_duo.hip: the epilogue of one 128 x 256 unit runs in the gaps between the next unit's MFMAs): 1 on, 0 off (the
- * round-4 kernels), -1 = the KEDS_GEMM_DUO environment variable decides (default on).  Same bits either way. */
-int keds_gemm_duo_enable(int on);
 
 /* y = LayerNorm(x) * gamma + beta over the last dim (fp32 statistics, eps 1e-5).
  * x fp32 [rows, dim] with row stride x_stride (elements); out bf16 (out_f32 == 0) or fp32,
@@ -353,6 +358,8 @@ typedef struct {
     const void *qkv_q8, *out_q8, *fc_q8, *proj_q8;
     const void *qkv_s8, *out_s8, *fc_s8, *proj_s8;
     const float *qkv_bc8, *fc_bc8;                  /* fp32 [2*3d], [2*4d] for the MXFP8 weights */
+    /* keds_tower_params.f32 == 2 only: the exponents keds_split_f16_weight returned for qkv_w, out_w, fc_w, proj_w */
+    int x3_exp[4];
 } keds_block_params;
 
 typedef struct {

@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libkeds_hip.so")
 
 # ---- constants mirrored from keds_hip.h ------------------------------------------------------
-ABI_VERSION = 7
+ABI_VERSION = 8
 METRIC_L2, METRIC_IP = 0, 1
 EPI_BIAS_BF16, EPI_BIAS_QGELU_BF16, EPI_BIAS_RELU_BF16, EPI_BIAS_RESID_F32, EPI_BIAS_F32, EPI_PATCH_F32 = range(6)
 EPI_LN_BIAS_BF16, EPI_LN_QGELU_BF16, EPI_RESID_STATS_F32, EPI_RESID_STATS_F16 = 6, 7, 8, 9
@@ -36,7 +36,7 @@ class BlockParams(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv_w", "out_w", "fc_w", "proj_w",
                                   "qkv_b", "out_b", "fc_b", "proj_b", "qkv_wf", "fc_wf", "qkv_bc", "fc_bc",
                                   "qkv_q8", "out_q8", "fc_q8", "proj_q8", "qkv_s8", "out_s8", "fc_s8", "proj_s8",
-                                  "qkv_bc8", "fc_bc8")]
+                                  "qkv_bc8", "fc_bc8")] + [("x3_exp", i32 * 4)]      # (f32 == 2: exponents of the split weights)
 
 
 class TowerParams(C.Structure):
@@ -162,9 +162,9 @@ SIGNATURES = {
     "keds_gemm_bt": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, vp, i32, vp]),
     "keds_gemm_set_workspace": (i32, [vp, sz]),
     "keds_gemm_force_small": (i32, [i32]),
-    "keds_gemm_x3": (i32, [vp, C.c_int64, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, i32, i32, i32, i32, i32, vp]),
+    "keds_gemm_x3": (i32, [vp, C.c_int64, C.c_int64, vp, C.c_int64, vp, vp, C.c_int64, i32, i32, i32, i32, i32, i32, vp]),
     "keds_split_f16_pair": (i32, [vp, C.c_int64, C.c_int64, i32, vp, C.c_int64, vp, vp]),
-    "keds_gemm_duo_enable": (i32, [i32]),
+    "keds_split_f16_weight": (i32, [vp, C.c_int64, i32, vp, C.c_int64, C.POINTER(i32), vp]),
     "keds_gemm_bt_ex2": (i32, [vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, vp, i32, vp, vp]),
     "keds_fold_layernorm": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp]),
     "keds_rowstats_cast": (i32, [vp, vp, vp, i32, i32, vp]),
@@ -282,6 +282,11 @@ def source_digest() -> str:
     if extra:
         h.update(b"EXTRA " + extra.encode())
     return h.hexdigest()[:16]
+
+
+def build_flags() -> str:
+    """The EXTRA flags the loaded library was built with ("" for the product build; "-DKEDS_EXPERIMENTS ..." for the A/B tools')."""
+    return (load().keds_build_flags() or b"").decode().strip()
 
 
 def last_error() -> str:

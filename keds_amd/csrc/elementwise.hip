@@ -26,7 +26,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= rows) return;
-    const long long src = (long long)r * row_mul + (row_map ? row_map[r] : 0);
+    // (a gathered row outside its sequence -- a read-out column >= the cut the caller declared, keds_text_run_ex's seq_used -- would
+    // read another sample's token: such a row comes out as NaN instead, loudly)
+    const int rm = row_map ? row_map[r] : 0;
+    const bool bad_row = row_map && (unsigned)rm >= (unsigned)row_mul;
+    const long long src = (long long)r * row_mul + (bad_row ? 0 : rm);
     const float* p = x + src * x_stride;
     constexpr int MAXV = NV > 0 ? NV : LN_MAXV;
     f32x4 v[MAXV], gg[MAXV], bb[MAXV];
@@ -57,7 +61,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
             q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)dim + LN_EPS);
+    const float rstd = bad_row ? __builtin_nanf("") : rsqrtf(wave_sum(q) / (float)dim + LN_EPS);
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
         const int i = j * 256 + lane * 4;
@@ -165,7 +169,19 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const void* __restrict
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= B * per_row) return;
     const int b = id / per_row, i = (id - b * per_row) << 3;
-    const size_t so = ((size_t)b * S + row[b]) * dim + i, d_o = (size_t)b * dim + i;
+    const size_t d_o = (size_t)b * dim + i;
+    if ((unsigned)row[b] >= (unsigned)S) {        // a row outside its sequence (see layernorm_kernel): NaN, not a neighbour's token
+        if constexpr (MODE == 0) {
+            *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(dst) + d_o) = u32x4{0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu, 0x7FFF7FFFu};
+        } else {
+            const float qn = __builtin_nanf("");
+            float* o = reinterpret_cast<float*>(dst) + d_o;
+            *reinterpret_cast<f32x4*>(o) = f32x4{qn, qn, qn, qn};
+            *reinterpret_cast<f32x4*>(o + 4) = f32x4{qn, qn, qn, qn};
+        }
+        return;
+    }
+    const size_t so = ((size_t)b * S + row[b]) * dim + i;
     if constexpr (MODE == 0) {
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(dst) + d_o) =
             *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(src) + so);
@@ -532,7 +548,7 @@ __global__ __launch_bounds__(256) void layernorm_pair_stream_kernel(const float*
 static bool ln_stream_env() {          // KEDS_LN_STREAM=0 in the environment: the one-row-per-wave form (A/B)
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("KEDS_LN_STREAM");
+        const char* e = keds_exp_env("KEDS_LN_STREAM");
         v = !(e && e[0] == '0');
     }
     return v != 0;
@@ -555,10 +571,14 @@ int keds_layernorm_pair_impl(const float* x, long long x_stride, const float* ga
     return keds_check_launch("layernorm_kernel<pair>");
 }
 
-// x fp32 [rows, cols] -> fp16 planes hi / lo (x = hi + lo to 22 significant bits); one thread per 8 elements.  |x| >= 65504 does
+// x fp32 [rows, cols] -> fp16 planes hi / lo (x = hi + lo: 22 significant bits for |x| >= 2^-3, an absolute 2^-25 below -- the low
+// plane of a small value is an fp16 subnormal); one thread per 8 elements.  |x| >= 65504 does
 // not fit an fp16 hi: the flag (nullable) is raised and the caller falls back to the f32-input MFMA flow.
+// `scale` (an exact power of two; 1 for activations): the planes hold x * scale -- weights are split at a scale that puts their
+// largest element in [2^13, 2^14), see keds_split_f16_weight.
 __global__ __launch_bounds__(256) void split_f16_pair_kernel(const float* __restrict__ x, long long ld, long long rows, int cols,
-                                                             f16_t* __restrict__ out, long long plane, int* __restrict__ overflow) {
+                                                             f16_t* __restrict__ out, long long plane, int* __restrict__ overflow,
+                                                             float scale) {
     const int per_row = cols >> 3;
     const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
     if (id >= rows * per_row) return;
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(256) void split_f16_pair_kernel(const float* __rest
     bool bad = false;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const float v = j < 4 ? a[j] : b[j - 4];
+        const float v = (j < 4 ? a[j] : b[j - 4]) * scale;
         bad |= !(fabsf(v) < 65504.0f);
         hi[j] = (f16_t)v;
         lo[j] = (f16_t)(v - (float)hi[j]);
@@ -581,13 +601,67 @@ __global__ __launch_bounds__(256) void split_f16_pair_kernel(const float* __rest
     if (bad && overflow) *overflow = 1;
 }
 
+// max |x| over a dense array as the bit pattern of a non-negative float (atomicMax on unsigned keeps the float order); NaN / inf
+// come out as a pattern >= 0x7F800000
+__global__ __launch_bounds__(256) void absmax_bits_kernel(const float* __restrict__ x, long long n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7FFFFFFFu);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 extern "C" int keds_split_f16_pair(const float* x, int64_t ld, int64_t rows, int cols, void* out, int64_t plane, int* overflow,
                                    void* stream) {
     KEDS_REQUIRE(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ld >= cols && ld % 4 == 0 && plane >= rows * cols,
                  "keds_split_f16_pair: bad argument");
     KedsProfScope prof(KEDS_PROF_OTHER, (hipStream_t)stream);
     const long long threads = (long long)rows * (cols / 8);
-    split_f16_pair_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, ld, rows, cols, (f16_t*)out, plane, overflow);
+    split_f16_pair_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, (hipStream_t)stream>>>(x, ld, rows, cols, (f16_t*)out, plane, overflow, 1.0f);
+    return keds_check_launch("split_f16_pair_kernel");
+}
+
+// A weight matrix W [n, k] (dense fp32) as the planes of W * 2^e, e chosen so that max |W| * 2^e lies in [2^13, 2^14): the low
+// plane lo = fp16(w 2^e - hi) of a typical element is then a NORMAL fp16 number and hi + lo carries w to 2^-22 relative down to
+// |w| = 2^-16 max|W|, absolutely to 2^-39 max|W| below that.  (Round 5 split the weights as stored: with |w| ~ 1e-2 .. 1e-3, as in
+// real CLIP checkpoints, lo fell into the fp16 subnormals -- spacing 2^-24 -- and hi + lo carried only 17 .. 14 bits: the advisor's
+// finding on round 5.)  The scale is exact (a power of two) and comes back out in the GEMM's epilogue (keds_gemm_x3, w_exp).
+// Packing-time call: it waits for the stream once (the exponent is needed on the host).
+extern "C" int keds_split_f16_weight(const float* w, int64_t n, int k, void* out, int64_t plane, int* w_exp, void* stream) {
+    KEDS_REQUIRE(w && out && w_exp && n > 0 && k > 0 && k % 8 == 0 && plane >= n * k, "keds_split_f16_weight: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned* dmax = nullptr;
+    if (hipMalloc(&dmax, sizeof(unsigned)) != hipSuccess) {
+        keds_set_error("keds_split_f16_weight: out of device memory");
+        return KEDS_E_LAUNCH;
+    }
+    unsigned hmax = 0;
+    int rc = KEDS_OK;
+    if (hipMemsetAsync(dmax, 0, sizeof(unsigned), st) != hipSuccess) rc = KEDS_E_LAUNCH;
+    if (!rc) {
+        absmax_bits_kernel<<<1024, 256, 0, st>>>(w, (long long)n * k, dmax);
+        rc = keds_check_launch("absmax_bits_kernel");
+    }
+    if (!rc && (hipMemcpyAsync(&hmax, dmax, sizeof(unsigned), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess))
+        rc = KEDS_E_LAUNCH;
+    (void)hipFree(dmax);
+    if (rc) {
+        if (rc == KEDS_E_LAUNCH) keds_set_error("keds_split_f16_weight: device error while reading max |W|");
+        return rc;
+    }
+    KEDS_REQUIRE(hmax < 0x7F800000u, "keds_split_f16_weight: the weight matrix holds a non-finite value");
+    int e = 0;
+    if (hmax) {                                       // floor(log2(max)) from the exponent field (subnormal max: scale by 2^40 at most)
+        const int lg = (int)(hmax >> 23) - 127;
+        e = 13 - lg;
+        if (e > 40) e = 40;
+        if (e < -100) e = -100;
+    }
+    *w_exp = e;
+    const long long threads = (long long)n * (k / 8);
+    split_f16_pair_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, st>>>(w, k, n, k, (f16_t*)out, plane, nullptr, ldexpf(1.0f, e));
     return keds_check_launch("split_f16_pair_kernel");
 }
 

@@ -370,14 +370,14 @@ static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* w
     auto pre = [&](const keds_block_params& k, const Span& sp) -> int {               // ln_1 + in_proj
         int r = keds_layernorm_pair_impl(x + sp.r0 * w, w, k.ln1_g, k.ln1_b, ln2 + sp.r0 * w, pl, sp.n, w, sp.st);
         if (r) return r;
-        return keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.qkv_w, wq, k.qkv_b, qkv + sp.r0 * 3 * w, 3 * w, sp.n, 3 * w, w, KEDS_EPI_X3_BIAS_F32, 0, sp.st);
+        return keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.qkv_w, wq, k.qkv_b, qkv + sp.r0 * 3 * w, 3 * w, sp.n, 3 * w, w, KEDS_EPI_X3_BIAS_F32, 0, k.x3_exp[0], sp.st);
     };
     auto post = [&](const keds_block_params& k, const Span& sp) -> int {              // out-proj + ln_2 + MLP
         int r;
-        if ((r = keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.out_w, wo, k.out_b, x + sp.r0 * w, w, sp.n, w, w, KEDS_EPI_X3_RESID_F32, 0, sp.st))) return r;
+        if ((r = keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.out_w, wo, k.out_b, x + sp.r0 * w, w, sp.n, w, w, KEDS_EPI_X3_RESID_F32, 0, k.x3_exp[1], sp.st))) return r;
         if ((r = keds_layernorm_pair_impl(x + sp.r0 * w, w, k.ln2_g, k.ln2_b, ln2 + sp.r0 * w, pl, sp.n, w, sp.st))) return r;
-        if ((r = keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.fc_w, wf, k.fc_b, hid2 + sp.r0 * 4 * w, 4 * w, sp.n, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)plh, sp.st))) return r;
-        return keds_gemm_x3(hid2 + sp.r0 * 4 * w, plh, 4 * w, k.proj_w, wf, k.proj_b, x + sp.r0 * w, w, sp.n, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, sp.st);
+        if ((r = keds_gemm_x3(ln2 + sp.r0 * w, pl, w, k.fc_w, wf, k.fc_b, hid2 + sp.r0 * 4 * w, 4 * w, sp.n, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)plh, k.x3_exp[2], sp.st))) return r;
+        return keds_gemm_x3(hid2 + sp.r0 * 4 * w, plh, 4 * w, k.proj_w, wf, k.proj_b, x + sp.r0 * w, w, sp.n, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, k.x3_exp[3], sp.st);
     };
     if (lane && (rc = keds_stream_order(st, lane->fork, lane->s))) return rc;
     for (int i = 0; i < nspan; ++i)
@@ -405,10 +405,10 @@ static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* w
             }
             const long long pc = (long long)keds_align_up((size_t)B, 256) * w;
             if ((rc = keds_split_f16_pair(att_c, w, B, w, ln2, pc, guard, st))) return rc;
-            if ((rc = keds_gemm_x3(ln2, pc, w, k.out_w, wo, k.out_b, x_c, w, B, w, w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
+            if ((rc = keds_gemm_x3(ln2, pc, w, k.out_w, wo, k.out_b, x_c, w, B, w, w, KEDS_EPI_X3_RESID_F32, 0, k.x3_exp[1], st))) return rc;
             if ((rc = keds_layernorm_pair_impl(x_c, w, k.ln2_g, k.ln2_b, ln2, pc, B, w, st))) return rc;
-            if ((rc = keds_gemm_x3(ln2, pc, w, k.fc_w, wf, k.fc_b, hid2, 4 * w, B, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)(4 * pc), st))) return rc;
-            if ((rc = keds_gemm_x3(hid2, 4 * pc, 4 * w, k.proj_w, wf, k.proj_b, x_c, w, B, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, st))) return rc;
+            if ((rc = keds_gemm_x3(ln2, pc, w, k.fc_w, wf, k.fc_b, hid2, 4 * w, B, 4 * w, w, KEDS_EPI_X3_QGELU_PAIR, (int)(4 * pc), k.x3_exp[2], st))) return rc;
+            if ((rc = keds_gemm_x3(hid2, 4 * pc, 4 * w, k.proj_w, wf, k.proj_b, x_c, w, B, w, 4 * w, KEDS_EPI_X3_RESID_F32, 0, k.x3_exp[3], st))) return rc;
             // the caller reads row b of a compact x (text tower) or row b * S (ViT: CLS rows in place)
             if (hipMemcpy2DAsync(x, (size_t)(last_rows ? w : S * w) * 4, x_c, (size_t)w * 4, (size_t)w * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess) {
                 keds_set_error("keds_tower_forward_f32: read-out rows: %s", hipGetErrorString(hipGetLastError()));

@@ -14,10 +14,13 @@
 #include <cstdlib>
 #include "gemm_shared.h"
 #include "gemm_quad_gen.h"
-// gemm_duo.hip: the two-accumulator-set kernel (LayerNorm-folded epilogues under the next unit's MFMAs)
+#ifdef KEDS_EXPERIMENTS
+// tools/experiments/gemm_duo.hip (round 5, a measured negative: docs/findings_r05.md section 1): the two-accumulator-set kernel
+// (LayerNorm-folded epilogues under the next unit's MFMAs); only the experiment build links it
 bool keds_gemm_duo_ok(int epi, int M, int N, int K);
 int keds_gemm_duo_launch(int epi, const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                          void* aux2, hipStream_t st);
+#endif
 
 #ifndef KEDS_QUAD_NOEPI
 #define KEDS_QUAD_NOEPI 0
@@ -142,7 +145,7 @@ template <int EPI, int MI, int DBG = 0>   // DBG (stamped diagnostic build only)
 __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* __restrict__ bias, void* __restrict__ out,
                                               int m_lane, int M, int n_lane, int N, int K, const float* __restrict__ aux,
                                               int aux_i, void* __restrict__ aux2, long long ldc, bool zero_lane,
-                                              int* __restrict__ guard = nullptr) {
+                                              int* __restrict__ guard = nullptr, float x3_ws = 1.0f) {
     if constexpr (epi_is_ln(EPI)) {
         const float invk = 1.0f / (float)K;
         float rstd[MI], nmr[MI];
@@ -271,7 +274,10 @@ __device__ __forceinline__ void tile_epilogue(f32x4 (&acc)[4][MI], const float* 
             for (int mi = 0; mi < MI; ++mi) {
                 const int m = m_lane + 16 * mi;
                 if (m >= M) continue;
-                epilogue_store<epi_base(EPI)>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
+                if constexpr (epi_x3(EPI))      // the weight planes hold W * 2^e: the product comes back to scale before the bias (exact)
+                    epilogue_store<epi_base(EPI)>(acc[2 * p][mi] * x3_ws + b0, acc[2 * p + 1][mi] * x3_ws + b1, out, m, n, N, aux, aux_i, ldc);
+                else
+                    epilogue_store<epi_base(EPI)>(acc[2 * p][mi] + b0, acc[2 * p + 1][mi] + b1, out, m, n, N, aux, aux_i, ldc);
             }
         }
     }
@@ -662,7 +668,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bt_kernel(const bf16_t* __restric
     }
     // zero_lane: LN epilogues: the one wave column that clears the other stats buffer; RESID_STATS: the lane that adds
     const bool zl = epi_is_ln(EPI) ? (n0 == 0 && wn == 0 && g == 0) : (g == 0);
-    tile_epilogue<EPI, 4>(acc, bias, out, m0 + 64 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, ldc, zl, guard);
+    tile_epilogue<EPI, 4>(acc, bias, out, m0 + 64 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, ldc, zl, guard,
+                          epi_x3(EPI) ? x3_wscale(w_plane) : 1.0f);
 }
 
 // split-K reduce: add this thread's partial {sum, sum sq} of a row to its statistics.  Lanes that are known to sit in
@@ -773,7 +780,7 @@ int g_no_split = 0;   // test hook
 static bool nosplit_env() {     // KEDS_NO_SPLITK=1 in the environment (A/B): no split-K anywhere
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("KEDS_NO_SPLITK");
+        const char* e = keds_exp_env("KEDS_NO_SPLITK");
         v = e && e[0] == '1';
     }
     return v != 0;
@@ -784,7 +791,7 @@ thread_local int tl_small_lds = 0;
 bool keds_small_lds_scope() {
     static int env = -1;
     if (env < 0) {
-        const char* e = getenv("KEDS_SMALL_NST");
+        const char* e = keds_exp_env("KEDS_SMALL_NST");
         env = e && e[0] == '2';
     }
     return env || tl_small_lds;
@@ -1148,7 +1155,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bt_pair_kernel(const bf16_t* __re
         pair_resid_epilogue(acc, smem + SIDE_OFF, out, m0, n0, N, wm, wn, g, c,
                             reinterpret_cast<keds_stat_t*>(const_cast<float*>(aux)), smem + (np & 1) * PBUF_BYTES);
     else
-        tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl);
+        tile_epilogue<EPI, 8>(acc, bias, out, m0 + 128 * wm + c, M, n0 + 64 * wn + 8 * g, N, K, aux, aux_i, aux2, N, zl, nullptr,
+                              epi_x3(EPI) ? x3_wscale(w_plane) : 1.0f);
 }
 
 // ---- 256 x 256 x 64 tiles on FOUR waves (round 3) ---------------------------------------------------------------------
@@ -1530,7 +1538,8 @@ __global__ __launch_bounds__(256, 1) void gemm_bt_quad_kernel(const bf16_t* __re
     else if constexpr (EPI == KEDS_EPI_RESID_STATS_F16)                                                                \
         pair_resid_epilogue<0, false>(av, side, out, m0, n0, N, wm, 2 * wn2 + h, g, c, stats, red);                    \
     else                                                                                                               \
-        tile_epilogue<EPI, 8>(av, bias, out, m0 + 128 * wm + c, M, n0 + 64 * (2 * wn2 + h) + 8 * g, N, K, aux, aux_i, aux2e, N, g == 0);
+        tile_epilogue<EPI, 8>(av, bias, out, m0 + 128 * wm + c, M, n0 + 64 * (2 * wn2 + h) + 8 * g, N, K, aux, aux_i, aux2e, N, g == 0, nullptr, \
+                              epi_x3(EPI) ? x3_wscale(w_plane) : 1.0f);
         if constexpr (DEFER) {
             // one 32-column quarter at a time: 64 read-back registers live instead of 128 leave room for the deferred stores
 #define KEDS_QUAD_EPQ(h, p)                                                                                             \
@@ -1796,7 +1805,7 @@ int g_skip_tail = 0;      // timing-only: skip the remainder-row launch
 static int quad_defer_env() {     // KEDS_QUAD_DEFER=0 in the environment: no deferred epilogue stores (whole-step A/B)
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("KEDS_QUAD_DEFER");
+        const char* e = keds_exp_env("KEDS_QUAD_DEFER");
         v = !(e && e[0] == '0');
     }
     return v;
@@ -1811,7 +1820,7 @@ int g_quad = -1;
 int quad_env() {
     static int v = -2;
     if (v == -2) {
-        const char* e = getenv("KEDS_GEMM_QUAD");
+        const char* e = keds_exp_env("KEDS_GEMM_QUAD");
         v = e && e[0] ? atoi(e) : -1;
     }
     return v;
@@ -1825,7 +1834,7 @@ int quad_env() {
 static int resid_quad_min_k() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("KEDS_RESID_QUAD_K");
+        const char* e = keds_exp_env("KEDS_RESID_QUAD_K");
         v = e && e[0] ? atoi(e) : 1024;       // round 4: out-proj too (+0.35 % on the headline in four same-box pairs: its A operand,
                                               // the attention output, is cold in the step and the three-deep ring tolerates that)
     }
@@ -1835,7 +1844,7 @@ static int resid_quad_min_k() {
 static bool x3_quad_env() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("KEDS_X3_QUAD");
+        const char* e = keds_exp_env("KEDS_X3_QUAD");
         v = !(e && e[0] == '0');
     }
     return v != 0;
@@ -1859,11 +1868,13 @@ int g_pair_stamp = 0;     // diagnostic: stamped build of the qkv instantiation 
 template <int EPI>
 int launch_big(const void* A, const void* W, const float* bias, void* out, int M, int N, int K, const float* aux,
                int aux_i, void* aux2, hipStream_t st) {
+#ifdef KEDS_EXPERIMENTS
     if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_LN_QGELU_BF16_H) {
         // (a forced kernel form -- keds_gemm_force_small bits 11-15, KEDS_GEMM_QUAD -- keeps the round-4 kernels: A/B tools)
         if (g_quad < 0 && quad_env() < 0 && !g_pair_stamp && keds_gemm_duo_ok(EPI, M, N, K))
             return keds_gemm_duo_launch(EPI, A, W, bias, out, M, N, K, aux, aux2, st);
     }
+#endif
     if (int rc = keds_func_lds_once((const void*)gemm_bt_pair_kernel<EPI>, pr::LDS_BYTES, "gemm_bt_pair_kernel")) return rc;
     if constexpr (EPI == KEDS_EPI_LN_BIAS_BF16_H || EPI == KEDS_EPI_RESID_STATS_F16) {
         if (g_pair_stamp && g_quad > 0) {                            // stamped build of the 4-wave kernel
@@ -1956,7 +1967,7 @@ int g_force_small = 0;   // test hook: route everything through the 128^2 kernel
 static int big_tiles_pct() {          // KEDS_BIG_TILES_PCT in the environment (A/B): the fill a 256^2 launch needs, default 85
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("KEDS_BIG_TILES_PCT");
+        const char* e = keds_exp_env("KEDS_BIG_TILES_PCT");
         v = e && e[0] ? atoi(e) : 85;
     }
     return v;
@@ -2079,7 +2090,7 @@ extern "C" int keds_gemm_bt_ex2(const void* A, int64_t lda, const void* W, const
 }
 
 extern "C" int keds_gemm_x3(const void* a, int64_t a_plane, int64_t lda, const void* w, int64_t w_plane, const float* bias, void* out,
-                            int64_t ldc, int M, int N, int K, int epilogue, int aux_i, void* stream) {
+                            int64_t ldc, int M, int N, int K, int epilogue, int aux_i, int w_exp, void* stream) {
     KEDS_REQUIRE(a && w && out && M > 0 && N > 0 && K > 0, "keds_gemm_x3: bad argument");
     KEDS_REQUIRE(N % BN == 0 && K % BK == 0 && lda >= K && ldc >= N && lda % 8 == 0 && ldc % 8 == 0, "keds_gemm_x3: bad shape / strides");
     // buffer offsets are 32-bit: a plane must be reachable from a tile's first row
@@ -2087,7 +2098,8 @@ extern "C" int keds_gemm_x3(const void* a, int64_t a_plane, int64_t lda, const v
                  "keds_gemm_x3: plane strides out of range");
     hipStream_t st = (hipStream_t)stream;
     g_x3_aplane = a_plane;
-    g_x3_wplane = w_plane;
+    KEDS_REQUIRE(w_exp >= -100 && w_exp <= 100, "keds_gemm_x3: w_exp %d out of range", w_exp);
+    g_x3_wplane = x3_pack_wplane(w_plane, w_exp);
     switch (epilogue) {
         case KEDS_EPI_X3_BIAS_F32:
             return launch_gemm<KEDS_EPI_X3_BIAS_F32>(a, w, bias, out, M, N, K, nullptr, 0, nullptr, lda, ldc, st);

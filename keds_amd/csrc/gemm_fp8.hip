@@ -984,7 +984,7 @@ int launch_mxfp8(const void* Aq, const void* As, int m_pad, const void* Wq, cons
 bool fp8_quad_enabled() {
     static int on = -1;
     if (on < 0) {
-        const char* e = getenv("KEDS_FP8_QUAD");
+        const char* e = keds_exp_env("KEDS_FP8_QUAD");
         on = !(e && e[0] == '0');
     }
     return on != 0;

@@ -41,6 +41,15 @@ __device__ __forceinline__ X3Seg x3_seg(int p, int np1) {
     return X3Seg{(unsigned)(p - seg * np1) * 128u, seg == 2, seg == 1};
 }
 
+// KEDS_EPI_X3_*: the W planes hold W * 2^e (keds_split_f16_weight), the epilogue multiplies the accumulators by 2^-e before the
+// bias.  Inside the library e travels in bits 40-47 of the kernels' `w_plane` argument (the plane stride itself is < 2^30 and every
+// use of it truncates to 32 bits), so that no kernel signature and no launch site changes.
+inline long long x3_pack_wplane(long long w_plane, int w_exp) { return w_plane | ((long long)(w_exp & 0xFF) << 40); }
+__device__ __forceinline__ float x3_wscale(long long w_plane) {
+    const int e = (int)(signed char)((w_plane >> 40) & 0xFF);
+    return __uint_as_float((unsigned)(127 - e) << 23);             // 2^-e, |e| <= 100
+}
+
 constexpr float LN_EPS = 1e-5f;
 
 // Numerics guard of the folded-LayerNorm flow (keds_hip.h, keds_numerics_guard): the GEMM multiplies UN-centred rows, so

@@ -19,6 +19,18 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define KEDS_WAVE 64
 
+// ---- switches of the EXPERIMENT build (host) -------------------------------------------------
+// The product library reads four environment variables, all documented in INTEGRATION.md: KEDS_DETERMINISTIC, KEDS_SIDE_STREAM,
+// KEDS_TEXT_TRIM (and, in Python, KEDS_PRECISION / the tokenizer's KEDS_BPE_VOCAB).  Every other KEDS_* switch selects a kernel form
+// or a schedule that lost a measured A/B; they exist only in a library built with `make EXTRA=-DKEDS_EXPERIMENTS` (what the A/B
+// tools under tools/ build), so that the product has one dispatch path per shape.
+#include <cstdlib>
+#ifdef KEDS_EXPERIMENTS
+inline const char* keds_exp_env(const char* name) { return getenv(name); }
+#else
+inline const char* keds_exp_env(const char*) { return nullptr; }
+#endif
+
 // ---- error plumbing (host) ---------------------------------------------------------
 void keds_set_error(const char* fmt, ...);
 int keds_check_launch(const char* what);

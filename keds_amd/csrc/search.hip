@@ -1187,14 +1187,16 @@ int g_tail_fused = 0; // keds_scan_debug bit 10: merge + re-rank + certificate i
 // (Measured, round 4, same box, tools/search_profile.py: fused 234-242 us per search, three launches 237 -- one block per
 // query re-ranks its 64 candidates on four waves where rerank_kernel spreads 8,192 waves over the chip; the two kernel
 // boundaries it saves cost less than that.  OFF by default; KEDS_SEARCH_FUSED=1 / keds_scan_debug bit 10 select it.)
+#ifdef KEDS_EXPERIMENTS
 bool search_tail_fused() {
     static int env = -1;
     if (env < 0) {
-        const char* e = getenv("KEDS_SEARCH_FUSED");
+        const char* e = keds_exp_env("KEDS_SEARCH_FUSED");
         env = e && e[0] == '1';
     }
     return env || g_tail_fused;
 }
+#endif
 
 template <int D, int L>
 int launch_scan(const void* packed, int stage_begin, int total_stages, const bf16_t* qb, const float* thr,
@@ -1361,7 +1363,7 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
     // rows).  KEDS_SCAN_SAMPLE_DIV=<d> forces 1/d (A/B).
     static int sample_div = -1;
     if (sample_div < 0) {
-        const char* e = getenv("KEDS_SCAN_SAMPLE_DIV");
+        const char* e = keds_exp_env("KEDS_SCAN_SAMPLE_DIV");
         sample_div = e && atoi(e) >= 2 ? atoi(e) : 0;
     }
     int stagesA = total_stages / 16;
@@ -1433,13 +1435,16 @@ extern "C" int keds_index_search_packed_ex(const void* packed, const float* db, 
             KedsProfScope prof(KEDS_PROF_OTHER, st);
             float* Dq = D + (size_t)q0 * k;
             long long* Iq = (long long*)I + (size_t)q0 * k;
+#ifdef KEDS_EXPERIMENTS
             if (search_tail_fused()) {       // merge + exact re-rank + selection + certificate: one launch
                 const TailArgs ta{db, qn, w.qstat, bounds, Dq, Iq, w.counters, w.fail_ids, w.fslot, w.dk, status, (long long)id_base,
                                   dim, metric, k, g_force_exact};
                 merge_pairs_kernel<true><<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgB, 4 * LISTK, w.cidx, w.cval, nullptr, ncand,
                                                                        two_phase ? w.thr : nullptr, w.sbound, ta);
                 if ((rc = keds_check_launch("merge_pairs_kernel<fused>"))) return rc;
-            } else {
+            } else
+#endif
+            {
                 merge_pairs_kernel<false><<<nb, MERGE_THREADS, 0, st>>>(w.lpairs, w.lmeta, nwgB, 4 * LISTK, w.cidx, w.cval, nullptr, ncand,
                                                                         two_phase ? w.thr : nullptr, w.sbound, TailArgs{});
                 if ((rc = keds_check_launch("merge_pairs_kernel"))) return rc;

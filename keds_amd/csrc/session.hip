@@ -208,7 +208,7 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
                 for (int j = 0; j < 4; ++j) {
                     void* planes = L.mem.alloc((size_t)2 * n[j] * k[j] * 2);
                     KEDS_REQUIRE(planes, "%s: out of device memory", L.what);
-                    if ((rc = keds_split_f16_pair((const float*)*slots[j], k[j], n[j], k[j], planes, (int64_t)n[j] * k[j], nullptr, nullptr)))
+                    if ((rc = keds_split_f16_weight((const float*)*slots[j], n[j], k[j], planes, (int64_t)n[j] * k[j], &p.x3_exp[j], nullptr)))
                         return rc;
                     *slots[j] = planes;
                 }

@@ -102,7 +102,7 @@ struct RowLanes {
     template <typename F>
     int attention_then_side(F launch) {
         static const bool ext = [] {
-            const char* e = getenv("KEDS_FORK_EXT");
+            const char* e = keds_exp_env("KEDS_FORK_EXT");
             return !(e && e[0] == '0');
         }();
         if (!split || !ext) {
@@ -192,14 +192,18 @@ int rows_tail(const keds_tower_params* p, const keds_block_params& k, const Towe
 
 // KEDS_TAIL_ATTN=1 in the environment: the tail samples' attention on the side lane (round-4 experiment, OFF by default:
 // bit-identical and neutral -- 6,759-6,770 vs 6,770-6,776 img/s in four same-box pairs, profiles/r04_tail_attention_ab.txt)
+#ifdef KEDS_EXPERIMENTS
 bool tail_attention_on_side() {
     static int v = -1;
     if (v < 0) {
-        const char* e = getenv("KEDS_TAIL_ATTN");
+        const char* e = keds_exp_env("KEDS_TAIL_ATTN");
         v = e && e[0] == '1';
     }
     return v != 0;
 }
+#else
+constexpr bool tail_attention_on_side() { return false; }
+#endif
 
 bool bf16_rows_split(int M, int w) {
     return keds_gemm_splits_rows(M, 3 * w, w) && keds_gemm_splits_rows(M, w, w) && keds_gemm_splits_rows(M, 4 * w, w) &&
@@ -214,15 +218,19 @@ bool bf16_rows_split(int M, int w) {
 // 4 ms per step SLOWER (23.9 vs 19.85 ms, same-box A/B): 129 row tiles x 4..16 column tiles is no longer a whole number of
 // 256-workgroup rounds, and every one of the 94 GEMM launches of a step pays a nearly empty extra round (12..16 tiles on 256
 // CUs) that the side lane's small launches used to fill.  KEDS_TOWER_FILL=1 / keds_tower_fill_enable(1) turn it on.
+#ifdef KEDS_EXPERIMENTS
 int g_tower_fill = -1;                          // -1: take KEDS_TOWER_FILL (default off)
 int tower_fill_rows(int M, int w) {
     if (g_tower_fill < 0) {
-        const char* e = getenv("KEDS_TOWER_FILL");
+        const char* e = keds_exp_env("KEDS_TOWER_FILL");
         g_tower_fill = e && e[0] == '1';
     }
     const int fill = (256 - M % 256) % 256;
     return g_tower_fill && fill && bf16_rows_split(M, w) && (long)fill * 64 <= M ? fill : 0;
 }
+#else
+constexpr int tower_fill_rows(int, int) { return 0; }      // (the product library: remainder rows always take the side lane)
+#endif
 
 // BASELINE config 5: the four GEMMs of every block on MXFP8 operands (gemm_fp8.hip).  The residual stream stays fp32;
 // its MXFP8 copy (xq, xs), the attention output (aq) and the MLP hidden (hq) are e4m3 + one e8m0 scale per 32 columns,
@@ -403,9 +411,15 @@ extern "C" size_t keds_tower_workspace_bytes(int width, int seq, int B) {
     return carve_tower(nullptr, width, seq, B).bytes;
 }
 
-extern "C" int keds_tower_fill_enable(int on) {       // run-time override of KEDS_TOWER_FILL (A/B, tests)
+extern "C" int keds_tower_fill_enable(int on) {       // run-time override of KEDS_TOWER_FILL (A/B, tests): experiment build only
+#ifdef KEDS_EXPERIMENTS
     g_tower_fill = on ? 1 : 0;
     return KEDS_OK;
+#else
+    if (!on) return KEDS_OK;
+    keds_set_error("keds_tower_fill_enable: the filler-row tower is an experiment (round 3, slower): build with make EXTRA=-DKEDS_EXPERIMENTS");
+    return KEDS_E_ARG;
+#endif
 }
 
 extern "C" int keds_tower_side_rows(int width, int seq, int B, int fp8) {

@@ -85,16 +85,22 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
                 fp8: bool = False, folded: bool = True, f32: bool = False) -> _lib.TowerParams:
     blocks = (_lib.BlockParams * tr.layers)()
     # f32 = 1: the fp32-accurate flow (csrc/f32path.hip) multiplies the weights as stored; f32 = 2 ("fp32x3"): the four block
-    # weights as PAIRS of fp16 planes [2, N, K] (w = hi + lo to 22 bits; keds_split_f16_pair) for the split-operand GEMMs
+    # weights as PAIRS of fp16 planes [2, N, K] of w 2^e (hi + lo to 22 bits; keds_split_f16_weight picks the exact per-matrix
+    # power of two that keeps the low plane of small weights out of the fp16 subnormals) for the split-operand GEMMs
+    x3_exps = []
+
     def _planes(w):
         w32 = _f32(w)
         n, k = w32.shape
         out = torch.empty((2, n, k), dtype=torch.float16, device=w32.device)
-        check(load().keds_split_f16_pair(ptr(w32), k, n, k, ptr(out), n * k, None, stream()), "keds_split_f16_pair")
+        e = C.c_int32(0)
+        check(load().keds_split_f16_weight(ptr(w32), n, k, ptr(out), n * k, C.byref(e), stream()), "keds_split_f16_weight")
+        x3_exps.append(int(e.value))
         return out
     wcast = _planes if f32 == 2 else _f32 if f32 else _bf16
     folded = folded and not f32
     for i, blk in enumerate(tr.resblocks):
+        del x3_exps[:]                                          # (filled in the order qkv, out, fc, proj below)
         t = dict(
             ln1_g=_f32(blk.ln_1.weight), ln1_b=_f32(blk.ln_1.bias), ln2_g=_f32(blk.ln_2.weight), ln2_b=_f32(blk.ln_2.bias),
             qkv_w=wcast(blk.attn.in_proj_weight), out_w=wcast(blk.attn.out_proj.weight),
@@ -137,6 +143,8 @@ def _pack_tower(tr: Transformer, seq: int, causal: bool, keep: list, cls_only: b
         torch.cuda.current_stream().synchronize()          # the fp32 temporaries die here
         for k, v in t.items():
             setattr(blocks[i], k, ptr(v))
+        if f32 == 2:
+            blocks[i].x3_exp = (C.c_int32 * 4)(*x3_exps)
         keep.append(t)
     keep.append(blocks)
     return _lib.TowerParams(tr.width, tr.layers, tr.heads, seq, 1 if causal else 0, blocks, 1 if fp8 else 0,
@@ -219,7 +227,7 @@ class CLIP(nn.Module):
         # a row with |mean|/std > 32 or non-finite statistics re-runs the pass on the fp32-stream flow with stand-alone
         # LayerNorm and keeps the model there (keds_hip.h, keds_numerics_guard_set); "fast": no guard; "safe": always the
         # fp32-stream flow (what KEDS_DETERMINISTIC=1 selected before).
-        self.numerics = "safe" if os.environ.get("KEDS_DETERMINISTIC", "0") == "1" else os.environ.get("KEDS_NUMERICS", "auto")
+        self.numerics = "safe" if os.environ.get("KEDS_DETERMINISTIC", "0") == "1" else "auto"      # (set_numerics() changes it)
         self.numerics_tripped = False
         self._guard: Optional[torch.Tensor] = None
         # "auto" reads the guard flag back EAGERLY (one host-device sync per pass, the pass is re-run on the safe flow when it
@@ -676,7 +684,7 @@ class CrossFormer(nn.Module):
             # launch-saving re-arrangement (keds_hip.h, keds_crossformer_fused): one k/v GEMM for all layers, and every
             # later layer's query projection folded with the previous output projection
             lib = load()
-            if self._num_layers <= 8 and os.environ.get("KEDS_KNOWLEDGE_UNFUSED", "0") != "1":
+            if self._num_layers <= 8:
                 dev = self.cross_layers[0].to_q.weight.device
                 buf = torch.empty(int(lib.keds_crossformer_fused_bytes(C.byref(p))), dtype=torch.uint8, device=dev)
                 fused = _lib.CrossFormerFused()

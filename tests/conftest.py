@@ -13,6 +13,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 EXCHANGE2 = None        # the two-process device-exchange job of tests/test_gpu_exchange2.py: {"procs": [...], "dir": path}
 
 
+def _keyword_selects(kexpr, names):
+    """Would `-k kexpr` keep a test whose keywords are `names`?  pytest's own expression grammar (substring match per identifier,
+    not / and / or); when it cannot be evaluated here the answer is yes: starting the job for nothing costs two idle processes,
+    not starting it lets a selected test skip silently."""
+    try:
+        from _pytest.mark.expression import Expression
+        return bool(Expression.compile(kexpr).evaluate(lambda ident, **kw: any(ident.lower() in n.lower() for n in names)))
+    except Exception:                                            # noqa: BLE001
+        return True
+
+
 def _start_exchange2(config):
     """Start the two ranks of tests/test_gpu_exchange2.py NOW: pytest_configure runs before any test module is imported, so
     this process has made no GPU call yet (torch.cuda.device_count() does not initialise the device on this image) -- a
@@ -26,8 +37,9 @@ def _start_exchange2(config):
     if any(a.endswith(".py") or "::" in a for a in args) and not any("test_gpu_exchange2" in a for a in args):
         return                                                   # a run of other test files only
     kexpr = getattr(config.option, "keyword", "") or ""
-    if kexpr and "exchange" not in kexpr:
-        return                                                   # -k selects by name and does not name this test
+    if kexpr and not _keyword_selects(kexpr, ("test_device_exchange_between_two_processes_equals_single_index", "test_gpu_exchange2.py",
+                                              "test_gpu_exchange2", "tests", "gpu")):
+        return                                                   # -k deselects this test (e.g. -k fp8); -k "not fullsize" keeps it
     try:
         import torch
         if torch.cuda.device_count() < 1:

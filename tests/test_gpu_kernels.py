@@ -549,10 +549,8 @@ def test_gemm_quad_kernel_bit_identical_to_the_eight_wave_kernel(M, K):
     one ragged -- fewer tiles than 85 % of whole rounds go to the 128 x 128 kernel and would not test it)
     must as well -- including the LayerNorm epilogue's deferred stores (K >= 512: 18 of a lane's 32 stores of a tile are issued
     from inside the next tile's K-loop; K = 256 is too short for the trickle and stores everything in the epilogue).
-    Round 5: what the dispatcher picks (`default`) is, for the LayerNorm-folded epilogues at K >= 1024, the two-accumulator-set
-    kernel (gemm_duo.hip: 128 x 256 units, the previous unit's epilogue in the gaps between this unit's MFMAs; K = 2048 also
-    runs its plain K-tile loop behind the 16 K-tiles that carry the sub-slices): the same chains, the same bits, and the other
-    statistics buffer cleared for exactly the rows of the launch."""
+    What the dispatcher picks by shape (`default`) must give the same bits too, with the other statistics buffer cleared for
+    exactly the rows of the launch.  (The two-accumulator-set kernel of round 5 is not in the product library: tools/experiments/.)"""
     lib = _lib.load()
     N = 4096                                                     # >= 256 tiles of 256 x 256: the big-tile path
     g = torch.Generator(device="cuda").manual_seed(K)

@@ -180,8 +180,10 @@ def test_fused_search_tail_equals_the_three_launch_tail(metric, dim, k):
     run selection + certificate in the same launch (merge_pairs_kernel<true>, keds_scan_debug bit 10).  Same arithmetic as
     merge -> rerank_kernel -> certify_select_kernel:
     distances, ids and the certificate verdicts must be identical -- on iid data, on clustered data with ties at the cut, and
-    with fewer valid candidates than k."""
+    with fewer valid candidates than k.  (Experiment build only: `make EXTRA=-DKEDS_EXPERIMENTS`.)"""
     lib = _lib.load()
+    if "KEDS_EXPERIMENTS" not in _lib.build_flags():
+        pytest.skip("the fused search tail lost its A/B and is not in the product library (experiment build only)")
     n = 70000
     db = O.synth_database(n, dim, seed=51, clustered=True, n_centroids=32)
     db[100:140] = db[100]                                        # 40 identical rows: ties in the scan score and the distance

@@ -185,17 +185,20 @@ def main():
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
     n, errors = 0, []
     with tempfile.TemporaryDirectory() as td:
-        out = (keep + ".gemm_duo" if keep else os.path.join(td, "gemm_duo.s"))
-        res = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--offload-device-only", "-S",
-                              os.path.join(ROOT, "keds_amd", "csrc", "gemm_duo.hip"), "-o", out], capture_output=True, text=True)
-        if res.returncode != 0:
-            print(res.stderr[-3000:])
-            return 2
-        k, e = check_duo(open(out).read())
-        if k == 0:
-            e.append("gemm_duo.hip: no two-accumulator-set kernel found")
-        n += k
-        errors += e
+        # the two-accumulator-set kernel lives with the experiments (tools/experiments/, linked by `make EXTRA=-DKEDS_EXPERIMENTS` only)
+        duo_src = os.path.join(ROOT, "tools", "experiments", "gemm_duo.hip")
+        if "--experiments" in sys.argv and os.path.exists(duo_src):
+            out = (keep + ".gemm_duo" if keep else os.path.join(td, "gemm_duo.s"))
+            res = subprocess.run([HIPCC, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "--offload-device-only", "-S",
+                                  "-I", os.path.join(ROOT, "keds_amd", "csrc"), duo_src, "-o", out], capture_output=True, text=True)
+            if res.returncode != 0:
+                print(res.stderr[-3000:])
+                return 2
+            k, e = check_duo(open(out).read())
+            if k == 0:
+                e.append("gemm_duo.hip: no two-accumulator-set kernel found")
+            n += k
+            errors += e
         for fname in ("gemm", "gemm_fp8"):
             out = (keep + "." + fname if keep else os.path.join(td, fname + ".s"))
             src = os.path.join(ROOT, "keds_amd", "csrc", fname + ".hip")
