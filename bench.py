@@ -614,6 +614,9 @@ def main():
     _lib.load()                                                # fail loudly if the HIP library is missing
 
     dual = args.workload == "dual"
+    if os.environ.get("KEDS_BENCH_TEXT_RECT") == "1":           # A/B only: the text tower on the rectangular [B, max len] layout
+        import keds_amd.model as _km
+        _km.TEXT_PACKED = False
     B, N, D = args.batch, args.db_rows, 768
     k = 16 if dual else args.k                                 # the knowledge path takes the 16 nearest rows of each database
     model = _DryModel(B, rank) if dry else random_clip(dev)

@@ -30,7 +30,7 @@ extern "C" {
 #define KEDS_E_LAUNCH (-2)   /* HIP launch or runtime error */
 #define KEDS_E_WORKSPACE (-3)/* workspace too small */
 
-#define KEDS_ABI_VERSION 8        /* 8 (round 6): keds_gemm_x3 takes w_exp, keds_split_f16_weight, keds_block_params.x3_exp; keds_gemm_duo_enable left the product */
+#define KEDS_ABI_VERSION 8        /* 8 (round 6): keds_gemm_x3 takes w_exp, keds_split_f16_weight, keds_block_params.x3_exp, keds_text_run_packed / keds_attention_packed; keds_gemm_duo_enable left the product */
 
 int keds_abi_version(void);
 /* compiler flags of this build beyond the Makefile's defaults ("" for the product build; `make EXTRA="-D..."` variants of the
@@ -310,6 +310,9 @@ int keds_attention_ex(const void* qkv, void* out, int B, int S, int heads, int c
  * INSTEAD of bf16; the remaining rows go to `out` as usual */
 int keds_attention_mx(const void* qkv, void* out, int B, int S, int heads, int causal, int q_limit, void* q8, void* s8,
                       int q8_rows, void* stream);
+/* PACKED rows (round 6): sample b is rows [seq_off[b], seq_off[b + 1]) of qkv / out (device int32 [B + 1]; lengths 1 .. s_max
+ * <= 288) instead of [b S, (b + 1) S): sequences of different lengths without padding rows (the text tower, keds_text_run_packed) */
+int keds_attention_packed(const void* qkv, void* out, int B, int s_max, const int32_t* seq_off, int heads, int causal, void* stream);
 
 /* patch im2col for conv1 (model.py:381,394-396): image fp32 [B,3,R,R] -> bf16 [B*G, Kpad],
  * column c*P*P + ky*P + kx, zero padded to Kpad (a multiple of 64). */
@@ -449,6 +452,17 @@ int keds_text_run_ex(const keds_text_params* p, const int32_t* tokens, const int
                      const float* img_tokens, int n_tok, int insert_col, int B, int seq_used, float* out, int normalize,
                      void* workspace, size_t workspace_bytes, void* stream);
 int keds_text_trim_enable(int on);
+int keds_text_trim_mode(void);      /* the flow in force (0 .. 3 as above) */
+/* The text tower on PACKED rows (round 6, ABI 8): captions end at different columns, and under the causal mask sample b needs its
+ * columns [0, len_b) only (len_b = its read-out column + 1) -- keds_text_run_ex cuts every sample at the LONGEST caption of the
+ * batch, here sample b owns rows [seq_off[b], seq_off[b + 1]) of every activation buffer and the tower runs sum(len_b) rows.
+ *   seq_off         device int32 [B + 1], seq_off[0] = 0, seq_off[B] = rows_total, 1 <= len_b <= seq_max <= tower.seq
+ *   readout_global  device int32 [B]: seq_off[b] + the read-out column of sample b (a row outside [0, rows_total) gives NaN)
+ * Same arithmetic per row as keds_text_run_ex's default flow (rows only land in other tiles); causal bf16 towers only -- fp8 /
+ * fp32 towers and the A/B flows of keds_text_trim_enable go through keds_text_run_ex.  Workspace: keds_text_workspace_bytes. */
+int keds_text_run_packed(const keds_text_params* p, const int32_t* tokens, const int32_t* seq_off, const int32_t* readout_global,
+                         int rows_total, int seq_max, const float* img_tokens, int n_tok, int insert_col, int B, float* out,
+                         int normalize, void* workspace, size_t workspace_bytes, void* stream);
 
 /* =====================================================================================
  * 4. Knowledge injection (IM2TEXT + 2 x CrossFormer, model.py:37-123, eval_utils.py:661-672)

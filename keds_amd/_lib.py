@@ -215,6 +215,9 @@ SIGNATURES = {
     "keds_text_run": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
     "keds_text_run_ex": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, i32, i32, vp, i32, vp, sz, vp]),
     "keds_text_trim_enable": (i32, [i32]),
+    "keds_text_trim_mode": (i32, []),
+    "keds_text_run_packed": (i32, [C.POINTER(TextParams), vp, vp, vp, i32, i32, vp, i32, i32, i32, vp, i32, vp, sz, vp]),
+    "keds_attention_packed": (i32, [vp, vp, i32, i32, vp, i32, i32, vp]),
     "keds_im2text_workspace_bytes": (sz, [C.POINTER(Im2TextParams), i32]),
     "keds_im2text_forward": (i32, [C.POINTER(Im2TextParams), vp, i32, vp, vp, sz, vp]),
     "keds_crossformer_workspace_bytes": (sz, [C.POINTER(CrossFormerParams), i32, i32]),

@@ -230,7 +230,8 @@ __device__ __forceinline__ void attn_tiles(const AttnCtx& cx, int qt0) {
 template <int NKT, bool CAUSAL, int NFULL, int DBG = 0, bool NQ2 = (NKT == 18 && !CAUSAL)>
 __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int S,
                                                         int heads, int q_limit, unsigned char* __restrict__ q8,
-                                                        unsigned char* __restrict__ s8, int q8_rows) {
+                                                        unsigned char* __restrict__ s8, int q8_rows,
+                                                        const int* __restrict__ seq_off) {
     using C = AttnCfg<NKT>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* k_lds = smem;
@@ -240,7 +241,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     const int ld = 3 * d;  // qkv row stride (elements)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, c = lane & 15;
-    const bf16_t* base = qkv + (size_t)b * S * ld + h * DH;
+    // PACKED rows (keds_attention_packed: the text tower's captions end at different columns): sample b owns rows
+    // [seq_off[b], seq_off[b + 1]) of qkv / out; S was the launch's upper bound and becomes the sample's own length
+    int row0 = b * S;
+    if (seq_off) {
+        row0 = seq_off[b];
+        S = seq_off[b + 1] - row0;
+        q_limit = q_limit < S ? q_limit : S;
+    }
+    const bf16_t* base = qkv + (size_t)row0 * ld + h * DH;
 
     // ---- stage K (swizzled rows) and V^T (permuted key order); keys >= S are zero.
     // Work item = (4 consecutive keys, one 8-wide dh chunk): all global loads of a thread are issued before the
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const bf16_t* __restr
     // ---- queries: NQ = 2 tiles (32 queries) per step share every K / V^T fragment read from LDS (the loop is
     // LDS-bandwidth bound: 72 ds_read_b128 per 16-query tile); an odd last tile runs alone on a rotating wave.
     const int nqt = DBG == 5 ? 0 : (q_limit + 15) >> 4;      // only the first q_limit query rows are computed and stored
-    AttnCtx cx{base, out + (size_t)b * S * d + h * DH, k_lds, vt_lds, S, q_limit, ld, d, g, c, q8, s8, q8_rows, b * S, h * DH};
+    AttnCtx cx{base, out + (size_t)row0 * d + h * DH, k_lds, vt_lds, S, q_limit, ld, d, g, c, q8, s8, q8_rows, row0, h * DH};
     if constexpr (NQ2) {
         const int npair = nqt >> 1;
         for (int qp = wave; qp < npair; qp += 4) attn_tiles<NKT, CAUSAL, NFULL, DBG, 2>(cx, 2 * qp);
@@ -1018,7 +1027,7 @@ int launch_attn_s257(const void* qkv, void* out, int B, int heads, int q_limit, 
 
 template <int NKT, bool CAUSAL, int NFULL>
 int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit, void* q8, void* s8, int q8_rows,
-                hipStream_t st) {
+                hipStream_t st, const int* seq_off = nullptr) {
     using C = AttnCfg<NKT>;
     if (int rc = keds_func_lds_once((const void*)attention_kernel<NKT, CAUSAL, NFULL>, C::LDS, "attention_kernel")) return rc;
     KedsProfScope prof(KEDS_PROF_ATTN, st);
@@ -1028,7 +1037,7 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit
     {                                                                                                            \
         (void)hipFuncSetAttribute((const void*)attention_kernel<NKT, CAUSAL, NFULL, V>,                          \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);                           \
-        attention_kernel<NKT, CAUSAL, NFULL, V><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit, (unsigned char*)q8, (unsigned char*)s8, q8_rows); \
+        attention_kernel<NKT, CAUSAL, NFULL, V><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit, (unsigned char*)q8, (unsigned char*)s8, q8_rows, seq_off); \
     }
             switch (g_attn_debug) {
                 case 1: KEDS_ATTN_DBG(1) break;
@@ -1042,7 +1051,7 @@ int launch_attn(const void* qkv, void* out, int B, int S, int heads, int q_limit
         }
     }
     attention_kernel<NKT, CAUSAL, NFULL><<<B * heads, 256, C::LDS, st>>>((const bf16_t*)qkv, (bf16_t*)out, S, heads, q_limit,
-                                                                         (unsigned char*)q8, (unsigned char*)s8, q8_rows);
+                                                                         (unsigned char*)q8, (unsigned char*)s8, q8_rows, seq_off);
     return keds_check_launch("attention_kernel");
 }
 
@@ -1096,6 +1105,24 @@ extern "C" int keds_attention_mx(const void* qkv, void* out, int B, int S, int h
     if (S == 257 && !q8 && g_attn_tail && !g_attn_debug) return launch_attn_tail1(qkv, out, B, heads, q_limit, st);
     if (S >= 256) return launch_attn<18, false, 16>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);   // ViT-L/14: 257 tokens
     return launch_attn<18, false, 0>(qkv, out, B, S, heads, q_limit, q8, s8, q8_rows, st);
+}
+
+// Packed rows: sample b is rows [seq_off[b], seq_off[b + 1]) of qkv / out (device int32 [B + 1], lengths 1 .. s_max).  The text
+// tower's captions end at different columns and the mask is causal: rows behind a caption's read-out column reach nothing that is
+// read (model.py:543-549), so the tower computes none of them (keds_text_run_packed).
+extern "C" int keds_attention_packed(const void* qkv, void* out, int B, int s_max, const int32_t* seq_off, int heads, int causal,
+                                     void* stream) {
+    KEDS_REQUIRE(qkv && out && seq_off && B > 0 && heads > 0, "keds_attention_packed: bad argument");
+    KEDS_REQUIRE(s_max >= 1 && s_max <= 288, "keds_attention_packed: s_max=%d unsupported (1..288)", s_max);
+    hipStream_t st = (hipStream_t)stream;
+    if (causal) {
+        if (s_max <= 32) return launch_attn<2, true, 0>(qkv, out, B, s_max, heads, s_max, nullptr, nullptr, 0, st, seq_off);
+        if (s_max <= 96) return launch_attn<6, true, 0>(qkv, out, B, s_max, heads, s_max, nullptr, nullptr, 0, st, seq_off);
+        return launch_attn<18, true, 0>(qkv, out, B, s_max, heads, s_max, nullptr, nullptr, 0, st, seq_off);
+    }
+    if (s_max <= 32) return launch_attn<2, false, 0>(qkv, out, B, s_max, heads, s_max, nullptr, nullptr, 0, st, seq_off);
+    if (s_max <= 96) return launch_attn<6, false, 0>(qkv, out, B, s_max, heads, s_max, nullptr, nullptr, 0, st, seq_off);
+    return launch_attn<18, false, 0>(qkv, out, B, s_max, heads, s_max, nullptr, nullptr, 0, st, seq_off);
 }
 
 extern "C" int keds_attention(const void* qkv, void* out, int B, int S, int heads, int causal, void* stream) {

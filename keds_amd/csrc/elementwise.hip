@@ -163,8 +163,9 @@ __global__ __launch_bounds__(256) void cast_rows_f16_f32_kernel(const f16_t* __r
 // (the read-out rows of the text tower, model.py:587-589, 847-849: the last block runs on them only).
 // MODE 0: 16-bit elements copied; 1: fp16 -> fp32; 2: fp32 copied.  One thread per 8 elements.
 template <int MODE>
+// GLOBAL (packed rows): row[b] is the row's index in src itself and S the number of rows src holds
 __global__ __launch_bounds__(256) void gather_rows_kernel(const void* __restrict__ src, void* __restrict__ dst,
-                                                          const int* __restrict__ row, int S, int B, int dim) {
+                                                          const int* __restrict__ row, int S, int B, int dim, int global_rows) {
     const int per_row = dim >> 3;
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= B * per_row) return;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const void* __restrict
         }
         return;
     }
-    const size_t so = ((size_t)b * S + row[b]) * dim + i;
+    const size_t so = ((global_rows ? (size_t)0 : (size_t)b * S) + row[b]) * dim + i;
     if constexpr (MODE == 0) {
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(dst) + d_o) =
             *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(src) + so);
@@ -367,10 +368,18 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict
                                                            const float* __restrict__ table,
                                                            const float* __restrict__ pos,
                                                            const float* __restrict__ img_tokens, int n_tok,
-                                                           int insert_col, float* __restrict__ x, int L, int Lx, int d) {
+                                                           int insert_col, float* __restrict__ x, int L, int Lx, int d,
+                                                           const int* __restrict__ seq_off) {
     // Lx <= L: only the first Lx columns of every sequence are written, x is [B, Lx, d] (keds_text_run_ex: columns that
-    // cannot reach the read-out under the causal mask are never embedded)
+    // cannot reach the read-out under the causal mask are never embedded).  seq_off (packed rows, keds_text_run_packed): sample b
+    // owns rows [seq_off[b], seq_off[b + 1]) of x and only its own columns are written
     const int b = blockIdx.x / Lx, t = blockIdx.x % Lx;
+    size_t orow = (size_t)b * Lx + t;
+    if (seq_off) {
+        const int r0 = seq_off[b];
+        if (t >= seq_off[b + 1] - r0) return;
+        orow = (size_t)r0 + t;
+    }
     const float* src;
     if (img_tokens && t >= insert_col && t < insert_col + n_tok) {
         src = img_tokens + ((size_t)b * n_tok + (t - insert_col)) * d;
@@ -379,7 +388,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const int* __restrict
         src = table + (size_t)tokens[(size_t)b * L + col] * d;
     }
     const float* pe = pos + (size_t)t * d;
-    float* o = x + ((size_t)b * Lx + t) * d;
+    float* o = x + orow * d;
     for (int i = threadIdx.x * 4; i < d; i += 1024)
         *reinterpret_cast<f32x4*>(o + i) =
             *reinterpret_cast<const f32x4*>(src + i) + *reinterpret_cast<const f32x4*>(pe + i);
@@ -688,7 +697,8 @@ int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int 
 }
 
 int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
-                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream);
+                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream,
+                           const int32_t* seq_off = nullptr);
 
 extern "C" int keds_embed_tokens(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
                                  int n_tok, int insert_col, float* x, int B, int L, int d, void* stream) {
@@ -697,7 +707,7 @@ extern "C" int keds_embed_tokens(const int32_t* tokens, const float* table, cons
 
 // the first Lx columns only (x: [B, Lx, d]); a splice that reaches beyond Lx is cut there, like the context cut at L
 int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
-                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream) {
+                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream, const int32_t* seq_off) {
     KEDS_REQUIRE(tokens && table && pos && x && B > 0 && L > 0 && Lx > 0 && Lx <= L, "keds_embed_tokens: bad argument");
     KEDS_REQUIRE(d % 4 == 0, "keds_embed_tokens: d must be a multiple of 4");
     if (img_tokens) {
@@ -706,7 +716,7 @@ int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const floa
     }
     KedsProfScope prof(KEDS_PROF_OTHER, (hipStream_t)stream);
     embed_tokens_kernel<<<B * Lx, 256, 0, (hipStream_t)stream>>>(tokens, table, pos, img_tokens, n_tok, insert_col, x, L,
-                                                                  Lx, d);
+                                                                  Lx, d, seq_off);
     return keds_check_launch("embed_tokens_kernel");
 }
 
@@ -781,13 +791,15 @@ int keds_cast_rows_f16_f32_impl(const void* x16, float* x32, int rows, int dim, 
     return keds_check_launch("cast_rows_f16_f32_kernel");
 }
 
-int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st) {
+int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st,
+                          bool global_rows) {
     KEDS_REQUIRE(src && dst && row && S > 0 && B > 0 && dim % 8 == 0 && mode >= 0 && mode <= 2, "gather_rows: bad argument");
     KedsProfScope prof(KEDS_PROF_OTHER, st);
     const unsigned grid = (unsigned)((B * (dim / 8) + 255) / 256);
-    if (mode == 0) gather_rows_kernel<0><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim);
-    else if (mode == 1) gather_rows_kernel<1><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim);
-    else gather_rows_kernel<2><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim);
+    const int gr = global_rows ? 1 : 0;
+    if (mode == 0) gather_rows_kernel<0><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim, gr);
+    else if (mode == 1) gather_rows_kernel<1><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim, gr);
+    else gather_rows_kernel<2><<<grid, 256, 0, st>>>(src, dst, row, S, B, dim, gr);
     return keds_check_launch("gather_rows_kernel");
 }
 

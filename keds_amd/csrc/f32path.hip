@@ -329,7 +329,8 @@ size_t keds_tower_f32_workspace_bytes(int width, int seq, int B) {
            keds_align_up(M * (size_t)width * 4 * 4, 256);
 }
 
-int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st);
+int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st,
+                          bool global_rows = false);
 
 int keds_layernorm_pair_impl(const float* x, long long x_stride, const float* gamma, const float* beta, void* out, long long plane,
                              int rows, int dim, hipStream_t st);

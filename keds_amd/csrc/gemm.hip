@@ -816,7 +816,10 @@ int launch_small(const void* A, const void* W, const float* bias, void* out, int
     // fewer workgroups than 2 per CU: nothing else hides the DMA latency, so use the deep ring -- unless the launch is meant to run
     // BESIDE another kernel's workgroups (the towers' remainder-row chain beside the attention launch, round 5): the deep ring's
     // 128 KiB of LDS needs an EMPTY CU, the two-deep ring's 64 KiB fits next to one resident attention workgroup (74 KiB)
-    if (tiles < 512 && !keds_small_lds_scope()) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
+    // (round 6: the deep ring only while ONE round of it holds the launch.  Its 128 KiB of LDS mean one workgroup per CU, 256 at a
+    // time: 324 workgroups -- the packed text tower's c_proj -- ran two rounds, the second a quarter full, where the two-deep form's
+    // 512 slots take them in one and the second resident workgroup hides the DMA latency the deep ring was there for)
+    if (tiles <= 256 && !keds_small_lds_scope()) return launch_small_nst<EPI, 4>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
     return launch_small_nst<EPI, 2>(A, W, bias, out, M, N, K, aux, aux_i, aux2, 1, lda, ldc, st);
 }
 

@@ -11,9 +11,20 @@ int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, 
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
 int keds_cls_rows_impl(float* x, const float* cls, const float* pos, int B, int S, int d, hipStream_t st);
 int keds_cast_rows_f16_f32_impl(const void* x16, float* x32, int rows, int dim, long long stride, hipStream_t st);
-int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st);
+int keds_gather_rows_impl(const void* src, void* dst, const int32_t* row, int S, int B, int dim, int mode, hipStream_t st,
+                          bool global_rows = false);
 int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const float* pos, const float* img_tokens,
-                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream);
+                           int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream,
+                           const int32_t* seq_off = nullptr);
+
+// Packed rows of a causal tower (round 6, keds_text_run_packed): sample b owns rows [off[b], off[b + 1]) of every activation buffer
+// instead of [b S, (b + 1) S); `rows` = off[B] on the host.  The GEMMs and LayerNorm statistics are row-wise and do not care; the
+// attention and the read-out-row gather take the offsets.
+struct PackedRows {
+    const int32_t* off;     // device int32 [B + 1]
+    int rows;               // rows the tower runs (whole 256-row tiles where the workspace allows)
+    int valid;              // off[B]: rows [valid, rows) belong to no sample -- zero rows, kept finite (the attention never writes them)
+};
 
 bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
 void keds_gemm_small_lds(int on);                  // gemm.hip: small GEMM launches of this thread take the 64 KiB-LDS kernel form
@@ -170,15 +181,19 @@ int cls_rows_tail(const keds_tower_params* p, const keds_block_params& k, const 
 // block), then the B read-out rows of the attention output and of the residual stream are gathered into compact [B, w]
 // buffers (in the qkv buffer, which nobody reads any more) and out-proj, ln_2 and the MLP run on those.  On return the first
 // B rows of x hold the block's output for sample b in row b: the caller reads out with S = 1, row 0.
+// pk (packed rows): `rows` are GLOBAL row indices (off[b] + the sample's read-out column).
 int rows_tail(const keds_tower_params* p, const keds_block_params& k, const TowerWs& t, float* x, const void* x16, int B,
-              const int32_t* rows, hipStream_t st) {
+              const int32_t* rows, hipStream_t st, const PackedRows* pk = nullptr) {
     const int w = p->width, S = p->seq;
     int rc;
-    if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
+    if (pk) rc = keds_attention_packed(t.qkv, t.att, B, S, pk->off, p->heads, p->causal, st);
+    else rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st);
+    if (rc) return rc;
     bf16_t* att_c = t.qkv;                                               // [B, w] bf16 (2 w bytes per row: a multiple of 256)
     float* x_c = (float*)((char*)t.qkv + (size_t)B * w * 2);             // [B, w] fp32; 6 B w <= the buffer's 6 w pad256(B S)
-    if ((rc = keds_gather_rows_impl(t.att, att_c, rows, S, B, w, 0, st))) return rc;
-    if ((rc = keds_gather_rows_impl(x16 ? x16 : (const void*)x, x_c, rows, S, B, w, x16 ? 1 : 2, st))) return rc;
+    const int bound = pk ? pk->valid : S;
+    if ((rc = keds_gather_rows_impl(t.att, att_c, rows, bound, B, w, 0, st, pk != nullptr))) return rc;
+    if ((rc = keds_gather_rows_impl(x16 ? x16 : (const void*)x, x_c, rows, bound, B, w, x16 ? 1 : 2, st, pk != nullptr))) return rc;
     if ((rc = keds_gemm_bt_ex(att_c, w, k.out_w, k.out_b, x_c, w, B, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
     if ((rc = keds_layernorm_impl(x_c, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, B, w, st))) return rc;
     if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, t.hid, B, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
@@ -281,10 +296,11 @@ int tower_forward_fp8(const keds_tower_params* p, float* x, int B, const TowerWs
 // keds_tower_forward promises only a multiple of 128 and keeps the two-lane scheme
 // last_rows (device int32 [B], nullable): the one row of every sample that is read after the last block (rows_tail): on
 // return x[b] (row b of the first B rows) holds that row of sample b; without it x holds every row as before
+// pk (nullable): packed rows -- M = pk->rows <= B * seq, the workspace is carved for B * seq
 int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, bool allow_fill,
-                  const int32_t* last_rows = nullptr) {
+                  const int32_t* last_rows = nullptr, const PackedRows* pk = nullptr) {
     const int w = p->width, S = p->seq;
-    const int M = B * S;
+    const int M = pk ? pk->rows : B * S;
     TowerWs t = carve_tower(ws, w, S, B);
     KedsSplitKScope splitk(t.splitk, KEDS_SPLITK_BYTES);   // this call's GEMMs split K into this call's scratch only
     int rc;
@@ -304,6 +320,19 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         return KEDS_E_ARG;
     }
     const bool fp8 = p->fp8 && Mm > 0;             // fewer than 256 rows: everything is "remainder rows" (bf16 kernels)
+    if (pk && (p->fp8 || !p->causal || !last_rows)) {
+        keds_set_error("keds_tower_forward: packed rows need a causal bf16 tower with a read-out row per sample");
+        return KEDS_E_ARG;
+    }
+    if (pk && pk->rows > pk->valid &&
+        hipMemsetAsync(t.att + (size_t)pk->valid * w, 0, (size_t)(pk->rows - pk->valid) * w * sizeof(bf16_t), st) != hipSuccess) {
+        keds_set_error("keds_tower_forward: packed rows: %s", hipGetErrorString(hipGetLastError()));
+        return KEDS_E_LAUNCH;
+    }
+    auto attention = [&](hipStream_t s_) {           // the block's attention on all samples
+        return pk ? keds_attention_packed(t.qkv, t.att, B, S, pk->off, p->heads, p->causal, s_)
+                  : keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, s_);
+    };
     if (fp8) return tower_forward_fp8(p, x, B, t, Mm, st, last_rows);
     if (folded) {
         // When every GEMM of the block would split into full 256-row tiles + a remainder launch anyway, the remainder
@@ -331,7 +360,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         // lane waits for the main in_proj, runs the tail samples' attention beside the main attention launch, and the main lane
         // waits for THAT in front of out-proj.  Bit-identical -- and neutral: the side launches (128 KiB of LDS each) do not fit
         // beside an attention workgroup either, so the wait only moves.
-        const int b_tail = lanes.split && tail_attention_on_side() ? Mm / S : B;      // first tail sample (B: none)
+        const int b_tail = lanes.split && !pk && tail_attention_on_side() ? Mm / S : B;      // first tail sample (B: none)
         const bool tail_side = b_tail > 0 && b_tail < B;
         // Round 5: with the tail samples' attention on the side lane the WHOLE remainder chain of a block (out-proj, c_fc, c_proj,
         // the next in_proj of the remainder rows) starts beside the main ATTENTION launch instead of beside the main GEMMs, whose
@@ -349,7 +378,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
             if (rem.n && (rc = qkv_rows(t, k, w, rem))) return rc;
             if (last && (p->last_cls_only || last_rows)) {
                 if ((rc = lanes.to_main())) return rc;
-                return last_rows ? rows_tail(p, k, t, x, t.h, B, last_rows, st) : cls_rows_tail(p, k, t, x, t.h, B, st);
+                return last_rows ? rows_tail(p, k, t, x, t.h, B, last_rows, st, pk) : cls_rows_tail(p, k, t, x, t.h, B, st);
             }
             if (tail_side) {
                 if ((rc = lanes.to_side())) return rc;               // side: behind the main in_proj
@@ -360,7 +389,7 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
                 if ((rc = lanes.to_main())) return rc;               // main: behind the tail samples' attention
             } else {
                 if ((rc = lanes.to_main())) return rc;
-                if ((rc = lanes.attention_then_side([&] { return keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st); }))) return rc;
+                if ((rc = lanes.attention_then_side([&] { return attention(st); }))) return rc;
             }
             if ((rc = out_rows(t, k, w, body))) return rc;
             if (rem.n && (rc = out_rows(t, k, w, rem))) return rc;
@@ -378,9 +407,9 @@ int tower_forward(const keds_tower_params* p, float* x, int B, void* ws, hipStre
         const bool last = l == p->layers - 1;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln1_g, k.ln1_b, t.h, 0, M, w, st))) return rc;
         if ((rc = keds_gemm_bt(t.h, k.qkv_w, k.qkv_b, t.qkv, M, 3 * w, w, KEDS_EPI_BIAS_BF16, nullptr, 0, st))) return rc;
-        if (last && last_rows) return rows_tail(p, k, t, x, nullptr, B, last_rows, st);
+        if (last && last_rows) return rows_tail(p, k, t, x, nullptr, B, last_rows, st, pk);
         if (last && p->last_cls_only) return cls_rows_tail(p, k, t, x, nullptr, B, st);
-        if ((rc = keds_attention(t.qkv, t.att, B, S, p->heads, p->causal, st))) return rc;
+        if ((rc = attention(st))) return rc;
         if ((rc = keds_gemm_bt(t.att, k.out_w, k.out_b, x, M, w, w, KEDS_EPI_BIAS_RESID_F32, nullptr, 0, st))) return rc;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, t.h, 0, M, w, st))) return rc;
         if ((rc = keds_gemm_bt(t.h, k.fc_w, k.fc_b, t.hid, M, 4 * w, w, KEDS_EPI_BIAS_QGELU_BF16, nullptr, 0, st))) return rc;
@@ -565,6 +594,9 @@ extern "C" int keds_text_trim_enable(int on) {   // 0 off, 1 on, 2 the column cu
     g_text_trim = on < 0 || on > 3 ? -1 : on;
     return KEDS_OK;
 }
+extern "C" int keds_text_trim_mode(void) {       // the flow in force: 1 = cut + read-out-row tail (the default; what packed rows build on)
+    return g_text_trim < 0 ? (text_trim_on() ? 1 : 0) : g_text_trim;
+}
 
 // Work that cannot reach the read-out is not done (round 5):
 //  * the mask is causal (model.py:543-549), so columns to the right of the last read-out column change no row that is read:
@@ -606,6 +638,54 @@ extern "C" int keds_text_run_ex(const keds_text_params* p, const int32_t* tokens
     if ((rc = tower_forward(&tp, v.x, B, v.tower, (hipStream_t)stream, true, last_rows))) return rc;
     return keds_readout(v.x, last_rows ? 1 : Lx, last_rows ? nullptr : readout_row, p->ln_final_g, p->ln_final_b, p->proj_t, out,
                         B, w, p->embed_dim, normalize, v.ro, keds_readout_workspace_bytes(B, w), stream);
+}
+
+// The same on PACKED rows (round 6).  Captions end at different columns and under the causal mask (model.py:543-549) a column to
+// the right of a caption's own read-out column reaches nothing that is read of THAT caption: sample b needs columns
+// [0, len_b) only, len_b = its read-out column + 1.  keds_text_run_ex cuts every sample at the batch's longest caption (B x max len
+// rows); here sample b owns rows [seq_off[b], seq_off[b + 1]) and the tower runs sum(len_b) rows -- at bench.py's captions (read-out
+// columns 10 .. 42) 6.9 k instead of 11 k rows for the dual workload's 2B-row pass, whole rounds of workgroups fewer in every GEMM.
+//   seq_off         device int32 [B + 1]: 0 = seq_off[0] <= ... <= seq_off[B] = rows_total, 1 <= len_b <= seq_max
+//   readout_global  device int32 [B]: seq_off[b] + the read-out column of sample b (a row outside [0, rows_total) comes out as NaN)
+// Causal bf16 towers with the read-out-row tail (the default flow); anything else (fp8 / fp32 towers, KEDS_TEXT_TRIM=0) is the
+// caller's to route through keds_text_run_ex.
+extern "C" int keds_text_run_packed(const keds_text_params* p, const int32_t* tokens, const int32_t* seq_off,
+                                    const int32_t* readout_global, int rows_total, int seq_max, const float* img_tokens, int n_tok,
+                                    int insert_col, int B, float* out, int normalize, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+    KEDS_REQUIRE(p && tokens && seq_off && readout_global && out && workspace && B > 0, "keds_text_run_packed: bad argument");
+    int rc = check_tower(&p->tower, "keds_text_run_packed");
+    if (rc) return rc;
+    KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_text_run_packed: embed_dim must be a multiple of 128");
+    const int w = p->tower.width, L = p->tower.seq;
+    KEDS_REQUIRE(p->tower.causal && !p->tower.fp8 && !p->tower.f32, "keds_text_run_packed: a causal bf16 tower only");
+    KEDS_REQUIRE(keds_text_trim_mode() == 1, "keds_text_run_packed: the A/B flows of keds_text_trim_enable / KEDS_TEXT_TRIM=0 go through keds_text_run_ex");
+    KEDS_REQUIRE(seq_max >= 1 && seq_max <= L && rows_total >= B && (long long)rows_total <= (long long)B * seq_max,
+                 "keds_text_run_packed: rows_total %d / seq_max %d do not fit B = %d sequences of <= %d columns", rows_total, seq_max, B, L);
+    TextWs v = carve_text(p, B, workspace);
+    if (workspace_bytes < v.bytes) {
+        keds_set_error("keds_text_run_packed: workspace %zu < %zu", workspace_bytes, v.bytes);
+        return KEDS_E_WORKSPACE;
+    }
+    keds_tower_params tp = p->tower;
+    tp.seq = seq_max;
+    v = carve_text_cols(p, B, seq_max, workspace);
+    // the tower runs WHOLE 256-row tiles: the rows between rows_total and the next multiple of 256 are zero rows that belong to no
+    // sample (no attention reads them, nothing gathers them).  A ragged last tile would send every GEMM of every block through the
+    // remainder-row launches and the stricter fill rule of the 256 x 256 kernels (gemm.hip, big_tiles_ok).
+    int rows_run = (rows_total + 255) / 256 * 256;
+    if ((size_t)rows_run > pad_rows((size_t)B * seq_max)) rows_run = rows_total;
+    if (rows_run > rows_total &&
+        hipMemsetAsync(v.x + (size_t)rows_total * w, 0, (size_t)(rows_run - rows_total) * w * sizeof(float), (hipStream_t)stream) != hipSuccess) {
+        keds_set_error("keds_text_run_packed: %s", hipGetErrorString(hipGetLastError()));
+        return KEDS_E_LAUNCH;
+    }
+    if ((rc = keds_embed_tokens_impl(tokens, p->token_emb, p->pos_emb, img_tokens, n_tok, insert_col, v.x, B, L, seq_max, w, stream, seq_off)))
+        return rc;
+    const PackedRows pk{seq_off, rows_run, rows_total};
+    if ((rc = tower_forward(&tp, v.x, B, v.tower, (hipStream_t)stream, false, readout_global, &pk))) return rc;
+    return keds_readout(v.x, 1, nullptr, p->ln_final_g, p->ln_final_b, p->proj_t, out, B, w, p->embed_dim, normalize, v.ro,
+                        keds_readout_workspace_bytes(B, w), stream);
 }
 
 extern "C" int keds_text_run(const keds_text_params* p, const int32_t* tokens, const int32_t* readout_row,

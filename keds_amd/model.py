@@ -192,6 +192,7 @@ class _Packed:
         self.device = conv.device
 
 
+TEXT_PACKED = True          # the text tower on packed rows when captions end at different columns (tests switch it off for an A/B)
 GUARD_EAGER_PASSES = 8      # numerics = "auto": tower passes whose guard flag is read back at once (see CLIP.__init__)
 
 
@@ -465,11 +466,29 @@ class CLIP(nn.Module):
         # (model.py:543-549): the host knows the read-out columns (they were derived from the host copy of the tokens), so
         # the library cuts the sequence there (keds_text_run_ex)
         seq_used = int(readout.max()) + 1
+        # ... and columns to the right of a caption's OWN read-out column cannot reach that caption's read-out: when the captions of
+        # a batch end at different columns the tower runs on PACKED rows, sample b owning len_b = read-out column + 1 of them
+        # (keds_text_run_packed, round 6) -- sum(len_b) rows instead of B * max(len_b).  Worth it from an eighth fewer rows; the
+        # bf16 flows only (the fp8 / fp32 towers and KEDS_TEXT_TRIM=0 keep the rectangular layout).
+        lens = readout.to(torch.int64).cpu() + 1
+        rows_total = int(lens.sum())
+        packed = None
+        if self.precision == "bf16" and TEXT_PACKED and lib.keds_text_trim_mode() == 1 and rows_total * 8 <= B * seq_used * 7:
+            off = torch.zeros(B + 1, dtype=torch.int64)
+            off[1:] = torch.cumsum(lens, 0)
+            both = torch.cat([off, off[:-1] + readout.to(torch.int64).cpu()]).to(torch.int32)
+            both = both.to(eng.device, non_blocking=True)
+            packed = (both[:B + 1], both[B + 1:])
 
         def run(eng):
             nbytes = lib.keds_text_workspace_bytes(C.byref(eng.text), B)
             ws = self._ws.get(nbytes, eng.device)
             out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
+            if packed is not None and self.precision == "bf16":
+                check(lib.keds_text_run_packed(C.byref(eng.text), ptr(tok), ptr(packed[0]), ptr(packed[1]), rows_total, seq_used,
+                                               ptr(it), n_tok, int(insert_col), B, ptr(out), 1 if normalize else 0, ptr(ws),
+                                               ws.numel(), stream()), "keds_text_run_packed")
+                return out
             check(lib.keds_text_run_ex(C.byref(eng.text), ptr(tok), ptr(ro), ptr(it), n_tok, int(insert_col), B, seq_used,
                                        ptr(out), 1 if normalize else 0, ptr(ws), ws.numel(), stream()), "keds_text_run")
             return out

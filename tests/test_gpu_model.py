@@ -461,6 +461,51 @@ def _ragged_tokens(B, L, eots, end_id, star, vocab, seed=11):
     return torch.from_numpy(t)
 
 
+@pytest.mark.parametrize("size", ["tiny", "vitl"])
+def test_text_tower_on_packed_rows_equals_the_rectangular_layout(size, tiny_model):
+    """Round 6: captions end at different columns, and under the causal mask (model.py:543-549) sample b needs its columns
+    [0, read-out column] only.  keds_text_run_packed gives every sample exactly those rows (sum of the lengths instead of
+    B x the longest); the GEMMs and LayerNorm statistics are row-wise, the attention takes per-sample offsets.  Same arithmetic per
+    row as the rectangular layout (rows only land in other tiles): equal bits on the tiny model, the batch-size sweep's class at
+    ViT-L/14 width (other tile shapes / split-K).  Every text entry point, ragged read-out columns from 6 to 73."""
+    import keds_amd.model as M
+    if size == "tiny":
+        _, sd, m = tiny_model
+        d = 128
+    else:
+        sd = O.synth_clip_state_dict(**VITL, seed=7)
+        m = keds_amd.build_model(sd, fp16=False).cuda()
+        del sd
+        d = 768
+    m.set_precision("bf16")
+    L, star = 77, 7
+    rs = np.random.RandomState(5)
+    try:
+        for tag, B, eots in (("mixed", 128, [9, 40, 12, 30, 41, 8]), ("wide", 37, [6, 73, 20, 33]), ("two", 2, [10, 50])):
+            text = _ragged_tokens(B, L, eots, m.end_id, star, m.vocab_size)
+            tok3 = torch.from_numpy(rs.standard_normal((B, 3, d)).astype(np.float32) * 0.05).cuda()
+            calls = {
+                "encode_text": lambda: m.encode_text(text.cuda()),
+                "eti3": lambda: m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False),
+                "eti2": lambda: m.encode_text_img_retrieval(text, tok3[:, :2].contiguous(), split_ind=star, repeat=False),
+                "eti_train3": lambda: m.encode_text_img_train(text.cuda(), tok3, split_ind=star),
+            }
+            for name, fn in calls.items():
+                M.TEXT_PACKED = True
+                a = fn().clone()
+                assert torch.equal(a, fn()) and torch.isfinite(a).all(), (size, tag, name)
+                M.TEXT_PACKED = False
+                b = fn().clone()
+                c, r = min_cosine(a, b), rel_l2(a, b)
+                report("text_packed_vs_rectangular", size=size, case=tag, call=name, B=B, bit_equal=bool(torch.equal(a, b)), min_cosine=c, rel_l2=r)
+                if size == "tiny":
+                    assert torch.equal(a, b), (size, tag, name, c, r)
+                else:
+                    assert c >= 0.99998 and r <= 6e-3, (size, tag, name, c, r)
+    finally:
+        M.TEXT_PACKED = True
+
+
 def test_text_readout_row_outside_the_declared_cut_comes_out_as_nan(tiny_model):
     """keds_text_run_ex trusts the host's `seq_used` (max read-out column + 1).  A device read-out row at or beyond it would read
     another sample's token out of the cut [B, seq_used, w] layout: the library returns NaN for such a row (every flow: the column
