@@ -77,6 +77,12 @@ int keds_text_forward(keds_text* txt, const int32_t* tokens, const void* img_tok
  * 0 = unknown.  Every readout_idx[b] must be < seq_used. */
 int keds_text_forward_used(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
                            int insert_idx, const int32_t* readout_idx, int seq_used, int B, void* out, void* stream);
+/* the same with the read-out columns themselves on the HOST (readout_host: host int32 [B]; round 6): a caption needs its own
+ * columns [0, read-out column] only (causal mask), so the tower runs on PACKED rows -- the sum of the captions' lengths instead
+ * of B x the longest -- where that pays (bf16 compute; keds_text_run_packed, keds_hip.h), the rectangular cut otherwise.  Same
+ * result as keds_text_forward within the bf16 flow's own reordering of tiles. */
+int keds_text_forward_packed(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
+                             int insert_idx, const int32_t* readout_host, int B, void* out, void* stream);
 
 /* ---- knowledge injection of ONE stream: IM2TEXT keys (layers.{i}.0.{weight,bias}, fc_out.*) and two
  *      CrossFormers (cross_layers.{i}.to_{q,k,v}.*, to_out.0.*): retrieval_fuse, text_condition ---- */

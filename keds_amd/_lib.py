@@ -101,6 +101,7 @@ SIGNATURES = {
     "keds_text_info": (i32, [vp] + [C.POINTER(i32)] * 5),
     "keds_text_forward": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, vp]),
     "keds_text_forward_used": (i32, [vp, vp, vp, i32, i32, vp, i32, i32, vp, vp]),
+    "keds_text_forward_packed": (i32, [vp, vp, vp, i32, i32, vp, i32, vp, vp]),
     "keds_knowledge_create": (i32, [vp, C.POINTER(Tensor), i32, C.POINTER(Tensor), i32, C.POINTER(Tensor), i32, pp]),
     "keds_knowledge_destroy": (i32, [vp]),
     "keds_knowledge_forward": (i32, [vp, vp, vp, vp, i32, i32, vp, vp]),

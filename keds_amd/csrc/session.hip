@@ -619,6 +619,49 @@ extern "C" int keds_text_forward_used(keds_text* txt, const int32_t* tokens, con
                             0, txt->ws.p, txt->ws.bytes, stream);
 }
 
+// The same with the read-out columns on the HOST (round 6): a caption needs its own columns [0, read-out column] only, so the
+// tower runs on packed rows -- sum of the captions' lengths instead of B x the longest (keds_text_run_packed, keds_hip.h) -- when
+// that saves an eighth of the rows and the tower is a bf16 one on its default flow; the rectangular cut of keds_text_forward_used
+// otherwise.  readout_host: host int32 [B].
+extern "C" int keds_text_forward_packed(keds_text* txt, const int32_t* tokens, const void* img_tokens, int n_img_tok,
+                                        int insert_idx, const int32_t* readout_host, int B, void* out, void* stream) {
+    const char* what = "keds_text_forward_packed";
+    KEDS_REQUIRE(txt && tokens && readout_host && out && B > 0, "%s: bad argument", what);
+    const int L = txt->p.tower.seq;
+    std::vector<int32_t> host(2 * (size_t)B + 1);        // [0, B]: offsets; [B + 1, 2B]: global read-out rows
+    long long rows = 0;
+    int seq_used = 0;
+    for (int b = 0; b < B; ++b) {
+        KEDS_REQUIRE(readout_host[b] >= 0 && readout_host[b] < L, "%s: read-out column %d of sample %d outside [0, %d)", what, readout_host[b], b, L);
+        host[b] = (int32_t)rows;
+        host[B + 1 + b] = (int32_t)(rows + readout_host[b]);
+        rows += readout_host[b] + 1;
+        seq_used = readout_host[b] + 1 > seq_used ? readout_host[b] + 1 : seq_used;
+    }
+    host[B] = (int32_t)rows;
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    if ((rc = txt->tok.reserve(host.size() * sizeof(int32_t), st, what))) return rc;
+    // (pageable source: the copy has left `host` when the call returns)
+    HIP_TRY(hipMemcpyAsync(txt->tok.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), what);
+    const int32_t* dev = (const int32_t*)txt->tok.p;
+    const bool packed = txt->p.tower.causal && !txt->p.tower.fp8 && !txt->p.tower.f32 && keds_text_trim_mode() == 1 &&
+                        rows * 8 <= (long long)B * seq_used * 7;
+    KEDS_REQUIRE((img_tokens == nullptr) == (n_img_tok == 0), "%s: img_tokens and n_img_tok disagree", what);
+    KEDS_REQUIRE(n_img_tok == 0 || n_img_tok == 2 || n_img_tok == 3, "%s: 2 or 3 pseudo tokens (model.py:831-834)", what);
+    KEDS_REQUIRE(n_img_tok == 0 || (insert_idx >= 0 && insert_idx + n_img_tok <= L), "%s: insert_idx out of range", what);
+    const size_t need = keds_text_workspace_bytes(&txt->p, B);
+    if ((rc = txt->ws.reserve(need, st, what))) return rc;
+    if (packed)
+        return keds_text_run_packed(&txt->p, tokens, dev, dev + B + 1, (int)rows, seq_used, (const float*)img_tokens, n_img_tok, insert_idx,
+                                    B, (float*)out, 0, txt->ws.p, txt->ws.bytes, stream);
+    // rectangular: the device copy of the columns themselves
+    for (int b = 0; b < B; ++b) host[b] = readout_host[b];
+    HIP_TRY(hipMemcpyAsync(txt->tok.p, host.data(), (size_t)B * sizeof(int32_t), hipMemcpyHostToDevice, st), what);
+    return keds_text_run_ex(&txt->p, tokens, dev, (const float*)img_tokens, n_img_tok, insert_idx, B, seq_used, (float*)out, 0,
+                            txt->ws.p, txt->ws.bytes, stream);
+}
+
 // ---- knowledge injection ------------------------------------------------------------------------------
 namespace {
 int load_crossformer(const Loader& L, const Weights& W, std::vector<keds_cross_layer_params>& layers,

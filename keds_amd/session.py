@@ -125,8 +125,15 @@ class Text(_Handle):
         """seq_used: max(readout) + 1 when the caller knows it on the host (None: taken from `readout`, one device-to-host
         copy when that lives on the device; 0: unknown -- every column runs)."""
         tok = tokens.to(torch.int32).contiguous()
-        ro = readout.to(torch.int32).contiguous()
         it = None if img_tokens is None else img_tokens.float().contiguous()
+        if seq_used is None and not readout.is_cuda and readout.numel():
+            # the read-out columns are on the host: the library packs the captions' rows where that pays (keds_text_forward_packed)
+            ro_h = readout.to(torch.int32).contiguous()
+            out = torch.empty((tok.shape[0], self.embed_dim), dtype=torch.float32, device=tok.device)
+            check(load().keds_text_forward_packed(self.h, ptr(tok), ptr(it), 0 if it is None else it.shape[1], insert_idx,
+                                                  ro_h.data_ptr(), tok.shape[0], ptr(out), stream()), "keds_text_forward_packed")
+            return out
+        ro = readout.to(torch.int32).contiguous()
         if seq_used is None:
             seq_used = int(ro.max()) + 1 if ro.numel() else 0
         out = torch.empty((tok.shape[0], self.embed_dim), dtype=torch.float32, device=tok.device)

@@ -502,8 +502,18 @@ def test_text_tower_on_packed_rows_equals_the_rectangular_layout(size, tiny_mode
                     assert torch.equal(a, b), (size, tag, name, c, r)
                 else:
                     assert c >= 0.99998 and r <= 6e-3, (size, tag, name, c, r)
+        if size == "tiny":       # the fp32-stream flow (stand-alone LayerNorm: set_numerics("safe") / KEDS_DETERMINISTIC=1) packs as well
+            m.set_numerics("safe")
+            text = _ragged_tokens(40, L, [9, 40, 12, 30, 41, 8], m.end_id, star, m.vocab_size)
+            tok3 = torch.from_numpy(rs.standard_normal((40, 3, d)).astype(np.float32) * 0.05).cuda()
+            M.TEXT_PACKED = True
+            a = m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False).clone()
+            M.TEXT_PACKED = False
+            b = m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False).clone()
+            assert torch.isfinite(a).all() and torch.equal(a, b)
     finally:
         M.TEXT_PACKED = True
+        m.set_numerics("auto")
 
 
 def test_text_readout_row_outside_the_declared_cut_comes_out_as_nan(tiny_model):

@@ -96,6 +96,24 @@ def test_text_handle_matches_facade_and_golden(ctx, tiny):
     _close("session.text.eti2", txt.forward(text, eot + 1, tok2, ins), g["eti2"])
     with pytest.raises(RuntimeError, match="pseudo tokens"):
         txt.forward(text, eot, torch.zeros(4, 4, 128, device="cuda"), ins)
+    # read-out columns on the HOST: keds_text_forward_packed lays the captions' rows out back to back (round 6); ragged captions so
+    # that packing really happens -- same bits as the facade (which packs too) and as the rectangular handle call on this model
+    rs = np.random.RandomState(4)
+    B, L = 24, 77
+    rag = np.zeros((B, L), dtype=np.int64)
+    for b in range(B):
+        e = int(rs.randint(6, 60))
+        rag[b, :e] = rs.randint(1, 500, size=e)
+        rag[b, 0], rag[b, 3], rag[b, e] = 510, star, 511
+        rag[b, 1:e][rag[b, 1:e] == star] = star + 1
+        rag[b, 3] = star
+    rag = torch.from_numpy(rag)
+    eot_h = (rag == 511).int().argmax(dim=1)
+    tok3b = torch.from_numpy(rs.standard_normal((B, 3, 128)).astype(np.float32) * 0.05).cuda()
+    packed = txt.forward(rag.cuda(), eot_h + 2, tok3b, 3)                # host read-out columns -> packed rows
+    rect = txt.forward(rag.cuda(), (eot_h + 2).cuda(), tok3b, 3)         # device read-out columns -> the rectangular cut
+    assert torch.isfinite(packed).all() and torch.equal(packed, rect)
+    assert torch.equal(packed, m.encode_text_img_retrieval(rag.cuda(), tok3b, split_ind=star, repeat=False))
 
 
 @pytest.mark.parametrize("dim,middle", [(128, 128), (768, 512)])
