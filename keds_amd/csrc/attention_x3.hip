@@ -63,8 +63,16 @@ __device__ __forceinline__ void ax_split(float v, f16_t& hi, f16_t& lo) {
 
 __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                        f16_t* __restrict__ pair, long long plane, int S, int heads,
-                                                                       int causal, int q_limit, int* __restrict__ overflow) {
+                                                                       int causal, int q_limit, int* __restrict__ overflow,
+                                                                       const int* __restrict__ seq_off) {
     extern __shared__ __attribute__((aligned(16))) f16_t ax_lds[];
+    // packed rows (keds_attention_x3_packed; towers.hip PackedRows): sample b owns rows [seq_off[b], seq_off[b + 1]); S was the
+    // launch's upper bound (it sized the LDS) and becomes the sample's own length
+    long long row_base = (long long)(blockIdx.x / heads) * S;
+    if (seq_off) {
+        row_base = seq_off[blockIdx.x / heads];
+        S = seq_off[blockIdx.x / heads + 1] - (int)row_base;
+    }
     const int nkt = (S + 31) >> 5, SP = nkt * 32, VP = SP + 8;
     f16_t* Kh = ax_lds;                                   // [SP][72]
     f16_t* Kl = Kh + (size_t)SP * AX_KP;
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
     f16_t* Vl = Vh + (size_t)64 * VP;
     const int b = blockIdx.x / heads, hd = blockIdx.x - b * heads;
     const int d = heads * 64, ld = 3 * d;
-    const float* base = qkv + (size_t)b * S * ld + hd * 64;
+    const float* base = qkv + (size_t)row_base * ld + hd * 64;
     bool bad = false;
     [[maybe_unused]] unsigned long long ts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define AX_STAMP(i) do { if (KEDS_AX_DBG & 16) ts[i] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -249,7 +257,7 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
     // lane = query q; register r of a0 / a1 = dim (r & 3) + 8 (r >> 2) + 4 h (+ 32)
     auto store_tile = [&](int q, const f32x16& a0, const f32x16& a1) {
         if (q >= nq) return;
-        const size_t off = ((size_t)b * S + q) * d + hd * 64 + 4 * hh;
+        const size_t off = ((size_t)row_base + q) * d + hd * 64 + 4 * hh;
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
@@ -330,7 +338,7 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
                         *reinterpret_cast<f16x4*>(w + 32 * AX_KP) = vl;
                     }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (the wave's own writes; no other wave touches this region)
-                const size_t row0 = ((size_t)b * S + wave * 32) * d + hd * 64;
+                const size_t row0 = ((size_t)row_base + wave * 32) * d + hd * 64;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int row = 8 * i + (lane >> 3), ch = lane & 7;          // (lone mode: all 32 queries of an own tile exist)
@@ -355,7 +363,7 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
                 acc = fmaf(part[w * 66 + 2 + lane], f, acc);
             }
             const float v = acc / lsum;
-            const size_t off = ((size_t)b * S + q) * d + hd * 64 + lane;
+            const size_t off = ((size_t)row_base + q) * d + hd * 64 + lane;
             if (out && !(KEDS_AX_DBG & 16)) out[off] = v;
             if (pair) {
                 f16_t x, y;
@@ -375,11 +383,12 @@ __global__ __launch_bounds__(64 * AX_WAVES) void attention_x3_kernel(const float
 // qkv fp32 [B, S, 3 * heads * 64]; out fp32 [B, S, heads * 64] (nullable); pair: fp16 planes [2][plane] of the same rows
 // (nullable; plane >= B * S * heads * 64 elements); at least one of them.  q_limit > 0: the first q_limit queries of every sample
 // only (the CLS query of the last ViT block).  overflow (nullable): raised when an operand does not fit an fp16 hi plane.
-extern "C" int keds_attention_x3(const float* qkv, float* out, void* pair, int64_t plane, int B, int S, int heads, int causal,
-                                 int q_limit, int* overflow, void* stream) {
+// seq_off (nullable; device int32 [B + 1]): packed rows -- sample b is rows [seq_off[b], seq_off[b + 1]), S the longest sample
+int keds_attention_x3_impl(const float* qkv, float* out, void* pair, int64_t plane, int B, int S, int heads, int causal, int q_limit,
+                           int* overflow, const int32_t* seq_off, void* stream) {
     KEDS_REQUIRE(qkv && (out || pair) && B > 0 && heads > 0, "keds_attention_x3: bad argument");
     KEDS_REQUIRE(S >= 1 && S <= 288, "keds_attention_x3: S must be in [1, 288] (got %d)", S);
-    KEDS_REQUIRE(!pair || plane >= (int64_t)B * S * heads * 64, "keds_attention_x3: plane stride shorter than the output");
+    KEDS_REQUIRE(!pair || seq_off || plane >= (int64_t)B * S * heads * 64, "keds_attention_x3: plane stride shorter than the output");
     const int SP = (S + 31) / 32 * 32;
     const int lds = 2 * (SP * AX_KP + 64 * (SP + 8)) * (int)sizeof(f16_t) + AX_WAVES * 66 * (int)sizeof(float);
     int rc = keds_func_lds_once((const void*)attention_x3_kernel, lds, "attention_x3_kernel");
@@ -387,6 +396,11 @@ extern "C" int keds_attention_x3(const float* qkv, float* out, void* pair, int64
     hipStream_t st = (hipStream_t)stream;
     KedsProfScope prof(KEDS_PROF_ATTN, st);
     attention_x3_kernel<<<B * heads, 64 * AX_WAVES, lds, st>>>(qkv, out, (f16_t*)pair, plane, S, heads, causal,
-                                                                q_limit > 0 ? q_limit : S, overflow);
+                                                                q_limit > 0 ? q_limit : S, overflow, seq_off);
     return keds_check_launch("attention_x3_kernel");
+}
+
+extern "C" int keds_attention_x3(const float* qkv, float* out, void* pair, int64_t plane, int B, int S, int heads, int causal,
+                                 int q_limit, int* overflow, void* stream) {
+    return keds_attention_x3_impl(qkv, out, pair, plane, B, S, heads, causal, q_limit, overflow, nullptr, stream);
 }

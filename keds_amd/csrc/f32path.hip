@@ -18,6 +18,8 @@
 int keds_layernorm_impl(const float* x, long long x_stride, const int* row_map, int row_mul, const float* gamma,
                         const float* beta, void* out, int out_f32, int rows, int dim, hipStream_t st);
 
+int keds_attention_x3_impl(const float* qkv, float* out, void* pair, int64_t plane, int B, int S, int heads, int causal, int q_limit,
+                           int* overflow, const int32_t* seq_off, void* stream);
 extern "C" int keds_attention_x3(const float* qkv, float* out, void* pair, int64_t plane, int B, int S, int heads, int causal,
                                  int q_limit, int* overflow, void* stream);
 
@@ -151,14 +153,23 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 // 4.4 ms per ViT-L/14 layer at B = 128, 37 % of the fp32 step; this one ~0.4 ms.)  S <= 288.
 constexpr int A32_WAVES = 9;
 __global__ __launch_bounds__(64 * A32_WAVES) void attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int S,
-                                                                        int heads, int causal, int q_limit) {
+                                                                        int heads, int causal, int q_limit,
+                                                                        const int* __restrict__ seq_off) {
     extern __shared__ __attribute__((aligned(16))) float a32_lds[];
+    // packed rows (towers.hip PackedRows): sample b owns rows [seq_off[b], seq_off[b + 1]); S (the longest sample: it sized the LDS)
+    // becomes the sample's own length
+    long long row_base = (long long)(blockIdx.x / heads) * S;
+    if (seq_off) {
+        row_base = seq_off[blockIdx.x / heads];
+        S = seq_off[blockIdx.x / heads + 1] - (int)row_base;
+        q_limit = q_limit < S ? q_limit : S;
+    }
     const int nkt = (S + 31) >> 5, SP = nkt * 32;
     float* Ks = a32_lds;                           // [SP][65]
     float* Vs = a32_lds + (size_t)SP * 65;         // [SP][64]
     const int b = blockIdx.x / heads, hd = blockIdx.x - b * heads;
     const int d = heads * 64, ld = 3 * d;
-    const float* base = qkv + (size_t)b * S * ld + hd * 64;
+    const float* base = qkv + (size_t)row_base * ld + hd * 64;
     for (int idx = threadIdx.x; idx < SP * 16; idx += 64 * A32_WAVES) {
         const int row = idx >> 4, c4 = idx & 15;
         f32x4 kv = f32x4{0.f, 0.f, 0.f, 0.f}, vv = kv;
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(64 * A32_WAVES) void attention_f32_kernel(const flo
         }
         const float ltot = l + __shfl_xor(l, 32, 64);
         if (q < nq) {                                                            // lane = query q; register r = dim (r & 3) + 8 (r >> 2) + 4 h
-            float* orow = out + ((size_t)b * S + q) * d + hd * 64 + 4 * hh;
+            float* orow = out + ((size_t)row_base + q) * d + hd * 64 + 4 * hh;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 *reinterpret_cast<f32x4*>(orow + 8 * g) = f32x4{o0[4 * g] / ltot, o0[4 * g + 1] / ltot, o0[4 * g + 2] / ltot, o0[4 * g + 3] / ltot};
@@ -300,7 +311,13 @@ extern "C" int keds_gemm_f32(const float* A, int64_t lda, const float* W, const 
     return KEDS_E_ARG;
 }
 
+static int attention_f32_impl(const float* qkv, float* out, int B, int S, int heads, int causal, int q_limit, const int32_t* seq_off,
+                              void* stream);
 extern "C" int keds_attention_f32(const float* qkv, float* out, int B, int S, int heads, int causal, int q_limit, void* stream) {
+    return attention_f32_impl(qkv, out, B, S, heads, causal, q_limit, nullptr, stream);
+}
+static int attention_f32_impl(const float* qkv, float* out, int B, int S, int heads, int causal, int q_limit, const int32_t* seq_off,
+                              void* stream) {
     KEDS_REQUIRE(qkv && out && B > 0 && heads > 0, "keds_attention_f32: bad argument");
     KEDS_REQUIRE(S >= 1 && S <= 288, "keds_attention_f32: S must be in [1, 288] (got %d)", S);
     const int lds = ((S + 31) / 32 * 32) * (65 + 64) * (int)sizeof(float);           // K and V padded to whole 32-key tiles
@@ -308,7 +325,7 @@ extern "C" int keds_attention_f32(const float* qkv, float* out, int B, int S, in
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     KedsProfScope prof(KEDS_PROF_ATTN, st);
-    attention_f32_kernel<<<B * heads, 64 * A32_WAVES, lds, st>>>(qkv, out, S, heads, causal, q_limit > 0 ? q_limit : S);
+    attention_f32_kernel<<<B * heads, 64 * A32_WAVES, lds, st>>>(qkv, out, S, heads, causal, q_limit > 0 ? q_limit : S, seq_off);
     return keds_check_launch("attention_f32_kernel");
 }
 
@@ -343,9 +360,12 @@ bool keds_gemm_splits_rows(int M, int N, int K);
 // rate instead of the f32-input MFMA's sixteenth.  The weights arrive as fp16 planes [2][N][K] (keds_split_f16_pair at packing
 // time); LayerNorm writes its output as planes, the attention output is split by a pass of its own, c_fc's epilogue writes the
 // MLP hidden layer as planes.  A value beyond the fp16 range raises the caller's numerics guard (the host falls back to f32 = 1).
-static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows) {
-    const int w = p->width, S = p->seq, M = B * S;
-    const size_t Mp = keds_align_up((size_t)M, 256);
+static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows,
+                            const PackedRows* pk) {
+    const int w = p->width, S = p->seq, M = pk ? pk->rows : B * S;
+    const size_t Mp = keds_align_up((size_t)B * S, 256);          // (the buffers are carved for the rectangular layout either way)
+    const int32_t* soff = pk ? pk->off : nullptr;
+    const int gbound = pk ? pk->valid : S;
     char* base = (char*)ws;
     _Float16* ln2 = (_Float16*)base;                              // planes [2][Mp][w] (the fp32 flow's ln buffer: same bytes)
     float* qkv = (float*)(base + keds_align_up(Mp * w * 4, 256));
@@ -393,9 +413,9 @@ static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* w
             float* att_c = qkv;                                   // [B, w] fp32 each, in the qkv buffer (dead after the attention)
             float* x_c = qkv + (size_t)B * w;
             if (last_rows) {
-                if ((rc = keds_attention_x3(qkv, att, nullptr, 0, B, S, p->heads, p->causal, S, guard, st))) return rc;
-                if ((rc = keds_gather_rows_impl(att, att_c, last_rows, S, B, w, 2, st))) return rc;
-                if ((rc = keds_gather_rows_impl(x, x_c, last_rows, S, B, w, 2, st))) return rc;
+                if ((rc = keds_attention_x3_impl(qkv, att, nullptr, 0, B, S, p->heads, p->causal, S, guard, soff, st))) return rc;
+                if ((rc = keds_gather_rows_impl(att, att_c, last_rows, gbound, B, w, 2, st, pk != nullptr))) return rc;
+                if ((rc = keds_gather_rows_impl(x, x_c, last_rows, gbound, B, w, 2, st, pk != nullptr))) return rc;
             } else {
                 if ((rc = keds_attention_x3(qkv, att, nullptr, 0, B, S, p->heads, p->causal, 1, guard, st))) return rc;
                 if (hipMemcpy2DAsync(att_c, (size_t)w * 4, att, (size_t)S * w * 4, (size_t)w * 4, B, hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -418,7 +438,7 @@ static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* w
             return KEDS_OK;
         }
         // (the attention writes the out-projection's A operand planes itself: no fp32 copy of its output, no split pass)
-        if ((rc = keds_attention_x3(qkv, nullptr, ln2, pl, B, S, p->heads, p->causal, S, guard, st))) return rc;
+        if ((rc = keds_attention_x3_impl(qkv, nullptr, ln2, pl, B, S, p->heads, p->causal, S, guard, soff, st))) return rc;
         if (lane && (rc = keds_stream_order(st, lane->fork, lane->s))) return rc;
         for (int i = 0; i < nspan; ++i) {
             if ((rc = post(k, spans[i]))) return rc;
@@ -429,16 +449,31 @@ static int tower_forward_x3(const keds_tower_params* p, float* x, int B, void* w
 }
 
 // last_rows (device int32 [B], nullable): towers.hip, rows_tail -- the text tower's read-out rows; on return x[b] = that row
-int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows) {
-    if (p->f32 == 2) return tower_forward_x3(p, x, B, ws, st, last_rows);
-    const int w = p->width, S = p->seq, M = B * S;
-    const size_t Mp = keds_align_up((size_t)M, 256);
+// pk (nullable): packed rows of a causal tower with a read-out row per sample (keds_common.h) -- M = pk->rows, last_rows global
+int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows,
+                           const PackedRows* pk) {
+    if (pk && (!p->causal || !last_rows)) {
+        keds_set_error("keds_tower_forward_f32: packed rows need a causal tower with a read-out row per sample");
+        return KEDS_E_ARG;
+    }
+    if (p->f32 == 2) return tower_forward_x3(p, x, B, ws, st, last_rows, pk);
+    const int w = p->width, S = p->seq, M = pk ? pk->rows : B * S;
+    const size_t Mp = keds_align_up((size_t)B * S, 256);          // (the buffers are carved for the rectangular layout either way)
+    const int32_t* soff = pk ? pk->off : nullptr;
+    const int gbound = pk ? pk->valid : S;
     char* base = (char*)ws;
     float* ln = (float*)base;
     float* qkv = (float*)(base + keds_align_up(Mp * w * 4, 256));
     float* att = (float*)((char*)qkv + keds_align_up(Mp * (size_t)w * 3 * 4, 256));
     float* hid = (float*)((char*)att + keds_align_up(Mp * (size_t)w * 4, 256));
     int rc;
+    // packed rows: the zero rows behind the last sample are nobody's queries -- their attention output is cleared once so that they
+    // stay finite through the blocks
+    if (pk && pk->rows > pk->valid &&
+        hipMemsetAsync(att + (size_t)pk->valid * w, 0, (size_t)(pk->rows - pk->valid) * w * sizeof(float), st) != hipSuccess) {
+        keds_set_error("keds_tower_forward_f32: packed rows: %s", hipGetErrorString(hipGetLastError()));
+        return KEDS_E_LAUNCH;
+    }
     for (int l = 0; l < p->layers; ++l) {
         const keds_block_params& k = p->blocks[l];
         const bool last = l == p->layers - 1;
@@ -449,11 +484,11 @@ int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws
         if (last && last_rows) {
             // after the last block only the read-out row of every sample is read (model.py:587-589, 847-849): attention on all
             // rows, then out-proj, ln_2 and the MLP on the B gathered rows (compact [B, w] buffers in the qkv buffer)
-            if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
+            if ((rc = attention_f32_impl(qkv, att, B, S, p->heads, p->causal, S, soff, st))) return rc;
             float* att_c = qkv;
             float* x_c = qkv + (size_t)B * w;
-            if ((rc = keds_gather_rows_impl(att, att_c, last_rows, S, B, w, 2, st))) return rc;
-            if ((rc = keds_gather_rows_impl(x, x_c, last_rows, S, B, w, 2, st))) return rc;
+            if ((rc = keds_gather_rows_impl(att, att_c, last_rows, gbound, B, w, 2, st, pk != nullptr))) return rc;
+            if ((rc = keds_gather_rows_impl(x, x_c, last_rows, gbound, B, w, 2, st, pk != nullptr))) return rc;
             if ((rc = keds_gemm_f32(att_c, w, out_w, k.out_b, x_c, w, B, w, w, F32_EPI_RESID, nullptr, 0, st))) return rc;
             if ((rc = keds_layernorm_impl(x_c, w, nullptr, 1, k.ln2_g, k.ln2_b, ln, 1, B, w, st))) return rc;
             if ((rc = keds_gemm_f32(ln, w, fc_w, k.fc_b, hid, 4 * w, B, 4 * w, w, F32_EPI_QGELU, nullptr, 0, st))) return rc;
@@ -474,7 +509,7 @@ int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws
             if ((rc = keds_gemm_f32(ln, w, fc_w, k.fc_b, hid, 4 * w, B, 4 * w, w, F32_EPI_QGELU, nullptr, 0, st))) return rc;
             return keds_gemm_f32(hid, 4 * w, proj_w, k.proj_b, x, ldr, B, w, 4 * w, F32_EPI_RESID, nullptr, 0, st);
         }
-        if ((rc = keds_attention_f32(qkv, att, B, S, p->heads, p->causal, S, st))) return rc;
+        if ((rc = attention_f32_impl(qkv, att, B, S, p->heads, p->causal, S, soff, st))) return rc;
         if ((rc = keds_gemm_f32(att, w, out_w, k.out_b, x, w, M, w, w, F32_EPI_RESID, nullptr, 0, st))) return rc;
         if ((rc = keds_layernorm_impl(x, w, nullptr, 1, k.ln2_g, k.ln2_b, ln, 1, M, w, st))) return rc;
         if ((rc = keds_gemm_f32(ln, w, fc_w, k.fc_b, hid, 4 * w, M, 4 * w, w, F32_EPI_QGELU, nullptr, 0, st))) return rc;

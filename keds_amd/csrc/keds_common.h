@@ -31,6 +31,15 @@ inline const char* keds_exp_env(const char* name) { return getenv(name); }
 inline const char* keds_exp_env(const char*) { return nullptr; }
 #endif
 
+// Packed rows of a causal tower (round 6, keds_text_run_packed): sample b owns rows [off[b], off[b + 1]) of every activation buffer
+// instead of [b S, (b + 1) S).  The GEMMs and LayerNorm statistics are row-wise and do not care; the attention kernels and the
+// read-out-row gather take the offsets (towers.hip, f32path.hip).
+struct PackedRows {
+    const int32_t* off;     // device int32 [B + 1]
+    int rows;               // rows the tower runs (whole 256-row tiles where the workspace allows)
+    int valid;              // off[B]: rows [valid, rows) belong to no sample -- zero rows, kept finite (the attention never writes them)
+};
+
 // ---- error plumbing (host) ---------------------------------------------------------
 void keds_set_error(const char* fmt, ...);
 int keds_check_launch(const char* what);

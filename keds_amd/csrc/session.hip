@@ -645,7 +645,7 @@ extern "C" int keds_text_forward_packed(keds_text* txt, const int32_t* tokens, c
     // (pageable source: the copy has left `host` when the call returns)
     HIP_TRY(hipMemcpyAsync(txt->tok.p, host.data(), host.size() * sizeof(int32_t), hipMemcpyHostToDevice, st), what);
     const int32_t* dev = (const int32_t*)txt->tok.p;
-    const bool packed = txt->p.tower.causal && !txt->p.tower.fp8 && !txt->p.tower.f32 && keds_text_trim_mode() == 1 &&
+    const bool packed = txt->p.tower.causal && !txt->p.tower.fp8 && keds_text_trim_mode() == 1 &&
                         rows * 8 <= (long long)B * seq_used * 7;
     KEDS_REQUIRE((img_tokens == nullptr) == (n_img_tok == 0), "%s: img_tokens and n_img_tok disagree", what);
     KEDS_REQUIRE(n_img_tok == 0 || n_img_tok == 2 || n_img_tok == 3, "%s: 2 or 3 pseudo tokens (model.py:831-834)", what);

@@ -17,21 +17,13 @@ int keds_embed_tokens_impl(const int32_t* tokens, const float* table, const floa
                            int n_tok, int insert_col, float* x, int B, int L, int Lx, int d, void* stream,
                            const int32_t* seq_off = nullptr);
 
-// Packed rows of a causal tower (round 6, keds_text_run_packed): sample b owns rows [off[b], off[b + 1]) of every activation buffer
-// instead of [b S, (b + 1) S); `rows` = off[B] on the host.  The GEMMs and LayerNorm statistics are row-wise and do not care; the
-// attention and the read-out-row gather take the offsets.
-struct PackedRows {
-    const int32_t* off;     // device int32 [B + 1]
-    int rows;               // rows the tower runs (whole 256-row tiles where the workspace allows)
-    int valid;              // off[B]: rows [valid, rows) belong to no sample -- zero rows, kept finite (the attention never writes them)
-};
-
 bool keds_gemm_splits_rows(int M, int N, int K);   // gemm.hip
 void keds_gemm_small_lds(int on);                  // gemm.hip: small GEMM launches of this thread take the 64 KiB-LDS kernel form
 
 // f32path.hip: the fp32-accurate flow (keds_tower_params.f32)
 size_t keds_tower_f32_workspace_bytes(int width, int seq, int B);
-int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows = nullptr);
+int keds_tower_forward_f32(const keds_tower_params* p, float* x, int B, void* ws, hipStream_t st, const int32_t* last_rows = nullptr,
+                           const PackedRows* pk = nullptr);
 size_t keds_readout_f32_workspace_bytes(int B, int d);
 int keds_readout_f32(const float* x, int S, const int32_t* row, const float* gamma, const float* beta, const float* proj_t,
                      float* out, int B, int d, int E, int normalize, void* workspace, hipStream_t st);
@@ -647,8 +639,8 @@ extern "C" int keds_text_run_ex(const keds_text_params* p, const int32_t* tokens
 // columns 10 .. 42) 6.9 k instead of 11 k rows for the dual workload's 2B-row pass, whole rounds of workgroups fewer in every GEMM.
 //   seq_off         device int32 [B + 1]: 0 = seq_off[0] <= ... <= seq_off[B] = rows_total, 1 <= len_b <= seq_max
 //   readout_global  device int32 [B]: seq_off[b] + the read-out column of sample b (a row outside [0, rows_total) comes out as NaN)
-// Causal bf16 towers with the read-out-row tail (the default flow); anything else (fp8 / fp32 towers, KEDS_TEXT_TRIM=0) is the
-// caller's to route through keds_text_run_ex.
+// Causal bf16 / fp32 / fp32x3 towers with the read-out-row tail (the default flow); anything else (the MXFP8 tower,
+// KEDS_TEXT_TRIM=0) is the caller's to route through keds_text_run_ex.
 extern "C" int keds_text_run_packed(const keds_text_params* p, const int32_t* tokens, const int32_t* seq_off,
                                     const int32_t* readout_global, int rows_total, int seq_max, const float* img_tokens, int n_tok,
                                     int insert_col, int B, float* out, int normalize, void* workspace, size_t workspace_bytes,
@@ -658,7 +650,7 @@ extern "C" int keds_text_run_packed(const keds_text_params* p, const int32_t* to
     if (rc) return rc;
     KEDS_REQUIRE(p->embed_dim % 128 == 0, "keds_text_run_packed: embed_dim must be a multiple of 128");
     const int w = p->tower.width, L = p->tower.seq;
-    KEDS_REQUIRE(p->tower.causal && !p->tower.fp8 && !p->tower.f32, "keds_text_run_packed: a causal bf16 tower only");
+    KEDS_REQUIRE(p->tower.causal && !p->tower.fp8, "keds_text_run_packed: a causal bf16 / fp32 / fp32x3 tower (the MXFP8 tower keeps the rectangular layout)");
     KEDS_REQUIRE(keds_text_trim_mode() == 1, "keds_text_run_packed: the A/B flows of keds_text_trim_enable / KEDS_TEXT_TRIM=0 go through keds_text_run_ex");
     KEDS_REQUIRE(seq_max >= 1 && seq_max <= L && rows_total >= B && (long long)rows_total <= (long long)B * seq_max,
                  "keds_text_run_packed: rows_total %d / seq_max %d do not fit B = %d sequences of <= %d columns", rows_total, seq_max, B, L);
@@ -683,6 +675,11 @@ extern "C" int keds_text_run_packed(const keds_text_params* p, const int32_t* to
     if ((rc = keds_embed_tokens_impl(tokens, p->token_emb, p->pos_emb, img_tokens, n_tok, insert_col, v.x, B, L, seq_max, w, stream, seq_off)))
         return rc;
     const PackedRows pk{seq_off, rows_run, rows_total};
+    if (tp.f32) {
+        if ((rc = keds_tower_forward_f32(&tp, v.x, B, v.tower, (hipStream_t)stream, readout_global, &pk))) return rc;
+        return keds_readout_f32(v.x, 1, nullptr, p->ln_final_g, p->ln_final_b, (const float*)p->proj_t, out, B, w, p->embed_dim, normalize,
+                                v.ro, (hipStream_t)stream);
+    }
     if ((rc = tower_forward(&tp, v.x, B, v.tower, (hipStream_t)stream, false, readout_global, &pk))) return rc;
     return keds_readout(v.x, 1, nullptr, p->ln_final_g, p->ln_final_b, p->proj_t, out, B, w, p->embed_dim, normalize, v.ro,
                         keds_readout_workspace_bytes(B, w), stream);

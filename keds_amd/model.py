@@ -469,11 +469,11 @@ class CLIP(nn.Module):
         # ... and columns to the right of a caption's OWN read-out column cannot reach that caption's read-out: when the captions of
         # a batch end at different columns the tower runs on PACKED rows, sample b owning len_b = read-out column + 1 of them
         # (keds_text_run_packed, round 6) -- sum(len_b) rows instead of B * max(len_b).  Worth it from an eighth fewer rows; the
-        # bf16 flows only (the fp8 / fp32 towers and KEDS_TEXT_TRIM=0 keep the rectangular layout).
+        # MXFP8 tower and KEDS_TEXT_TRIM=0 keep the rectangular layout.
         lens = readout.to(torch.int64).cpu() + 1
         rows_total = int(lens.sum())
         packed = None
-        if self.precision == "bf16" and TEXT_PACKED and lib.keds_text_trim_mode() == 1 and rows_total * 8 <= B * seq_used * 7:
+        if self.precision != "fp8" and TEXT_PACKED and lib.keds_text_trim_mode() == 1 and rows_total * 8 <= B * seq_used * 7:
             off = torch.zeros(B + 1, dtype=torch.int64)
             off[1:] = torch.cumsum(lens, 0)
             both = torch.cat([off, off[:-1] + readout.to(torch.int64).cpu()]).to(torch.int32)
@@ -484,7 +484,7 @@ class CLIP(nn.Module):
             nbytes = lib.keds_text_workspace_bytes(C.byref(eng.text), B)
             ws = self._ws.get(nbytes, eng.device)
             out = torch.empty((B, self.embed_dim), dtype=torch.float32, device=eng.device)
-            if packed is not None and self.precision == "bf16":
+            if packed is not None and self.precision != "fp8":
                 check(lib.keds_text_run_packed(C.byref(eng.text), ptr(tok), ptr(packed[0]), ptr(packed[1]), rows_total, seq_used,
                                                ptr(it), n_tok, int(insert_col), B, ptr(out), 1 if normalize else 0, ptr(ws),
                                                ws.numel(), stream()), "keds_text_run_packed")

@@ -477,11 +477,14 @@ def test_text_tower_on_packed_rows_equals_the_rectangular_layout(size, tiny_mode
         m = keds_amd.build_model(sd, fp16=False).cuda()
         del sd
         d = 768
-    m.set_precision("bf16")
     L, star = 77, 7
     rs = np.random.RandomState(5)
     try:
+      for precision in ("bf16", "fp32x3", "fp32"):
+        m.set_precision(precision)
         for tag, B, eots in (("mixed", 128, [9, 40, 12, 30, 41, 8]), ("wide", 37, [6, 73, 20, 33]), ("two", 2, [10, 50])):
+            if precision != "bf16" and (tag != "wide" or (size == "vitl" and precision == "fp32")):
+                continue                                    # the fp32-grade flows: one ragged case (fp32x3 at both sizes, fp32 on the tiny model)
             text = _ragged_tokens(B, L, eots, m.end_id, star, m.vocab_size)
             tok3 = torch.from_numpy(rs.standard_normal((B, 3, d)).astype(np.float32) * 0.05).cuda()
             calls = {
@@ -497,11 +500,17 @@ def test_text_tower_on_packed_rows_equals_the_rectangular_layout(size, tiny_mode
                 M.TEXT_PACKED = False
                 b = fn().clone()
                 c, r = min_cosine(a, b), rel_l2(a, b)
-                report("text_packed_vs_rectangular", size=size, case=tag, call=name, B=B, bit_equal=bool(torch.equal(a, b)), min_cosine=c, rel_l2=r)
-                if size == "tiny":
+                report("text_packed_vs_rectangular", size=size, precision=precision, case=tag, call=name, B=B,
+                       bit_equal=bool(torch.equal(a, b)), min_cosine=c, rel_l2=r)
+                assert m.precision == precision                               # (no fp32x3 range trip on the zero rows behind the last sample)
+                if precision != "bf16":
+                    assert r <= (2e-6 if precision == "fp32" else 1e-5), (size, precision, tag, name, r)
+                elif size == "tiny":
                     assert torch.equal(a, b), (size, tag, name, c, r)
                 else:
                     assert c >= 0.99998 and r <= 6e-3, (size, tag, name, c, r)
+      m.set_precision("bf16")
+      if True:
         if size == "tiny":       # the fp32-stream flow (stand-alone LayerNorm: set_numerics("safe") / KEDS_DETERMINISTIC=1) packs as well
             m.set_numerics("safe")
             text = _ragged_tokens(40, L, [9, 40, 12, 30, 41, 8], m.end_id, star, m.vocab_size)
@@ -514,6 +523,7 @@ def test_text_tower_on_packed_rows_equals_the_rectangular_layout(size, tiny_mode
     finally:
         M.TEXT_PACKED = True
         m.set_numerics("auto")
+        m.set_precision("bf16")
 
 
 def test_text_readout_row_outside_the_declared_cut_comes_out_as_nan(tiny_model):

@@ -20,6 +20,7 @@ KEDS_BENCH_INJECT_FAULT=2 timeout 300 python bench.py --steps 5 --warmup 1 --no-
 timeout 300 python tools/bench_train.py > $O/r06_bench_train.json 2>/dev/null; echo "train rc=$?"
 timeout 900 bash tools/profile_round.sh r06_final > $O/profile_round.log 2>&1; echo "profile rc=$?"; tail -4 $O/profile_round.log
 cp gpurun_out/r06_final_* $O/ 2>/dev/null
+timeout 600 bash tools/pmc_l2.sh r06 > $O/pmc_l2.log 2>&1; echo "pmc l2 rc=$?"; cp gpurun_out/r06_pmc_l2.json $O/ 2>/dev/null
 timeout 300 bash tools/kstats_cmd.sh bench.py --workload dual --steps 8 --warmup 2 --no-cpu-baseline --no-verify 2>&1 | grep -v "amdgpu.ids\|^E2026\|^W2026" > $O/r06_dual_kstats.txt
 timeout 300 bash tools/kstats_cmd.sh bench.py --precision fp8 --steps 8 --warmup 2 --no-cpu-baseline --no-verify --no-legs 2>&1 | grep -v "amdgpu.ids\|^E2026\|^W2026" > $O/r06_fp8_kstats.txt
 timeout 300 bash tools/kstats_cmd.sh bench.py --precision fp32x3 --steps 6 --warmup 2 --no-cpu-baseline --no-verify --no-legs 2>&1 | grep -v "amdgpu.ids\|^E2026\|^W2026" > $O/r06_x3_kstats.txt
