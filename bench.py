@@ -135,6 +135,44 @@ def cpu_threads():
     return max(1, min(ncpu // 2 if ncpu >= 16 else ncpu, 128))
 
 
+def pin_host_threads(n):
+    """Best effort: confine this process (and the oracle's OpenMP pool with it) to `n` hardware threads of ONE NUMA node, one per
+    physical core, for the duration of the CPU leg -- on a two-socket host shared with other jobs most of the run-to-run spread of
+    the oracle is threads migrating between sockets and onto busy SMT siblings.  Returns (previous affinity or None, the CPUs
+    chosen or None); restore with os.sched_setaffinity(0, previous)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+
+        def cpulist(path):
+            out = []
+            for part in open(path).read().strip().split(","):
+                a, _, b = part.partition("-")
+                out += list(range(int(a), int(b or a) + 1))
+            return out
+        best = None
+        import glob
+        for node in sorted(glob.glob("/sys/devices/system/node/node[0-9]*")):
+            cpus = [c for c in cpulist(node + "/cpulist") if c in allowed]
+            cores, seen = [], set()
+            for c in cpus:                                   # one hardware thread per physical core
+                sib = tuple(cpulist(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list"))
+                if sib not in seen:
+                    seen.add(sib)
+                    cores.append(c)
+            if best is None or len(cores) > len(best):
+                best = cores
+            if len(cores) >= n:
+                best = cores
+                break
+        if not best or len(best) < max(2, n // 2):
+            return None, None
+        chosen = best[:n]
+        os.sched_setaffinity(0, chosen)
+        return allowed, chosen
+    except Exception:                                         # noqa: BLE001  (no sysfs, no permission: run unpinned)
+        return None, None
+
+
 def _vit_sd(model):
     sd = {k_: v.detach().float().cpu() for k_, v in model.state_dict().items() if k_.startswith("visual.")}
     for k_ in ("text_projection", "positional_embedding", "token_embedding.weight", "ln_final.weight"):
@@ -183,6 +221,7 @@ def cpu_baseline(model, n_db, dim, k):
                 pilot[(nb, threads)] = min(ts)
         (nb, threads), _ = min(pilot.items(), key=lambda kv: kv[1])
         torch.set_num_threads(threads)
+        prev_aff, pinned = pin_host_threads(threads)
         img = img_all[:nb]
 
         def one():
@@ -212,11 +251,14 @@ def cpu_baseline(model, n_db, dim, k):
             O.flat_l2_search_f32(db, q, k)
             tq.append((time.perf_counter() - t0) / q.shape[0] * (n_db / rows))
         t_q = statistics.median(tq)
+        if prev_aff is not None:
+            os.sched_setaffinity(0, prev_aff)
     mid = sorted(ts)[1:-1] if len(ts) >= 7 else ts
     spread = (max(mid) - min(mid)) / t_img
     spread_all = (max(ts) - min(ts)) / t_img
     rec = {"value": 1.0 / (t_img + t_q), "unit": "query-images/sec", "cores": threads, "kind": "port",
            "setting": {"batch": nb, "threads": threads, "host_threads": ncpu, "physical_cores_assumed": phys,
+                       "pinned_to_cpus": (f"{pinned[0]}..{pinned[-1]} ({len(pinned)} hardware threads of one NUMA node, one per core)" if pinned else None),
                        "pilot_ms_per_image_of_one_block": {f"B{b}xT{t}": round(v * 1e3, 2) for (b, t), v in sorted(pilot.items())}},
            "warmup_s_per_image": [round(t, 3) for t in warm], "settled_within_5pct": bool(settled),
            "runs_s_per_image": [round(t, 3) for t in ts], "spread_over_median": round(spread, 3),
