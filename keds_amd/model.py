@@ -424,6 +424,13 @@ class CLIP(nn.Module):
         B = img.shape[0]
         if B == 0:                                    # an empty last batch of a loader: the reference returns [0, embed_dim]
             return torch.empty((0, self.embed_dim), dtype=self.dtype, device=eng.device)
+        if self.precision == "fp32x3":
+            # the split-operand GEMMs address their planes with 32-bit byte offsets (keds_gemm_x3): the MLP hidden planes of one call
+            # must stay below 2 GiB -- rows * 4 * width * 2 bytes.  Larger batches run in chunks (rows are independent between samples).
+            rows_max = (1 << 31) // (8 * self.visual.transformer.width) - 512
+            chunk = max(1, rows_max // ((self.visual.input_resolution // self.visual.conv1.kernel_size[0]) ** 2 + 1))
+            if B > chunk:
+                return torch.cat([self.encode_image(img[i:i + chunk], normalize=normalize) for i in range(0, B, chunk)])
         lib = load()
 
         def run(eng):
@@ -470,6 +477,11 @@ class CLIP(nn.Module):
         # a batch end at different columns the tower runs on PACKED rows, sample b owning len_b = read-out column + 1 of them
         # (keds_text_run_packed, round 6) -- sum(len_b) rows instead of B * max(len_b).  Worth it from an eighth fewer rows; the
         # MXFP8 tower and KEDS_TEXT_TRIM=0 keep the rectangular layout.
+        if self.precision == "fp32x3":                       # (see encode_image: the planes of one call stay below 2 GiB)
+            chunk = max(1, ((1 << 31) // (8 * self.transformer.width) - 512) // self.context_length)
+            if B > chunk:
+                return torch.cat([self._run_text(text[i:i + chunk], readout[i:i + chunk], None if img_tokens is None else img_tokens[i:i + chunk],
+                                                 insert_col, normalize) for i in range(0, B, chunk)])
         lens = readout.to(torch.int64).cpu() + 1
         rows_total = int(lens.sum())
         packed = None

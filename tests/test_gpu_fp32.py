@@ -442,3 +442,18 @@ def test_gemm_x3_small_magnitude_weights_keep_fp32_grade(std):
     pre = a.double() @ w_big.double().t() + bb.double()
     gelu = pre * torch.sigmoid(1.702 * pre)
     assert rel_l2(pair[0, :M].double() + pair[1, :M].double(), gelu) <= 3e-6
+
+
+def test_fp32x3_batches_beyond_the_plane_offset_limit_run_in_chunks():
+    """The split-operand GEMMs address their operand planes with 32-bit byte offsets: the MLP hidden planes of one tower call must
+    stay below 2 GiB, i.e. B <= 1,018 images at ViT-L/14.  Round 5 raised a RuntimeError beyond that (the advisor's finding);
+    encode_image now runs such a batch in chunks -- rows are independent between samples, so the result is the concatenation of
+    the chunks' results, bit for bit."""
+    sd = O.synth_clip_state_dict(**VITL, seed=7, visual_only=True)
+    m = keds_amd.build_model(sd, fp16=False).cuda().set_precision("fp32x3")
+    del sd
+    B = 1030
+    img = torch.randn(B, 3, 224, 224, generator=torch.Generator(device="cuda").manual_seed(11), device="cuda")
+    out = m.encode_image(img)
+    assert m.precision == "fp32x3" and out.shape == (B, 768) and bool(torch.isfinite(out).all())
+    assert torch.equal(out[:1018], m.encode_image(img[:1018])) and torch.equal(out[1018:], m.encode_image(img[1018:]))
