@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6: tile-switch arrangement of the 4-wave MXFP8 kernel, same box: the round-5 kernel, then this round's with each piece off
+# (needs the older kernel beside it, which is not kept in the tree: before the gpurun call, in the build container:
+#  mkdir -p tools/ab_old && git show <commit of the older kernel>:keds_amd/csrc/gemm_fp8.hip > tools/ab_old/gemm_fp8_r05.hip -- round 6 used 235db3d / the commit before the scale-LDS experiment)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r06; mkdir -p $O
 build() { (cd keds_amd/csrc && make -j8 EXTRA="$1" > /tmp/mk.log 2>&1) || { echo "BUILD FAILED: $1"; tail -5 /tmp/mk.log; return 1; }; }

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6: MX scale bytes through LDS (whole-dword stores) against the previous kernel, alone and in the step, same box
+# (needs the older kernel beside it, which is not kept in the tree: before the gpurun call, in the build container:
+#  mkdir -p tools/ab_old && git show <commit of the older kernel>:keds_amd/csrc/gemm_fp8.hip > tools/ab_old/gemm_fp8_prev.hip -- round 6 used b4a0f71^ / the commit before the scale-LDS experiment)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r06; mkdir -p $O
 build() { (cd keds_amd/csrc && make -j8 EXTRA="$1" > /tmp/mk.log 2>&1) || { echo "BUILD FAILED: $1"; tail -5 /tmp/mk.log; return 1; }; }
