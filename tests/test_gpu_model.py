@@ -467,7 +467,8 @@ def test_text_tower_on_packed_rows_equals_the_rectangular_layout(size, tiny_mode
     [0, read-out column] only.  keds_text_run_packed gives every sample exactly those rows (sum of the lengths instead of
     B x the longest); the GEMMs and LayerNorm statistics are row-wise, the attention takes per-sample offsets.  Same arithmetic per
     row as the rectangular layout (rows only land in other tiles): equal bits on the tiny model, the batch-size sweep's class at
-    ViT-L/14 width (other tile shapes / split-K).  Every text entry point, ragged read-out columns from 6 to 73."""
+    ViT-L/14 width (other tile shapes / split-K); the fp32-grade flows within their own tolerance.  Every text entry point, ragged
+    read-out columns from 6 to 73; the fp32-stream flow (set_numerics("safe")) packs as well."""
     import keds_amd.model as M
     if size == "tiny":
         _, sd, m = tiny_model
@@ -479,47 +480,46 @@ def test_text_tower_on_packed_rows_equals_the_rectangular_layout(size, tiny_mode
         d = 768
     L, star = 77, 7
     rs = np.random.RandomState(5)
+
+    def both_layouts(fn):
+        M.TEXT_PACKED = True
+        a = fn().clone()
+        assert torch.equal(a, fn()) and torch.isfinite(a).all()
+        M.TEXT_PACKED = False
+        return a, fn().clone()
     try:
-      for precision in ("bf16", "fp32x3", "fp32"):
-        m.set_precision(precision)
-        for tag, B, eots in (("mixed", 128, [9, 40, 12, 30, 41, 8]), ("wide", 37, [6, 73, 20, 33]), ("two", 2, [10, 50])):
-            if precision != "bf16" and (tag != "wide" or (size == "vitl" and precision == "fp32")):
-                continue                                    # the fp32-grade flows: one ragged case (fp32x3 at both sizes, fp32 on the tiny model)
-            text = _ragged_tokens(B, L, eots, m.end_id, star, m.vocab_size)
-            tok3 = torch.from_numpy(rs.standard_normal((B, 3, d)).astype(np.float32) * 0.05).cuda()
-            calls = {
-                "encode_text": lambda: m.encode_text(text.cuda()),
-                "eti3": lambda: m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False),
-                "eti2": lambda: m.encode_text_img_retrieval(text, tok3[:, :2].contiguous(), split_ind=star, repeat=False),
-                "eti_train3": lambda: m.encode_text_img_train(text.cuda(), tok3, split_ind=star),
-            }
-            for name, fn in calls.items():
-                M.TEXT_PACKED = True
-                a = fn().clone()
-                assert torch.equal(a, fn()) and torch.isfinite(a).all(), (size, tag, name)
-                M.TEXT_PACKED = False
-                b = fn().clone()
-                c, r = min_cosine(a, b), rel_l2(a, b)
-                report("text_packed_vs_rectangular", size=size, precision=precision, case=tag, call=name, B=B,
-                       bit_equal=bool(torch.equal(a, b)), min_cosine=c, rel_l2=r)
-                assert m.precision == precision                               # (no fp32x3 range trip on the zero rows behind the last sample)
-                if precision != "bf16":
-                    assert r <= (2e-6 if precision == "fp32" else 1e-5), (size, precision, tag, name, r)
-                elif size == "tiny":
-                    assert torch.equal(a, b), (size, tag, name, c, r)
-                else:
-                    assert c >= 0.99998 and r <= 6e-3, (size, tag, name, c, r)
-      m.set_precision("bf16")
-      if True:
-        if size == "tiny":       # the fp32-stream flow (stand-alone LayerNorm: set_numerics("safe") / KEDS_DETERMINISTIC=1) packs as well
+        for precision in ("bf16", "fp32x3", "fp32"):
+            m.set_precision(precision)
+            for tag, B, eots in (("mixed", 128, [9, 40, 12, 30, 41, 8]), ("wide", 37, [6, 73, 20, 33]), ("two", 2, [10, 50])):
+                if precision != "bf16" and (tag != "wide" or (size == "vitl" and precision == "fp32")):
+                    continue                    # the fp32-grade flows: one ragged case (fp32x3 at both sizes, fp32 on the tiny model)
+                text = _ragged_tokens(B, L, eots, m.end_id, star, m.vocab_size)
+                tok3 = torch.from_numpy(rs.standard_normal((B, 3, d)).astype(np.float32) * 0.05).cuda()
+                calls = {
+                    "encode_text": lambda: m.encode_text(text.cuda()),
+                    "eti3": lambda: m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False),
+                    "eti2": lambda: m.encode_text_img_retrieval(text, tok3[:, :2].contiguous(), split_ind=star, repeat=False),
+                    "eti_train3": lambda: m.encode_text_img_train(text.cuda(), tok3, split_ind=star),
+                }
+                for name, fn in calls.items():
+                    a, b = both_layouts(fn)
+                    c, r = min_cosine(a, b), rel_l2(a, b)
+                    report("text_packed_vs_rectangular", size=size, precision=precision, case=tag, call=name, B=B,
+                           bit_equal=bool(torch.equal(a, b)), min_cosine=c, rel_l2=r)
+                    assert m.precision == precision         # (no fp32x3 range trip on the zero rows behind the last sample)
+                    if precision != "bf16":
+                        assert r <= (2e-6 if precision == "fp32" else 1e-5), (size, precision, tag, name, r)
+                    elif size == "tiny":
+                        assert torch.equal(a, b), (size, tag, name, c, r)
+                    else:
+                        assert c >= 0.99998 and r <= 6e-3, (size, tag, name, c, r)
+        m.set_precision("bf16")
+        if size == "tiny":
             m.set_numerics("safe")
             text = _ragged_tokens(40, L, [9, 40, 12, 30, 41, 8], m.end_id, star, m.vocab_size)
             tok3 = torch.from_numpy(rs.standard_normal((40, 3, d)).astype(np.float32) * 0.05).cuda()
-            M.TEXT_PACKED = True
-            a = m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False).clone()
-            M.TEXT_PACKED = False
-            b = m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False).clone()
-            assert torch.isfinite(a).all() and torch.equal(a, b)
+            a, b = both_layouts(lambda: m.encode_text_img_retrieval(text.cuda(), tok3, split_ind=star, repeat=False))
+            assert torch.equal(a, b)
     finally:
         M.TEXT_PACKED = True
         m.set_numerics("auto")
