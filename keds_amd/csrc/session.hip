@@ -192,6 +192,23 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
             (rc = L.vec(b + "attn.out_proj.bias", width, &p.out_b)) ||
             (rc = L.vec(b + "mlp.c_fc.bias", 4 * width, &p.fc_b)) || (rc = L.vec(b + "mlp.c_proj.bias", width, &p.proj_b)))
             return rc;
+        if (f32 == 2) {      // fp32x3: every weight as its fp16 planes; the fp32 copies are temporary (round 5 kept them: 1.2 GB for ViT-L/14)
+            const char* names[4] = {"attn.in_proj_weight", "attn.out_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight"};
+            const void** slots[4] = {&p.qkv_w, &p.out_w, &p.fc_w, &p.proj_w};
+            const int n[4] = {3 * width, width, 4 * width, width}, k[4] = {width, width, width, 4 * width};
+            for (int j = 0; j < 4; ++j) {
+                Arena tmp;
+                Loader T{L.w, tmp, L.what};
+                const float* f;
+                if ((rc = T.mat<float>(b + names[j], n[j], k[j], &f))) return rc;
+                void* planes = L.mem.alloc((size_t)2 * n[j] * k[j] * 2);
+                KEDS_REQUIRE(planes, "%s: out of device memory", L.what);
+                if ((rc = keds_split_f16_weight(f, n[j], k[j], planes, (int64_t)n[j] * k[j], &p.x3_exp[j], nullptr))) return rc;
+                *slots[j] = planes;
+                HIP_TRY(hipDeviceSynchronize(), L.what);            // (the split has read `f` before tmp frees it)
+            }
+            continue;
+        }
         if (f32) {   // KEDS_F32 compute (the fp32-accurate flow, f32path.hip): the four weights stay fp32, nothing is folded
             const float* f;
             if ((rc = L.mat<float>(b + "attn.in_proj_weight", 3 * width, width, &f))) return rc;
@@ -202,18 +219,6 @@ int load_blocks(const Loader& L, const std::string& prefix, int width, int layer
             p.fc_w = f;
             if ((rc = L.mat<float>(b + "mlp.c_proj.weight", width, 4 * width, &f))) return rc;
             p.proj_w = f;
-            if (f32 == 2) {      // split every weight into its fp16 planes (the fp32 copies stay in the arena: 1.2 GB for ViT-L/14)
-                const void** slots[4] = {&p.qkv_w, &p.out_w, &p.fc_w, &p.proj_w};
-                const int n[4] = {3 * width, width, 4 * width, width}, k[4] = {width, width, width, 4 * width};
-                for (int j = 0; j < 4; ++j) {
-                    void* planes = L.mem.alloc((size_t)2 * n[j] * k[j] * 2);
-                    KEDS_REQUIRE(planes, "%s: out of device memory", L.what);
-                    if ((rc = keds_split_f16_weight((const float*)*slots[j], n[j], k[j], planes, (int64_t)n[j] * k[j], &p.x3_exp[j], nullptr)))
-                        return rc;
-                    *slots[j] = planes;
-                }
-                HIP_TRY(hipDeviceSynchronize(), L.what);
-            }
             continue;
         }
         if ((rc = L.mat<bf16_t>(b + "attn.in_proj_weight", 3 * width, width, &m))) return rc;
